@@ -1,0 +1,262 @@
+/*
+ * semseg_hip.h -- C ABI of libsemseg_hip.so, the gfx950 (MI355X / CDNA4) kernel
+ * library underneath the HRNet-OCR-MScale hot path.
+ *
+ * The reference (NVIDIA/semantic-segmentation) has no FFI of its own: every
+ * arithmetic op on the hot path is a PyTorch/cuDNN/apex call made from Python
+ * (SURVEY.md section 2b, rows K1..K15).  Each entry point below replaces one of
+ * those call sites; the reference file:line is cited per function.  The Python
+ * binding is ctypes (semseg_amd/_lib.py): plain pointers, ints and a
+ * hipStream_t passed as void*.  No torch types cross this boundary.
+ *
+ * Conventions
+ *  - every function returns 0 on success, SSA_EINVAL(-1)/SSA_EUNSUPPORTED(-2)
+ *    for bad arguments, or a positive hipError_t.
+ *  - all pointers are DEVICE pointers borrowed for the duration of the call;
+ *    nothing is allocated, freed, retained or synchronised inside the library
+ *    (hipGraph-capture safe, callable from the autograd thread).
+ *  - activations are NHWC.  "ld" arguments are the pixel stride in elements so
+ *    a tensor may be a channel slice of a wider buffer (concat-free writes).
+ *  - bf16 tensors are 16-bit words, 16-byte aligned, channel count % 8 == 0.
+ */
+#ifndef SEMSEG_HIP_H
+#define SEMSEG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSA_OK 0
+#define SSA_EINVAL (-1)
+#define SSA_EUNSUPPORTED (-2)
+
+int ssa_version(void);
+
+/* ------------------------------------------------------------------ conv --
+ * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x16_bf16), NHWC bf16 in,
+ * fp32 accumulate, bf16 or fp32 out.  Replaces nn.Conv2d forward / dgrad /
+ * wgrad at network/hrnetv2.py:31-34,42-45,76-77,270-275 (K1,K2),
+ * network/ocrnet.py:54-58 (K3), network/utils.py:348-357 (K4), every 1x1 in
+ * network/ocr_utils.py:68-93,142-147 (K5) and the dilated ASPP convs at
+ * network/utils.py:192-198 (K6). */
+typedef struct ssa_conv_desc {
+  int B, H, W, Cin;   /* input  [B,H,W,Cin], Cin % 8 == 0                      */
+  int ldx;            /* input pixel stride (elements)                         */
+  int Ho, Wo, Cout;   /* output [B,Ho,Wo,Cout]                                 */
+  int ldy;            /* output pixel stride (elements)                        */
+  int KH, KW;         /* filter taps                                           */
+  int stride, pad, dil;
+  int transposed;     /* 0: iy = oy*stride - pad + kh*dil   (forward)
+                         1: iy = (oy - pad + kh*dil)/stride when divisible
+                            (data-gradient of a strided forward conv)          */
+  int Kpad;           /* row length of the packed filter matrix (multiple of 32) */
+  int out_f32;        /* 0: bf16 output, 1: fp32 output                        */
+  int cfg;            /* tile configuration id, -1 = choose automatically       */
+} ssa_conv_desc;
+
+/* y[m, n] = bias[n] + sum_k A[m, k] * Wp[n, k];  m=(b,oy,ox), k=(kh,kw,ci). */
+int ssa_conv2d_igemm(const ssa_conv_desc* d, const void* x, const void* w_packed,
+                     const float* bias, void* y, void* stream);
+
+/* Filter packing: OIHW fp32 parameter -> bf16 [rows][Kpad] GEMM operand.
+ * mode 0 (forward): rows = Cout, k = (kh,kw,ci) with ci < cin_pad.
+ * mode 1 (dgrad)  : rows = Cin,  k = (kh',kw',co) with co < cout_pad, taps
+ *                   flipped (kh' = KH-1-kh) -- the transposed filter.          */
+int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin,
+                    int KH, int KW, int cin_pad, int cout_pad, int Kpad,
+                    int mode, void* stream);
+
+/* Weight gradient, split over the pixel axis.  partial is
+ * [nsplit][cout_pad][KH*KW*Cin] fp32; ssa_conv2d_wgrad_reduce sums the splits
+ * and writes dW in the parameter's OIHW fp32 layout (cin_real <= d->Cin).    */
+int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit,
+                          size_t* ws_bytes);
+int ssa_conv2d_wgrad(const ssa_conv_desc* d, const void* x, const void* dy,
+                     int lddy, int cout_pad, int nsplit, float* partial,
+                     void* stream);
+int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad,
+                            int Cout, int Cin_pad, int Cin, int KH, int KW,
+                            float* dw_oihw, void* stream);
+
+/* Column sum over pixels: out[c] = sum_p x[p, c]  (bias gradient). x bf16. */
+int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out,
+                    double* scratch2c, void* stream);
+
+/* fp32 [P,C] -> bf16 [P,Cpad] zero padded (gradient of the fp32 heads). */
+int ssa_pad_cast_f32_bf16(const float* x, long P, int C, int ldx, void* y,
+                          int Cpad, void* stream);
+
+/* --------------------------------------------------------------- batchnorm --
+ * Replaces cfg.MODEL.BNFUNC (nn.BatchNorm2d / apex SyncBatchNorm) selected at
+ * config.py:216-225 and instantiated by network/mynn.py:18-24 (K7, C3).      */
+/* sums[0:C] = sum_p x, sums[C:2C] = sum_p x^2 (fp64).  sums is zeroed inside. */
+int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, void* stream);
+/* From (possibly all-reduced) sums and total count: scale/shift for the apply
+ * pass, mean/invstd for backward, running-stat update (momentum, unbiased var).
+ * use_running=1 (eval): scale/shift from running stats, sums ignored.          */
+int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int use_running, float* scale,
+                    float* shift, float* mean, float* invstd, void* stream);
+/* z = post[b,c] * act(scale[c]*x + shift[c] + residual)                       */
+int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
+                 int ldz, long P, int C, const float* scale, const float* shift,
+                 int relu, const float* post, long pix_per_img, void* stream);
+/* backward pass 1: sums[0:C]=sum g, sums[C:2C]=sum g*xhat, g = dz*post*(z>0).  */
+int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz,
+                      const void* z, int ldz, long P, int C, const float* mean,
+                      const float* invstd, int relu, const float* post,
+                      long pix_per_img, double* sums, void* stream);
+/* backward pass 2: dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N);
+ * dres (optional) = g.  sums may have been all-reduced; count is global.     */
+int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
+                     const void* z, int ldz, void* dx, int lddx, void* dres,
+                     int lddres, long P, int C, const float* gamma,
+                     const float* mean, const float* invstd, const double* sums,
+                     double count, int relu, const float* post,
+                     long pix_per_img, void* stream);
+/* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
+int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
+                       void* stream);
+
+/* ----------------------------------------------------------- elementwise ---- */
+/* z = relu?(a + b + c + d); b,c,d optional.  HRNet fuse sum,
+ * network/hrnetv2.py:236-252 (K12). All bf16, dense [n] with n % 8 == 0.      */
+int ssa_sum_act(const void* a, const void* b, const void* c, const void* d,
+                void* z, long n, int relu, void* stream);
+/* g = dz * (z > 0) */
+int ssa_relu_bwd(const void* dz, const void* z, void* g, long n, void* stream);
+/* NCHW fp32 image -> NHWC bf16 with channels zero-padded to cpad.
+ * (train.py:487 hands the module an NCHW fp32 batch.)                         */
+int ssa_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int H, int W,
+                              int cpad, void* stream);
+
+/* ResizeX(images, s) (network/mynn.py:101-114, called at network/ocrnet.py:276)
+ * fused with the layout change: NCHW fp32 [B,C,Hi,Wi] -> NHWC bf16
+ * [B,Ho,Wo,cpad]; Ho==Hi && Wo==Wi is an exact copy.                          */
+int ssa_image_resize_to_nhwc_bf16(const float* x, int B, int C, int Hi, int Wi,
+                                  void* y, int Ho, int Wo, int cpad, void* stream);
+
+/* -------------------------------------------------------------- bilinear ----
+ * F.interpolate(mode='bilinear', align_corners=False): network/mynn.py:42-114,
+ * network/hrnetv2.py:246-249,440-445 (K8).  in_dtype/out_dtype: 0 bf16, 1 f32.
+ * Backward is a deterministic gather (no atomics).                             */
+int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C,
+                     int ldx, void* y, int out_dtype, int Ho, int Wo, int ldy,
+                     void* stream);
+int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
+                     int lddy, void* dx, int dx_dtype, int Hi, int Wi, int lddx,
+                     void* stream);
+
+/* ------------------------------------------------------------------- OCR ----
+ * SpatialGather_Module.forward, network/ocr_utils.py:34-46 (K9) and
+ * ObjectAttentionBlock.forward, network/ocr_utils.py:95-119 (K10).
+ * The matrix products (probs^T @ feats, q @ k^T, sim @ v and their gradients)
+ * run on ssa_conv2d_igemm / ssa_conv2d_wgrad as 1x1 GEMMs whose "filters" are
+ * activations packed by ssa_pack_matrix; the functions below are the two
+ * softmaxes and their backward.
+ *
+ * softmax over HW, per (image, class): logits fp32 [HW, K] (pixel stride ld);
+ * rowstat fp32 [K][2] = (max, sum exp).                                       */
+int ssa_softmax_hw_stats(const float* logits, int ld, long HW, int K,
+                         float* rowstat, void* stream);
+/* probs bf16 [HW, Kpad] (zero padded columns K..Kpad)                         */
+int ssa_softmax_hw_probs(const float* logits, int ld, long HW, int K,
+                         const float* rowstat, void* probs, int Kpad, void* stream);
+/* out[k] = sum_c a[k,c]*b[k,c]                                                */
+int ssa_rowdot_f32(const float* a, const float* b, int K, int C, float* out,
+                   void* stream);
+/* dlogits[p,k] (+)= probs[p,k] * (dprobs[p,k] - dot[k])                        */
+int ssa_softmax_hw_bwd(const float* logits, int ld, long HW, int K,
+                       const float* rowstat, const float* dprobs, int lddp,
+                       const float* dot, float* dlogits, int lddl, int accumulate,
+                       void* stream);
+/* per-pixel softmax over K object regions of scale*sim: sim fp32 [P, K];
+ * probs bf16 [P, Kpad]; backward returns dsim as bf16 [P, Kpad].              */
+int ssa_softmax_lastdim_fwd(const float* sim, int ld, long P, int K, float scale,
+                            void* probs, int Kpad, void* stream);
+int ssa_softmax_lastdim_bwd(const float* sim, int ld, long P, int K, float scale,
+                            const float* dprobs, int lddp, void* dsim, int Kpad,
+                            void* stream);
+/* GEMM operand from an activation matrix: dst bf16 [rows_out][Kpad] = src
+ * (or src^T), zero padded.  src_dtype 0 bf16, 1 fp32; src is [R][C], row
+ * stride ld.                                                                  */
+int ssa_pack_matrix(const void* src, int src_dtype, int R, int C, int ld,
+                    int transpose, void* dst, int rows_out, int Kpad, void* stream);
+
+/* ----------------------------------------------------- scale attention -----
+ * sigmoid of the attention logit (network/utils.py:363) and the two-scale
+ * fusion of MscaleOCR.two_scale_forward, network/ocrnet.py:289-298 (K11):
+ *   joint = up(attn*p_lo) + (1 - up(attn)) * p_hi   (all fp32 NHWC)           */
+int ssa_sigmoid_fwd(const float* x, float* y, long n, void* stream);
+int ssa_sigmoid_bwd(const float* y, const float* dy, float* dx, long n, void* stream);
+/* out[p,c] = a[p]*x[p,c]  (attn broadcast over classes), and its backward.   */
+int ssa_bcast_mul_fwd(const float* a, const float* x, float* out, long P, int C,
+                      void* stream);
+int ssa_bcast_mul_bwd(const float* a, const float* x, const float* dout, float* da,
+                      float* dx, long P, int C, void* stream);
+/* joint[p,c] = lo[p,c] + (1-a[p])*hi[p,c], and its backward.                  */
+int ssa_attn_blend_fwd(const float* lo, const float* a, const float* hi,
+                       float* joint, long P, int C, void* stream);
+int ssa_attn_blend_bwd(const float* a, const float* hi, const float* djoint,
+                       float* da, float* dhi, long P, int C, int accumulate_da,
+                       void* stream);
+
+/* ---------------------------------------------------------------- losses ----
+ * CrossEntropyLoss2d, loss/utils.py:121-134 (K13): mean over valid pixels of
+ * -log_softmax(x)[t], ignore_index skipped.  logits fp32 NHWC [P,C], labels
+ * int64 [P].  acc = {sum nll, valid count} fp64; dlogits (optional) receives
+ * softmax - onehot for valid pixels (un-normalised; scale in ssa_scale_grad).  */
+int ssa_ce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C,
+               int ignore_index, double* acc, float* dlogits, void* stream);
+/* RMILoss.forward_sigmoid part I, loss/rmi.py:91-116 (K14): masked BCE with
+ * logits, sum over pixels and classes; acc = {sum bce, valid count}.
+ * dlogits = (sigmoid(x) - onehot) * mask (un-normalised).                     */
+int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C,
+                double* acc, float* dlogits, void* stream);
+/* loss = acc[0] / (acc[1] + denom_add) ; writes fp32 scalar                    */
+int ssa_loss_finalize(const double* acc, double denom_add, float* loss, void* stream);
+/* g[i] *= upstream[0] * coef / (acc[1] + denom_add)                            */
+int ssa_scale_grad(float* g, long n, const float* upstream, double coef,
+                   const double* acc, double denom_add, void* stream);
+
+/* RMILoss.rmi_lower_bound, loss/rmi.py:139-215 + loss/rmi_utils.py:15-56,
+ * 95-107 (K15).  Fused: sigmoid*mask+1e-6 -> 4x4/4 avg pool (pad 2) ->
+ * 3x3-neighbourhood Gram matrices in fp64 (never materialising the
+ * [B,C,9,65025] stack) -> 9x9 inverse / Cholesky per (b,c) in one wavefront. */
+int ssa_rmi_pool(const float* logits, int ld, const int64_t* labels, int B, int H,
+                 int W, int C, float* pooled_pr, float* pooled_la, int Hp, int Wp,
+                 void* stream);
+int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
+                 int Wp, double* gram /*[BC][189]*/, void* stream);
+/* per (b,c): loss value + gradient matrices G_lp, G_pp (9x9) + means.         */
+int ssa_rmi_solve(const double* gram, int BC, int Hp, int Wp, double* loss_bc,
+                  double* gmat /*[BC][2*81+18]*/, void* stream);
+/* rmi = sum_c mean_b loss_bc / 9  -> fp32 scalar                              */
+int ssa_rmi_finalize(const double* loss_bc, int B, int C, float* out, void* stream);
+/* d rmi / d pooled_pr  [BC][Hp][Wp] fp32                                      */
+int ssa_rmi_bwd_pooled(const float* pooled_pr, const float* pooled_la,
+                       const double* gmat, int BC, int Hp, int Wp, float* dpooled,
+                       void* stream);
+/* dlogits[p,c] += coef*upstream * dpooled[cell(p)]/16 * mask * s*(1-s)        */
+int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B,
+                       int H, int W, int C, const float* dpooled, int Hp, int Wp,
+                       const float* upstream, double coef, float* dlogits,
+                       int accumulate, void* stream);
+
+/* axpy on fp32: y = alpha*x + (accumulate? y : 0) */
+int ssa_axpy_f32(const float* x, float alpha, float* y, long n, int accumulate,
+                 void* stream);
+
+/* ---------------------------------------------------------------- probes ----
+ * Hardware-layout probes used by tests/test_probe_gpu.py (MFMA fragment and
+ * ds_read_b64_tr_b16 lane maps are verified on the device, not assumed).      */
+int ssa_probe_mfma32(const void* a, const void* b, float* c, void* stream);
+int ssa_probe_tr16(unsigned short* out, int mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMSEG_HIP_H */

@@ -1,0 +1,381 @@
+// BatchNorm2d (training + eval) on NHWC bf16 activations, fp32 math, fp64
+// statistics.  Replaces cfg.MODEL.BNFUNC = nn.BatchNorm2d / apex SyncBatchNorm
+// (config.py:216-225, network/mynn.py:18-24).
+//
+// The statistics are exposed as raw fp64 sums so that SyncBN is "all-reduce the
+// 2C sums, pass the global count to ssa_bn_finalize" -- numerically identical to
+// BatchNorm over the concatenated global batch.
+//
+// All passes are HBM-bound streaming kernels: each thread owns one 16-byte
+// channel group (8 channels) and walks pixels with that group fixed, so the
+// per-channel accumulators live in registers and every wave-level access is a
+// contiguous run of 16-byte pieces.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// number of threads of a block that do work: the largest multiple of VC <= NT
+__host__ __device__ inline int active_threads(int VC) { return (NT / VC) * VC; }
+
+// Accumulate per-channel sums for this block into fp64 global sums.
+// v0/v1 hold 8 channels each (this thread's channel group cg).
+__device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v1, int cg, int C,
+                                                 bool active, double* gsums, float* sh) {
+  // sh: [2*C] floats
+  for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&sh[cg * 8 + j], v0[j]);
+      atomicAdd(&sh[C + cg * 8 + j], v1[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&gsums[i], (double)sh[i]);
+}
+
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const bf16_t* __restrict__ x, long P, int C,
+                                                      int ld, double* __restrict__ sums,
+                                                      long pix_per_block) {
+  extern __shared__ float sh[];
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  const bool active = t < NA;
+  const int cg = t % VC, pr = t / VC;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  const long p0 = blockIdx.x * pix_per_block;
+  const long p1 = min(P, p0 + pix_per_block);
+  if (active) {
+    for (long p = p0 + pr; p < p1; p += RP) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + p * ld + cg * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+    }
+  }
+  block_reduce_2x8(s, q, cg, C, active, sums, sh);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, int use_running,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (use_running) {
+    mean = running_mean[c];
+    var = running_var[c];
+  } else {
+    mean = sums[c] / count;
+    var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double b = beta ? (double)beta[c] : 0.0;
+  scale[c] = (float)(g * invstd);
+  shift[c] = (float)(b - mean * g * invstd);
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = (float)invstd;
+}
+
+__global__ __launch_bounds__(NT) void bn_apply_kernel(
+    const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
+    bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, int relu, const float* __restrict__ post, long pix_per_img,
+    long pix_per_block) {
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  if (t >= NA) return;
+  const int cg = t % VC, pr = t / VC;
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = scale[cg * 8 + j]; b[j] = shift[cg * 8 + j]; }
+  const long p0 = blockIdx.x * pix_per_block;
+  const long p1 = min(P, p0 + pix_per_block);
+  for (long p = p0 + pr; p < p1; p += RP) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
+    if (res) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(res + p * ldr + cg * 8);
+      float r[8];
+      unpack8(rv, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    if (post) {
+      const float* pp = post + (p / pix_per_img) * C + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= pp[j];
+    }
+    *reinterpret_cast<uint4*>(z + p * ldz + cg * 8) = pack8(f);
+  }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
+    const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
+    double* __restrict__ sums, long pix_per_block) {
+  extern __shared__ float sh[];
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  const bool active = t < NA;
+  const int cg = t % VC, pr = t / VC;
+  float sg[8], sgx[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
+    const long p0 = blockIdx.x * pix_per_block;
+    const long p1 = min(P, p0 + pix_per_block);
+    for (long p = p0 + pr; p < p1; p += RP) {
+      float g[8], xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
+      unpack8(*reinterpret_cast<const uint4*>(x + p * ldx + cg * 8), xv);
+      if (post) {
+        const float* pp = post + (p / pix_per_img) * C + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= pp[j];
+      }
+      if (relu) {
+        float zv[8];
+        unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sg[j] += g[j];
+        sgx[j] += g[j] * (xv[j] - mu[j]) * is[j];
+      }
+    }
+  }
+  block_reduce_2x8(sg, sgx, cg, C, active, sums, sh);
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
+    const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
+    bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const double* __restrict__ sums, double count, int relu, const float* __restrict__ post,
+    long pix_per_img, long pix_per_block) {
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  if (t >= NA) return;
+  const int cg = t % VC, pr = t / VC;
+  float mu[8], is[8], a[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    mu[j] = mean[c];
+    is[j] = invstd[c];
+    a[j] = (gamma ? gamma[c] : 1.f) * is[j];
+    c1[j] = (float)(sums[c] / count);
+    c2[j] = (float)(sums[C + c] / count);
+  }
+  const long p0 = blockIdx.x * pix_per_block;
+  const long p1 = min(P, p0 + pix_per_block);
+  for (long p = p0 + pr; p < p1; p += RP) {
+    float g[8], xv[8];
+    unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(x + p * ldx + cg * 8), xv);
+    if (post) {
+      const float* pp = post + (p / pix_per_img) * C + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] *= pp[j];
+    }
+    if (relu) {
+      float zv[8];
+      unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) *reinterpret_cast<uint4*>(dres + p * lddres + cg * 8) = pack8(g);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (xv[j] - mu[j]) * is[j];
+      o[j] = a[j] * (g[j] - c1[j] - xh * c2[j]);
+    }
+    *reinterpret_cast<uint4*>(dx + p * lddx + cg * 8) = pack8(o);
+  }
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (float)sums[c];
+  if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+__global__ __launch_bounds__(NT) void colsum_kernel(const bf16_t* __restrict__ x, long P, int C,
+                                                    int ld, double* __restrict__ sums,
+                                                    long pix_per_block) {
+  extern __shared__ float sh[];
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  const bool active = t < NA;
+  const int cg = t % VC, pr = t / VC;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  const long p0 = blockIdx.x * pix_per_block;
+  const long p1 = min(P, p0 + pix_per_block);
+  if (active) {
+    for (long p = p0 + pr; p < p1; p += RP) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + p * ld + cg * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+  }
+  block_reduce_2x8(s, q, cg, C, active, sums, sh);
+}
+
+__global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+struct Grid { int blocks; long ppb; };
+Grid plan_grid(long P, int C) {
+  const int VC = C >> 3;
+  const int RP = active_threads(VC) / VC;
+  // ~8 pixel rows per thread per block, capped at 2048 blocks
+  long ppb = (long)RP * 8;
+  long blocks = (P + ppb - 1) / ppb;
+  if (blocks > 2048) {
+    blocks = 2048;
+    ppb = (P + blocks - 1) / blocks;
+    ppb = (ppb + RP - 1) / RP * RP;
+    blocks = (P + ppb - 1) / ppb;
+  }
+  if (blocks < 1) blocks = 1;
+  return {(int)blocks, ppb};
+}
+
+bool ok_c(int C) { return C > 0 && C % 8 == 0 && C <= 2048; }
+
+}  // namespace
+
+extern "C" {
+
+int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, void* stream) {
+  if (!x || !sums || !ok_c(C) || ld % 8 || P <= 0) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+  if (e != hipSuccess) return (int)e;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
+                     (const bf16_t*)x, P, C, ld, sums, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    int use_running, float* scale, float* shift, float* mean, float* invstd,
+                    void* stream) {
+  if (!scale || !shift || C <= 0) return SSA_EINVAL;
+  if (use_running ? (!running_mean || !running_var) : (!sums || count <= 0)) return SSA_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                     sums, count, C, gamma, beta, running_mean, running_var, momentum, eps,
+                     use_running, scale, shift, mean, invstd);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz, long P,
+                 int C, const float* scale, const float* shift, int relu, const float* post,
+                 long pix_per_img, void* stream) {
+  if (!x || !z || !scale || !shift || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8))
+    return SSA_EINVAL;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
+                     scale, shift, relu, post, pix_per_img, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
+                      long P, int C, const float* mean, const float* invstd, int relu,
+                      const float* post, long pix_per_img, double* sums, void* stream) {
+  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
+  if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+  if (e != hipSuccess) return (int)e;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
+                     (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
+                     mean, invstd, relu, post, pix_per_img, sums, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
+                     void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
+                     const float* mean, const float* invstd, const double* sums, double count,
+                     int relu, const float* post, long pix_per_img, void* stream) {
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
+  if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz,
+                     (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums,
+                     count, relu, post, pix_per_img, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {
+  if (!sums || C <= 0) return SSA_EINVAL;
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3((C + 127) / 128), dim3(128), 0,
+                     (hipStream_t)stream, sums, C, dgamma, dbeta);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out, double* scratch2c,
+                    void* stream) {
+  if (!x || !out || !scratch2c || !ok_c(C) || ld % 8) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(scratch2c, 0, sizeof(double) * 2 * C, s);
+  if (e != hipSuccess) return (int)e;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(colsum_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
+                     (const bf16_t*)x, P, C, ld, scratch2c, g.ppb);
+  SSA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(d2f_kernel, dim3((C + 127) / 128), dim3(128), 0, s, scratch2c, out, C);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+}  // extern "C"

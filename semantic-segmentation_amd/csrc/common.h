@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (CDNA4) segmentation kernels.
+// Activations are NHWC, bf16 stored as raw 16-bit words; all arithmetic is
+// fp32 (fp64 for the BN / RMI statistics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));     // MFMA A/B fragment
+typedef float f32x16_t __attribute__((ext_vector_type(16)));     // 32x32 MFMA C/D
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define SSA_OK 0
+#define SSA_EINVAL (-1)
+#define SSA_EUNSUPPORTED (-2)
+
+#define SSA_LAUNCH_CHECK()                          \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  return v;
+}
+
+// generic scalar load/store by element type (bf16_t or float)
+template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p);
+template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_as_f32<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v);
+template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

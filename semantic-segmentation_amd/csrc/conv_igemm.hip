@@ -1,0 +1,577 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): NHWC bf16 activations, packed
+// bf16 filters [N][Kpad], fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+//
+//   forward / data-gradient:  Y[m, n] = sum_k A[m, k] * Wp[n, k]
+//        m = (b, oy, ox) output pixel, n = output channel, k = (kh, kw, ci)
+//        A is never materialised: each 16-byte piece (8 channels of one tap of
+//        one pixel) is gathered straight from the NHWC tensor into LDS.
+//   weight-gradient:          dW[co, k] = sum_p dY[p, co] * A[p, k]
+//        the reduction runs over pixels, so both operands are transposed on
+//        their way into LDS; the pixel axis is split over blockIdx.y and the
+//        fp32 partials are summed by conv_wgrad_reduce (deterministic).
+//
+// Replaces cuDNN behind nn.Conv2d on the reference's hot path (SURVEY.md K1-K6;
+// network/hrnetv2.py:31-34, network/ocrnet.py:54-58, network/utils.py:192-198).
+//
+// Tile geometry: a workgroup of WGM x WGN wavefronts; each wavefront owns
+// MI x NI MFMA tiles of 32x32.  K advances 32 per stage (two MFMA k-steps),
+// LDS is double buffered with the next stage's global loads issued before the
+// current stage's MFMAs.  LDS rows are padded to 80 bytes so the 16 lanes that
+// ds_read_b128 services together hit 16 distinct 16-byte slots.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+#include <limits.h>
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDT = BK + 8;
+
+template <int MI, int NI>
+__device__ __forceinline__ void mma_stage(const bf16_t* __restrict__ As,
+                                          const bf16_t* __restrict__ Bs, int a_row0,
+                                          int b_row0, int lane,
+                                          f32x16_t (&acc)[MI][NI]) {
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    bf16x8_t af[MI], bfr[NI];
+    const int koff = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      af[mi] = *reinterpret_cast<const bf16x8_t*>(As + (a_row0 + mi * 32 + (lane & 31)) * LDT + koff);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      bfr[ni] = *reinterpret_cast<const bf16x8_t*>(Bs + (b_row0 + ni * 32 + (lane & 31)) * LDT + koff);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// forward / dgrad kernel
+// ----------------------------------------------------------------------------
+template <int WGM, int WGN, int MI, int NI>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
+    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+    const float* __restrict__ bias, void* __restrict__ yv, int tiles_n, int tr_shift) {
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
+  constexpr int PPR = BK / 8;
+  constexpr int RPP = NT / PPR;
+  constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
+  constexpr int STAGE = (BM + BN) * LDT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = d.B * d.Ho * d.Wo;
+  const int HoWo = d.Ho * d.Wo;
+  const int pc = tid % PPR, r0 = tid / PPR;
+
+  int iy0[A_IT], ix0[A_IT], pb[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int r = r0 + i * RPP, m = m0 + r;
+    if (r < BM && m < M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+      if (d.transposed) { iy0[i] = oy - d.pad; ix0[i] = ox - d.pad; }
+      else { iy0[i] = oy * d.stride - d.pad; ix0[i] = ox * d.stride - d.pad; }
+      pb[i] = b * d.H * d.W;
+    } else {
+      iy0[i] = INT_MIN / 2; ix0[i] = INT_MIN / 2; pb[i] = 0;
+    }
+  }
+  // this thread's K cursor: channel offset inside the tap, and the tap itself
+  int kc, kh, kw;
+  {
+    const int kpos = pc * 8;
+    const int tap = kpos / d.Cin;
+    kc = kpos - tap * d.Cin;
+    kh = tap / d.KW;
+    kw = tap - kh * d.KW;
+  }
+  const int tr_mask = (1 << tr_shift) - 1;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const int nk = d.Kpad / BK;
+
+  uint4 ra[A_IT], rb[B_IT];
+  auto gload = [&](int kt) {
+    const bool kvalid = kh < d.KH;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int iy = iy0[i] + kh * d.dil, ix = ix0[i] + kw * d.dil;
+      bool ok = kvalid;
+      if (d.transposed) {
+        ok = ok && iy >= 0 && ix >= 0 && ((iy & tr_mask) == 0) && ((ix & tr_mask) == 0);
+        iy >>= tr_shift; ix >>= tr_shift;
+        ok = ok && iy < d.H && ix < d.W;
+      } else {
+        ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+      }
+      const long pix = ok ? (long)(pb[i] + iy * d.W + ix) : 0;
+      const bf16_t* p = x + pix * d.ldx + kc;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int r = r0 + j * RPP, n = n0 + r;
+      const bool ok = (r < BN) && (n < d.Cout);
+      const bf16_t* p = w + (long)n * d.Kpad + kt * BK + pc * 8;
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
+    }
+    // advance the cursor by one stage
+    kc += BK;
+    while (kc >= d.Cin) {
+      kc -= d.Cin;
+      if (++kw == d.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* As = lds + buf * STAGE;
+    bf16_t* Bs = As + BM * LDT;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int r = r0 + i * RPP;
+      if (r < BM) *reinterpret_cast<uint4*>(As + r * LDT + pc * 8) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int r = r0 + j * RPP;
+      if (r < BN) *reinterpret_cast<uint4*>(Bs + r * LDT + pc * 8) = rb[j];
+    }
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const bf16_t* As = lds + buf * STAGE;
+    mma_stage<MI, NI>(As, As + BM * LDT, wm * MI * 32, wn * NI * 32, lane, acc);
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------- epilogue
+  if (d.out_f32) {
+    float* y = reinterpret_cast<float*>(yv);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wn * NI * 32 + ni * 32 + (lane & 31);
+        const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int m = m0 + row;
+          if (m < M && n < d.Cout) y[(long)m * d.ldy + n] = acc[mi][ni][r] + bv;
+        }
+      }
+    return;
+  }
+  constexpr int LDC = BN + 8;
+  bf16_t* Cs = lds;  // safe: the K loop ended on a barrier
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = wn * NI * 32 + ni * 32 + (lane & 31);
+      const int n = n0 + col;
+      const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Cs[row * LDC + col] = f2bf(acc[mi][ni][r] + bv);
+      }
+    }
+  __syncthreads();
+  bf16_t* y = reinterpret_cast<bf16_t*>(yv);
+  constexpr int CPR = BN / 8;
+  for (int idx = tid; idx < BM * CPR; idx += NT) {
+    const int row = idx / CPR, cp = idx - row * CPR;
+    const int m = m0 + row, n = n0 + cp * 8;
+    if (m >= M || n >= d.Cout) continue;
+    bf16_t* dst = y + (long)m * d.ldy + n;
+    const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (n + 8 <= d.Cout) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int j = 0; n + j < d.Cout; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// weight-gradient kernel (v0: transposing LDS stores)
+// ----------------------------------------------------------------------------
+template <int WGM, int WGN, int MI, int NI>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(
+    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
+    int cout_pad, float* __restrict__ partial, int tiles_n, int chunk) {
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
+  constexpr int A_PIECES = 32 * BM / 8, B_PIECES = 32 * BN / 8;
+  constexpr int A_IT = (A_PIECES + NT - 1) / NT, B_IT = (B_PIECES + NT - 1) / NT;
+  constexpr int STAGE = (BM + BN) * LDT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int P = d.B * d.Ho * d.Wo, HoWo = d.Ho * d.Wo;
+  const int Kflat = d.KH * d.KW * d.Cin;
+  const int p_begin = blockIdx.y * chunk;
+  const int p_end = min(P, p_begin + chunk);
+  const int pixel = tid & 31;
+
+  // per-piece constants
+  int a_co[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int idx = tid + i * NT, piece = idx >> 5;
+    a_co[i] = m0 + piece * 8;
+    a_ok[i] = (idx < A_PIECES) && (a_co[i] < cout_pad);
+  }
+  int b_ci[B_IT], b_dy[B_IT], b_dx[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int idx = tid + j * NT, piece = idx >> 5;
+    const int kcol = n0 + piece * 8;
+    b_ok[j] = (idx < B_PIECES) && (kcol < Kflat);
+    const int tap = kcol / d.Cin;
+    b_ci[j] = kcol - tap * d.Cin;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    b_dy[j] = kh * d.dil - d.pad;
+    b_dx[j] = kw * d.dil - d.pad;
+  }
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  uint4 ra[A_IT], rb[B_IT];
+  auto gload = [&](int kt) {
+    const int p = p_begin + kt * 32 + pixel;
+    const bool pok = p < p_end;
+    const int pp = pok ? p : 0;
+    const int b = pp / HoWo, rem = pp - b * HoWo;
+    const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bf16_t* ptr = dy + (long)pp * lddy + a_co[i];
+      ra[i] = (pok && a_ok[i]) ? *reinterpret_cast<const uint4*>(ptr) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int iy = oy * d.stride + b_dy[j], ix = ox * d.stride + b_dx[j];
+      const bool ok = pok && b_ok[j] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+      const long pix = ok ? (long)((b * d.H + iy) * d.W + ix) : 0;
+      const bf16_t* ptr = x + pix * d.ldx + b_ci[j];
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(ptr) : zero4;
+    }
+  };
+  auto tstore = [&](bf16_t* dst, const uint4& v, int piece) {
+    bf16_t* q = dst + (piece * 8) * LDT + pixel;
+    q[0 * LDT] = (bf16_t)(v.x & 0xffff); q[1 * LDT] = (bf16_t)(v.x >> 16);
+    q[2 * LDT] = (bf16_t)(v.y & 0xffff); q[3 * LDT] = (bf16_t)(v.y >> 16);
+    q[4 * LDT] = (bf16_t)(v.z & 0xffff); q[5 * LDT] = (bf16_t)(v.z >> 16);
+    q[6 * LDT] = (bf16_t)(v.w & 0xffff); q[7 * LDT] = (bf16_t)(v.w >> 16);
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* As = lds + buf * STAGE;
+    bf16_t* Bs = As + BM * LDT;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < A_PIECES) tstore(As, ra[i], idx >> 5);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int idx = tid + j * NT;
+      if (idx < B_PIECES) tstore(Bs, rb[j], idx >> 5);
+    }
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nk = (p_end - p_begin + 31) / 32;
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      const bf16_t* As = lds + buf * STAGE;
+      mma_stage<MI, NI>(As, As + BM * LDT, wm * MI * 32, wn * NI * 32, lane, acc);
+      if (kt + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = partial + (long)blockIdx.y * cout_pad * Kflat;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int kcol = n0 + wn * NI * 32 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad && kcol < Kflat) out[(long)co * Kflat + kcol] = acc[mi][ni][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int cout_pad,
+                                    int Cout, int Cin_pad, int Cin, int KH, int KW,
+                                    float* __restrict__ dw) {
+  // one thread per OIHW element
+  const long n = (long)Cout * Cin * KH * KW;
+  const long Kflat = (long)KH * KW * Cin_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int kw = t % KW; t /= KW;
+    const int kh = t % KH; t /= KH;
+    const int ci = t % Cin; t /= Cin;
+    const int co = (int)t;
+    const long src = (long)co * Kflat + (long)(kh * KW + kw) * Cin_pad + ci;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * cout_pad * Kflat + src];
+    dw[i] = s;
+  }
+}
+
+__global__ void pack_filter_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
+                                   int Cin, int KH, int KW, int cin_pad, int cout_pad, int Kpad,
+                                   int mode, int rows) {
+  const long n = (long)rows * Kpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Kpad), k = (int)(i - (long)r * Kpad);
+    float v = 0.f;
+    if (mode == 0) {
+      const int tap = k / cin_pad, ci = k - tap * cin_pad;
+      if (tap < KH * KW && ci < Cin && r < Cout) {
+        const int kh = tap / KW, kw = tap - kh * KW;
+        v = w[(((long)r * Cin + ci) * KH + kh) * KW + kw];
+      }
+    } else {
+      const int tap = k / cout_pad, co = k - tap * cout_pad;
+      if (tap < KH * KW && co < Cout && r < Cin) {
+        const int khp = tap / KW, kwp = tap - khp * KW;
+        const int kh = KH - 1 - khp, kw = KW - 1 - kwp;
+        v = w[(((long)co * Cin + r) * KH + kh) * KW + kw];
+      }
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+__global__ void pad_cast_kernel(const float* __restrict__ x, long P, int C, int ldx,
+                                bf16_t* __restrict__ y, int Cpad) {
+  const long n = P * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / Cpad;
+    const int c = (int)(i - p * Cpad);
+    y[i] = f2bf(c < C ? x[p * ldx + c] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------- dispatch
+struct TileChoice { int id, bm, bn; float eff; };
+// id: 0 = 128x128 (2x2 waves, 2x2 tiles)   1 = 256x64 (4x1, 2x2)
+//     2 = 128x96  (4x1, 1x3)               3 = 256x32 (4x1, 2x1)
+//     4 = 64x64   (2x2, 1x1)               5 = 128x64 (2x2, 2x1)
+constexpr TileChoice kFwdTiles[] = {
+    {0, 128, 128, 1.00f}, {1, 256, 64, 0.90f}, {2, 128, 96, 0.85f},
+    {3, 256, 32, 0.55f},  {4, 64, 64, 0.50f},  {5, 128, 64, 0.75f}};
+
+int choose_fwd_tile(long M, int N) {
+  int best = 0;
+  double best_cost = 1e300;
+  for (const TileChoice& t : kFwdTiles) {
+    const long tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+    // work is issued in rounds of ~2 workgroups per CU on 256 CUs
+    const double rounds = (double)((tiles + 511) / 512);
+    const double full = (double)tiles / 512.0;
+    const double cost = (0.5 * rounds + 0.5 * full) * t.bm * t.bn / t.eff;
+    if (cost < best_cost) { best_cost = cost; best = t.id; }
+  }
+  return best;
+}
+
+template <int WGM, int WGN, int MI, int NI>
+int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
+               hipStream_t s, int tr_shift) {
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
+  const long M = (long)d.B * d.Ho * d.Wo;
+  const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (d.Cout + BN - 1) / BN;
+  size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
+  const size_t cs = (size_t)BM * (BN + 8) * 2;
+  if (cs > lds) lds = cs;
+  hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n),
+                     dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)w, bias, y,
+                     tiles_n, tr_shift);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+template <int WGM, int WGN, int MI, int NI>
+int launch_wgrad(const ssa_conv_desc& d, const void* x, const void* dy, int lddy, int cout_pad,
+                 int nsplit, float* partial, hipStream_t s) {
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
+  const int Kflat = d.KH * d.KW * d.Cin;
+  const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
+  const long P = (long)d.B * d.Ho * d.Wo;
+  long chunk = (P + nsplit - 1) / nsplit;
+  chunk = (chunk + 31) / 32 * 32;
+  const size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
+  hipLaunchKernelGGL((conv_wgrad_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n, nsplit),
+                     dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
+                     cout_pad, partial, tiles_n, (int)chunk);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+// wgrad tile ids: 0 = 128x128, 1 = 64x64, 2 = 32x128, 3 = 96x128
+int choose_wgrad_tile(int cout_pad) {
+  if (cout_pad <= 32) return 2;
+  if (cout_pad <= 64) return 1;
+  if (cout_pad % 96 == 0 && cout_pad % 128 != 0) return 3;
+  return 0;
+}
+void wgrad_tile_dims(int id, int* bm, int* bn) {
+  switch (id) {
+    case 1: *bm = 64; *bn = 64; break;
+    case 2: *bm = 32; *bn = 128; break;
+    case 3: *bm = 96; *bn = 128; break;
+    default: *bm = 128; *bn = 128; break;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ssa_version(void) { return 1; }
+
+int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packed,
+                     const float* bias, void* y, void* stream) {
+  if (!dp || !x || !w_packed || !y) return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  if (d.Cin % 8 || d.ldx % 8 || d.Kpad % BK || d.Kpad < d.KH * d.KW * d.Cin) return SSA_EINVAL;
+  if (!aligned16(x) || !aligned16(w_packed)) return SSA_EINVAL;
+  if (!d.out_f32 && (d.ldy % 8 || !aligned16(y))) return SSA_EINVAL;
+  if (d.B <= 0 || d.Ho <= 0 || d.Wo <= 0 || d.Cout <= 0) return SSA_EINVAL;
+  if ((long)d.B * d.H * d.W >= INT_MAX / 2 || (long)d.B * d.Ho * d.Wo >= INT_MAX / 2) return SSA_EUNSUPPORTED;
+  int tr_shift = 0;
+  if (d.transposed) {
+    while ((1 << tr_shift) < d.stride) ++tr_shift;
+    if ((1 << tr_shift) != d.stride) return SSA_EUNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const long M = (long)d.B * d.Ho * d.Wo;
+  const int cfg = d.cfg >= 0 ? d.cfg : choose_fwd_tile(M, d.Cout);
+  switch (cfg) {
+    case 0: return launch_fwd<2, 2, 2, 2>(d, x, w_packed, bias, y, s, tr_shift);
+    case 1: return launch_fwd<4, 1, 2, 2>(d, x, w_packed, bias, y, s, tr_shift);
+    case 2: return launch_fwd<4, 1, 1, 3>(d, x, w_packed, bias, y, s, tr_shift);
+    case 3: return launch_fwd<4, 1, 2, 1>(d, x, w_packed, bias, y, s, tr_shift);
+    case 4: return launch_fwd<2, 2, 1, 1>(d, x, w_packed, bias, y, s, tr_shift);
+    case 5: return launch_fwd<2, 2, 2, 1>(d, x, w_packed, bias, y, s, tr_shift);
+    default: return SSA_EINVAL;
+  }
+}
+
+int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
+                    int cin_pad, int cout_pad, int Kpad, int mode, void* stream) {
+  if (!w_oihw || !w_packed || Kpad % BK) return SSA_EINVAL;
+  const int rows = mode == 0 ? Cout : Cin;
+  const long kneed = (long)KH * KW * (mode == 0 ? cin_pad : cout_pad);
+  if (Kpad < kneed) return SSA_EINVAL;
+  const long n = (long)rows * Kpad;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(pack_filter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (bf16_t*)w_packed, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, size_t* ws_bytes) {
+  if (!d || !nsplit || !ws_bytes) return SSA_EINVAL;
+  int bm, bn;
+  wgrad_tile_dims(choose_wgrad_tile(cout_pad), &bm, &bn);
+  const int Kflat = d->KH * d->KW * d->Cin;
+  const long tiles = (long)((cout_pad + bm - 1) / bm) * ((Kflat + bn - 1) / bn);
+  const long P = (long)d->B * d->Ho * d->Wo;
+  long ns = (1024 + tiles - 1) / tiles;
+  const long max_by_pixels = (P + 127) / 128;  // at least 4 stages per split
+  if (ns > max_by_pixels) ns = max_by_pixels;
+  if (ns < 1) ns = 1;
+  if (ns > 512) ns = 512;
+  *nsplit = (int)ns;
+  *ws_bytes = (size_t)ns * cout_pad * Kflat * sizeof(float);
+  return SSA_OK;
+}
+
+int ssa_conv2d_wgrad(const ssa_conv_desc* dp, const void* x, const void* dy, int lddy,
+                     int cout_pad, int nsplit, float* partial, void* stream) {
+  if (!dp || !x || !dy || !partial || nsplit < 1) return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  if (d.transposed) return SSA_EUNSUPPORTED;
+  if (d.Cin % 8 || d.ldx % 8 || cout_pad % 8 || lddy % 8) return SSA_EINVAL;
+  if (!aligned16(x) || !aligned16(dy)) return SSA_EINVAL;
+  if ((long)d.B * d.H * d.W >= INT_MAX / 2 || (long)d.B * d.Ho * d.Wo >= INT_MAX / 2) return SSA_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  switch (choose_wgrad_tile(cout_pad)) {
+    case 1: return launch_wgrad<2, 2, 1, 1>(d, x, dy, lddy, cout_pad, nsplit, partial, s);
+    case 2: return launch_wgrad<1, 4, 1, 1>(d, x, dy, lddy, cout_pad, nsplit, partial, s);
+    case 3: return launch_wgrad<1, 4, 3, 1>(d, x, dy, lddy, cout_pad, nsplit, partial, s);
+    default: return launch_wgrad<2, 2, 2, 2>(d, x, dy, lddy, cout_pad, nsplit, partial, s);
+  }
+}
+
+int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int Cout, int Cin_pad,
+                            int Cin, int KH, int KW, float* dw_oihw, void* stream) {
+  if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad) return SSA_EINVAL;
+  const long n = (long)Cout * Cin * KH * KW;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial,
+                     nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, dw_oihw);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_pad_cast_f32_bf16(const float* x, long P, int C, int ldx, void* y, int Cpad, void* stream) {
+  if (!x || !y || Cpad < C) return SSA_EINVAL;
+  const long n = P * Cpad;
+  const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(pad_cast_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ldx,
+                     (bf16_t*)y, Cpad);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+// Per-pixel losses of the path, on fp32 NHWC logits [P, C] + int64 labels [P].
+//   * CrossEntropyLoss2d            loss/utils.py:121-134        (K13)
+//   * RMILoss part I  (masked BCE)  loss/rmi.py:91-116           (K14)
+//   * RMILoss part II (RMI bound)   loss/rmi.py:139-215,
+//                                   loss/rmi_utils.py:15-56,95-107 (K15)
+// Forward kernels also emit the un-normalised gradient so the backward is one
+// scaling pass.  RMI never materialises the [B,C,9,65025] fp64 neighbourhood
+// stack: Gram matrices are accumulated straight from the pooled maps.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+#include <float.h>
+
+namespace {
+
+constexpr int NT = 256;
+constexpr float kClipMin = 1e-6f;   // loss/rmi.py:24  _CLIP_MIN
+constexpr double kPosAlpha = 5e-4;  // loss/rmi.py:26  _POS_ALPHA
+
+__device__ __forceinline__ void block_acc2(double a, double b, double* acc) {
+  __shared__ double red[2 * (NT / 64)];
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int i = 0; i < NT / 64; ++i) { sa += red[2 * i]; sb += red[2 * i + 1]; }
+    atomicAdd(&acc[0], sa);
+    atomicAdd(&acc[1], sb);
+  }
+}
+
+// MODE 0: softmax cross entropy;  MODE 1: masked sigmoid BCE (sum over classes)
+template <int MODE>
+__global__ __launch_bounds__(NT) void pixel_loss_kernel(const float* __restrict__ logits, int ld,
+                                                        const int64_t* __restrict__ labels, long P,
+                                                        int C, int ignore_index,
+                                                        double* __restrict__ acc,
+                                                        float* __restrict__ dlogits) {
+  extern __shared__ float tile[];  // [NT][C]
+  double lsum = 0.0, lcnt = 0.0;
+  for (long base = (long)blockIdx.x * NT; base < P; base += (long)gridDim.x * NT) {
+    const long npx = min((long)NT, P - base);
+    // coalesced stage-in
+    if (ld == C) {
+      const float* src = logits + base * C;
+      for (long i = threadIdx.x; i < npx * C; i += NT) tile[i] = src[i];
+    } else {
+      for (long i = threadIdx.x; i < npx * C; i += NT) tile[i] = logits[(base + i / C) * ld + i % C];
+    }
+    __syncthreads();
+    if (threadIdx.x < npx) {
+      float* x = tile + threadIdx.x * C;
+      const long lab = labels[base + threadIdx.x];
+      if (MODE == 0) {
+        const bool valid = lab != ignore_index && lab >= 0 && lab < C;
+        float mx = -FLT_MAX;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(x[c] - mx);
+        const float lse = mx + logf(se);
+        if (valid) { lsum += (double)(lse - x[lab]); lcnt += 1.0; }
+        if (dlogits) {
+          const float inv = 1.f / se;
+          for (int c = 0; c < C; ++c) {
+            const float p = expf(x[c] - mx) * inv;
+            x[c] = valid ? (p - (c == lab ? 1.f : 0.f)) : 0.f;
+          }
+        }
+      } else {
+        const bool valid = lab >= 0 && lab < C;
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float v = x[c], t = (c == lab) ? 1.f : 0.f;
+          // stable BCE-with-logits: max(v,0) - v*t + log1p(exp(-|v|))
+          s += fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+          if (dlogits) x[c] = valid ? (1.f / (1.f + expf(-v)) - t) : 0.f;
+        }
+        if (valid) { lsum += (double)s; lcnt += 1.0; }
+      }
+    }
+    __syncthreads();
+    if (dlogits) {
+      float* dst = dlogits + base * C;  // gradient buffer is dense [P, C]
+      for (long i = threadIdx.x; i < npx * C; i += NT) dst[i] = tile[i];
+    }
+    __syncthreads();
+  }
+  block_acc2(lsum, lcnt, acc);
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ acc, double denom_add,
+                                     float* __restrict__ loss) {
+  loss[0] = (float)(acc[0] / (acc[1] + denom_add));
+}
+
+__global__ void scale_grad_kernel(float* __restrict__ g, long n, const float* __restrict__ upstream,
+                                  double coef, const double* __restrict__ acc, double denom_add) {
+  const float s = (float)((double)upstream[0] * coef / (acc[1] + denom_add));
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    g[i] *= s;
+}
+
+// ------------------------------------------------------------------- RMI
+// pooled_pr[b,c,py,px] = avg over the 4x4 cell (zero padded, /16) of
+//   sigmoid(logit)*mask + 1e-6 ; pooled_la likewise of onehot*mask.
+// One block = one pooled row, 32 pooled columns: stages 4 x 128 input pixels.
+constexpr int CELLS = 32;
+__global__ __launch_bounds__(NT) void rmi_pool_kernel(const float* __restrict__ logits, int ld,
+                                                      const int64_t* __restrict__ labels, int H,
+                                                      int W, int C, float* __restrict__ ppr,
+                                                      float* __restrict__ pla, int Hp, int Wp) {
+  extern __shared__ float sm[];  // [4][CELLS*4][C] probs, then [4][CELLS*4] labels (as float)
+  float* pr = sm;
+  float* lb = sm + 4 * CELLS * 4 * C;
+  const int b = blockIdx.z, py = blockIdx.y, px0 = blockIdx.x * CELLS;
+  const int y0 = py * 4 - 2, x0 = px0 * 4 - 2;
+  const int NPX = CELLS * 4;
+  // stage labels (as float; -1 = outside / invalid)
+  for (int i = threadIdx.x; i < 4 * NPX; i += NT) {
+    const int r = i / NPX, xx = i - r * NPX;
+    const int y = y0 + r, x = x0 + xx;
+    float l = -1.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const long lab = labels[((long)b * H + y) * W + x];
+      l = (lab >= 0 && lab < C) ? (float)lab : -1.f;
+    }
+    lb[i] = l;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * NPX * C; i += NT) {
+    const int c = i % C, pxl = i / C;
+    const int r = pxl / NPX, xx = pxl - r * NPX;
+    const int y = y0 + r, x = x0 + xx;
+    float v = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const float lg = logits[(((long)b * H + y) * W + x) * ld + c];
+      const float m = lb[pxl] >= 0.f ? 1.f : 0.f;
+      v = m / (1.f + expf(-lg)) + kClipMin;
+    }
+    pr[i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CELLS * C; i += NT) {
+    const int c = i / CELLS, cell = i - c * CELLS;
+    const int px = px0 + cell;
+    if (px >= Wp) continue;
+    float sp = 0.f, sl = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pxl = r * NPX + cell * 4 + q;
+        sp += pr[pxl * C + c];
+        sl += (lb[pxl] == (float)c) ? 1.f : 0.f;
+      }
+    const long o = (((long)b * C + c) * Hp + py) * Wp + px;
+    ppr[o] = sp * (1.f / 16.f);
+    pla[o] = sl * (1.f / 16.f);
+  }
+}
+
+// Gram entries, per (b,c): 45 la-la (upper), 45 pr-pr (upper), 81 la-pr,
+// 9 sum la, 9 sum pr = 189 doubles.
+constexpr int NG = 189;
+constexpr int GROWS = 4;  // position rows per block
+__device__ __forceinline__ void tri_index(int e, int* i, int* j) {
+  int r = 0, rem = e;
+  while (rem >= 9 - r) { rem -= 9 - r; ++r; }
+  *i = r; *j = r + rem;
+}
+__global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ ppr,
+                                                      const float* __restrict__ pla, int Hp, int Wp,
+                                                      double* __restrict__ gram) {
+  extern __shared__ float sm[];  // la tile [GROWS+2][Wp], pr tile [GROWS+2][Wp]
+  const int bc = blockIdx.y;
+  const int Hn = Hp - 2, Wn = Wp - 2;
+  const int yb = blockIdx.x * GROWS;
+  const int nrows = min(GROWS, Hn - yb);
+  float* la = sm;
+  float* pr = sm + (GROWS + 2) * Wp;
+  const float* gla = pla + (long)bc * Hp * Wp + (long)yb * Wp;
+  const float* gpr = ppr + (long)bc * Hp * Wp + (long)yb * Wp;
+  for (int i = threadIdx.x; i < (nrows + 2) * Wp; i += NT) { la[i] = gla[i]; pr[i] = gpr[i]; }
+  __syncthreads();
+  const int e = threadIdx.x;
+  if (e >= NG) return;
+  int ti, tj, kind;  // kind 0: a*b, 1: a only
+  const float *ta, *tb;
+  if (e < 45) { tri_index(e, &ti, &tj); ta = la; tb = la; kind = 0; }
+  else if (e < 90) { tri_index(e - 45, &ti, &tj); ta = pr; tb = pr; kind = 0; }
+  else if (e < 171) { ti = (e - 90) / 9; tj = (e - 90) % 9; ta = la; tb = pr; kind = 0; }
+  else if (e < 180) { ti = e - 171; tj = 0; ta = la; tb = la; kind = 1; }
+  else { ti = e - 180; tj = 0; ta = pr; tb = pr; kind = 1; }
+  const int oa = (ti / 3) * Wp + (ti % 3), ob = (tj / 3) * Wp + (tj % 3);
+  double acc = 0.0;
+  for (int y = 0; y < nrows; ++y) {
+    const float* ra = ta + y * Wp + oa;
+    const float* rb = tb + y * Wp + ob;
+    if (kind == 0) { for (int x = 0; x < Wn; ++x) acc += (double)ra[x] * (double)rb[x]; }
+    else { for (int x = 0; x < Wn; ++x) acc += (double)ra[x]; }
+  }
+  atomicAdd(&gram[(long)bc * NG + e], acc);
+}
+
+// 9x9 helpers (row-major double[81]), executed by a single thread
+__device__ void mat_mul9(const double* A, const double* B, double* C, bool tA, bool tB) {
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 9; ++k) s += (tA ? A[k * 9 + i] : A[i * 9 + k]) * (tB ? B[j * 9 + k] : B[k * 9 + j]);
+      C[i * 9 + j] = s;
+    }
+}
+// in-place Gauss-Jordan inverse with partial pivoting; returns false if singular
+__device__ bool mat_inv9(const double* A, double* X, double* W /*81 scratch*/) {
+  for (int i = 0; i < 81; ++i) { W[i] = A[i]; X[i] = 0.0; }
+  for (int i = 0; i < 9; ++i) X[i * 9 + i] = 1.0;
+  for (int col = 0; col < 9; ++col) {
+    int piv = col;
+    double best = fabs(W[col * 9 + col]);
+    for (int r = col + 1; r < 9; ++r) { const double v = fabs(W[r * 9 + col]); if (v > best) { best = v; piv = r; } }
+    if (best == 0.0) return false;
+    if (piv != col)
+      for (int k = 0; k < 9; ++k) {
+        double t = W[col * 9 + k]; W[col * 9 + k] = W[piv * 9 + k]; W[piv * 9 + k] = t;
+        t = X[col * 9 + k]; X[col * 9 + k] = X[piv * 9 + k]; X[piv * 9 + k] = t;
+      }
+    const double inv = 1.0 / W[col * 9 + col];
+    for (int k = 0; k < 9; ++k) { W[col * 9 + k] *= inv; X[col * 9 + k] *= inv; }
+    for (int r = 0; r < 9; ++r) {
+      if (r == col) continue;
+      const double f = W[r * 9 + col];
+      if (f == 0.0) continue;
+      for (int k = 0; k < 9; ++k) { W[r * 9 + k] -= f * W[col * 9 + k]; X[r * 9 + k] -= f * X[col * 9 + k]; }
+    }
+  }
+  return true;
+}
+// lower Cholesky; returns false if not positive definite
+__device__ bool chol9(const double* A, double* L) {
+  for (int i = 0; i < 81; ++i) L[i] = 0.0;
+  for (int j = 0; j < 9; ++j) {
+    double d = A[j * 9 + j];
+    for (int k = 0; k < j; ++k) d -= L[j * 9 + k] * L[j * 9 + k];
+    if (!(d > 0.0)) return false;
+    const double ljj = sqrt(d);
+    L[j * 9 + j] = ljj;
+    for (int i = j + 1; i < 9; ++i) {
+      double s = A[i * 9 + j];
+      for (int k = 0; k < j; ++k) s -= L[i * 9 + k] * L[j * 9 + k];
+      L[i * 9 + j] = s / ljj;
+    }
+  }
+  return true;
+}
+// inverse of lower-triangular L
+__device__ void tri_inv9(const double* L, double* Li) {
+  for (int i = 0; i < 81; ++i) Li[i] = 0.0;
+  for (int j = 0; j < 9; ++j) {
+    Li[j * 9 + j] = 1.0 / L[j * 9 + j];
+    for (int i = j + 1; i < 9; ++i) {
+      double s = 0.0;
+      for (int k = j; k < i; ++k) s += L[i * 9 + k] * Li[k * 9 + j];
+      Li[i * 9 + j] = -s / L[i * 9 + i];
+    }
+  }
+}
+
+__global__ void rmi_solve_kernel(const double* __restrict__ gram, int Hp, int Wp,
+                                 double* __restrict__ loss_bc, double* __restrict__ gmat) {
+  __shared__ double S[11 * 81];
+  if (threadIdx.x != 0) return;
+  const int bc = blockIdx.x;
+  const double* g = gram + (long)bc * NG;
+  const double n = (double)(Hp - 2) * (double)(Wp - 2);
+  double* Cll = S; double* Cpp = S + 81; double* Clp = S + 162; double* X = S + 243;
+  double* T1 = S + 324; double* T2 = S + 405; double* M = S + 486; double* Lc = S + 567;
+  double* Li = S + 648; double* GM = S + 729; double* T3 = S + 810;
+  const double* sla = g + 171; const double* spr = g + 180;
+  int e = 0;
+  for (int i = 0; i < 9; ++i)
+    for (int j = i; j < 9; ++j, ++e) {
+      const double v = g[e] - sla[i] * sla[j] / n;
+      Cll[i * 9 + j] = v; Cll[j * 9 + i] = v;
+      const double w = g[45 + e] - spr[i] * spr[j] / n;
+      Cpp[i * 9 + j] = w; Cpp[j * 9 + i] = w;
+    }
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) Clp[i * 9 + j] = g[90 + i * 9 + j] - sla[i] * spr[j] / n;
+  double* out = gmat + (long)bc * (2 * 81 + 18);
+  for (int i = 0; i < 9; ++i) { out[162 + i] = sla[i] / n; out[171 + i] = spr[i] / n; }
+  // X = (Cpp + alpha I)^-1
+  for (int i = 0; i < 81; ++i) T1[i] = Cpp[i];
+  for (int i = 0; i < 9; ++i) T1[i * 9 + i] += kPosAlpha;
+  bool ok = mat_inv9(T1, X, T2);
+  // A = Cll - Clp X Clp^T ; M = A + alpha I
+  mat_mul9(Clp, X, T1, false, false);        // T1 = Clp X
+  mat_mul9(T1, Clp, T2, false, true);        // T2 = Clp X Clp^T
+  for (int i = 0; i < 81; ++i) M[i] = Cll[i] - T2[i];
+  for (int i = 0; i < 9; ++i) M[i * 9 + i] += kPosAlpha;
+  ok = ok && chol9(M, Lc);
+  if (!ok) {
+    loss_bc[bc] = __longlong_as_double(0x7ff8000000000000LL);
+    for (int i = 0; i < 162; ++i) out[i] = 0.0;
+    return;
+  }
+  double loss = 0.0;
+  for (int i = 0; i < 9; ++i) loss += log(Lc[i * 9 + i] + 1e-8);
+  loss_bc[bc] = loss;  // = 0.5 * 2 * sum log(diag + 1e-8)
+  // G_M = 0.5 * Li^T diag(w) Li, w_i = L_ii / (L_ii + 1e-8)
+  tri_inv9(Lc, Li);
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 9; ++k) {
+        const double w = Lc[k * 9 + k] / (Lc[k * 9 + k] + 1e-8);
+        s += Li[k * 9 + i] * w * Li[k * 9 + j];
+      }
+      GM[i * 9 + j] = 0.5 * s;
+    }
+  // G_lp = -2 GM Clp X = -2 GM T1
+  mat_mul9(GM, T1, T2, false, false);
+  for (int i = 0; i < 81; ++i) out[i] = -2.0 * T2[i];
+  // G_pp = X Clp^T GM Clp X = T1^T GM T1
+  mat_mul9(GM, T1, T2, false, false);   // T2 = GM T1
+  mat_mul9(T1, T2, T3, true, false);    // T3 = T1^T GM T1
+  for (int i = 0; i < 81; ++i) out[81 + i] = T3[i];
+}
+
+__global__ void rmi_finalize_kernel(const double* __restrict__ loss_bc, int B, int C,
+                                    float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int c = 0; c < C; ++c) {
+    double m = 0.0;
+    for (int b = 0; b < B; ++b) m += loss_bc[b * C + c];
+    s += m / (double)B / 9.0;
+  }
+  out[0] = (float)s;
+}
+
+// dP[bc,Y,X] = sum_j dpr_j(Y-dy_j, X-dx_j),
+// dpr_j(q) = sum_i Glp[i][j] (la_i(q)-mla_i) + 2 sum_i Gpp[j][i] (pr_i(q)-mpr_i)
+__global__ __launch_bounds__(NT) void rmi_bwd_pooled_kernel(const float* __restrict__ ppr,
+                                                            const float* __restrict__ pla,
+                                                            const double* __restrict__ gmat, int Hp,
+                                                            int Wp, float* __restrict__ dpooled) {
+  __shared__ double G[2 * 81 + 18];
+  const int bc = blockIdx.y;
+  for (int i = threadIdx.x; i < 2 * 81 + 18; i += NT) G[i] = gmat[(long)bc * (2 * 81 + 18) + i];
+  __syncthreads();
+  const int Hn = Hp - 2, Wn = Wp - 2;
+  const long cell = (long)blockIdx.x * NT + threadIdx.x;
+  if (cell >= (long)Hp * Wp) return;
+  const int Y = (int)(cell / Wp), X = (int)(cell - (long)Y * Wp);
+  const float* L = pla + (long)bc * Hp * Wp;
+  const float* P = ppr + (long)bc * Hp * Wp;
+  double acc = 0.0;
+  for (int j = 0; j < 9; ++j) {
+    const int y = Y - j / 3, x = X - j % 3;
+    if (y < 0 || y >= Hn || x < 0 || x >= Wn) continue;
+    double s = 0.0;
+    for (int i = 0; i < 9; ++i) {
+      const long o = (long)(y + i / 3) * Wp + (x + i % 3);
+      s += G[i * 9 + j] * ((double)L[o] - G[162 + i]);
+      s += 2.0 * G[81 + j * 9 + i] * ((double)P[o] - G[171 + i]);
+    }
+    acc += s;
+  }
+  dpooled[(long)bc * Hp * Wp + cell] = (float)acc;
+}
+
+__global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
+                                      const int64_t* __restrict__ labels, int B, int H, int W, int C,
+                                      const float* __restrict__ dpooled, int Hp, int Wp,
+                                      const float* __restrict__ upstream, double coef,
+                                      float* __restrict__ dlogits, int accumulate) {
+  const long n = (long)B * H * W * C;
+  const float k = (float)((double)upstream[0] * coef / 16.0);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long p = i / C;
+    const int x = (int)(p % W);
+    const long t = p / W;
+    const int y = (int)(t % H), b = (int)(t / H);
+    const long lab = labels[p];
+    float g = 0.f;
+    if (lab >= 0 && lab < C) {
+      const float s = 1.f / (1.f + expf(-logits[p * ld + c]));
+      const int py = (y + 2) >> 2, px = (x + 2) >> 2;
+      g = k * dpooled[(((long)b * C + c) * Hp + py) * Wp + px] * s * (1.f - s);
+    }
+    dlogits[i] = accumulate ? dlogits[i] + g : g;
+  }
+}
+
+inline int grid_for(long n, int cap = 8192) {
+  long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_ce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C, int ignore_index,
+               double* acc, float* dlogits, void* stream) {
+  if (!logits || !labels || !acc || P <= 0 || C <= 0 || C > 128) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(pixel_loss_kernel<0>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
+                     s, logits, ld, labels, P, C, ignore_index, acc, dlogits);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C, double* acc,
+                float* dlogits, void* stream) {
+  if (!logits || !labels || !acc || P <= 0 || C <= 0 || C > 128) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(pixel_loss_kernel<1>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
+                     s, logits, ld, labels, P, C, 0, acc, dlogits);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_loss_finalize(const double* acc, double denom_add, float* loss, void* stream) {
+  if (!acc || !loss) return SSA_EINVAL;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, denom_add, loss);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_scale_grad(float* g, long n, const float* upstream, double coef, const double* acc,
+                   double denom_add, void* stream) {
+  if (!g || !upstream || !acc || n <= 0) return SSA_EINVAL;
+  hipLaunchKernelGGL(scale_grad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n,
+                     upstream, coef, acc, denom_add);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_pool(const float* logits, int ld, const int64_t* labels, int B, int H, int W, int C,
+                 float* pooled_pr, float* pooled_la, int Hp, int Wp, void* stream) {
+  if (!logits || !labels || !pooled_pr || !pooled_la) return SSA_EINVAL;
+  if (Hp != H / 4 + 1 || Wp != W / 4 + 1) return SSA_EINVAL;
+  const size_t lds = (size_t)(4 * CELLS * 4 * C + 4 * CELLS * 4) * sizeof(float);
+  if (lds > 64000) return SSA_EUNSUPPORTED;
+  hipLaunchKernelGGL(rmi_pool_kernel, dim3((Wp + CELLS - 1) / CELLS, Hp, B), dim3(NT), lds,
+                     (hipStream_t)stream, logits, ld, labels, H, W, C, pooled_pr, pooled_la, Hp, Wp);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp, int Wp,
+                 double* gram, void* stream) {
+  if (!pooled_pr || !pooled_la || !gram || Hp < 3 || Wp < 3) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(gram, 0, sizeof(double) * NG * BC, s);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = (size_t)2 * (GROWS + 2) * Wp * sizeof(float);
+  if (lds > 60000) return SSA_EUNSUPPORTED;
+  hipLaunchKernelGGL(rmi_gram_kernel, dim3((Hp - 2 + GROWS - 1) / GROWS, BC), dim3(NT), lds, s,
+                     pooled_pr, pooled_la, Hp, Wp, gram);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_solve(const double* gram, int BC, int Hp, int Wp, double* loss_bc, double* gmat,
+                  void* stream) {
+  if (!gram || !loss_bc || !gmat) return SSA_EINVAL;
+  hipLaunchKernelGGL(rmi_solve_kernel, dim3(BC), dim3(64), 0, (hipStream_t)stream, gram, Hp, Wp,
+                     loss_bc, gmat);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_finalize(const double* loss_bc, int B, int C, float* out, void* stream) {
+  if (!loss_bc || !out) return SSA_EINVAL;
+  hipLaunchKernelGGL(rmi_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_bc, B, C, out);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_bwd_pooled(const float* pooled_pr, const float* pooled_la, const double* gmat, int BC,
+                       int Hp, int Wp, float* dpooled, void* stream) {
+  if (!pooled_pr || !pooled_la || !gmat || !dpooled) return SSA_EINVAL;
+  hipLaunchKernelGGL(rmi_bwd_pooled_kernel, dim3(((long)Hp * Wp + NT - 1) / NT, BC), dim3(NT), 0,
+                     (hipStream_t)stream, pooled_pr, pooled_la, gmat, Hp, Wp, dpooled);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B, int H, int W,
+                       int C, const float* dpooled, int Hp, int Wp, const float* upstream,
+                       double coef, float* dlogits, int accumulate, void* stream) {
+  if (!logits || !labels || !dpooled || !upstream || !dlogits) return SSA_EINVAL;
+  hipLaunchKernelGGL(rmi_bwd_logits_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0,
+                     (hipStream_t)stream, logits, ld, labels, B, H, W, C, dpooled, Hp, Wp, upstream,
+                     coef, dlogits, accumulate);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// Bilinear resampling, align_corners=False, on NHWC tensors.
+// Same index arithmetic as ATen's upsample_bilinear2d (fp32 source index,
+// negative source clamped to 0, i1 = i0 + (i0 < in-1)), which is what
+// F.interpolate does behind network/mynn.py:42-114 and
+// network/hrnetv2.py:246-249,440-445.
+// The backward is a gather over the output pixels that reference an input
+// pixel -- deterministic, no atomics.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+struct Src { int i0, i1; float l0, l1; };
+
+__device__ __forceinline__ Src src_index(int o, float scale, int in_size) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  Src r;
+  r.i0 = (int)s;
+  if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+  r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+  r.l1 = s - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+// ---- forward, 8 bf16 channels per thread
+__global__ void bilinear_fwd_v8(const bf16_t* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
+                                bf16_t* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw) {
+  const int VC = C >> 3;
+  const long n = (long)B * Ho * Wo * VC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % VC);
+    long t = i / VC;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const Src ys = src_index(oy, sh, Hi), xs = src_index(ox, sw, Wi);
+    const bf16_t* base = x + (long)b * Hi * Wi * ldx + cg * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(base + ((long)ys.i0 * Wi + xs.i0) * ldx), v00);
+    unpack8(*reinterpret_cast<const uint4*>(base + ((long)ys.i0 * Wi + xs.i1) * ldx), v01);
+    unpack8(*reinterpret_cast<const uint4*>(base + ((long)ys.i1 * Wi + xs.i0) * ldx), v10);
+    unpack8(*reinterpret_cast<const uint4*>(base + ((long)ys.i1 * Wi + xs.i1) * ldx), v11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = ys.l0 * (xs.l0 * v00[j] + xs.l1 * v01[j]) + ys.l1 * (xs.l0 * v10[j] + xs.l1 * v11[j]);
+    *reinterpret_cast<uint4*>(y + ((long)(b * Ho + oy) * Wo + ox) * ldy + cg * 8) = pack8(o);
+  }
+}
+
+// ---- forward, one element per thread (any C, any dtype pair)
+template <typename InT, typename OutT>
+__global__ void bilinear_fwd_s(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
+                               OutT* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw) {
+  const long n = (long)B * Ho * Wo * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const Src ys = src_index(oy, sh, Hi), xs = src_index(ox, sw, Wi);
+    const InT* base = x + (long)b * Hi * Wi * ldx + c;
+    const float v00 = ld_as_f32(base + ((long)ys.i0 * Wi + xs.i0) * ldx);
+    const float v01 = ld_as_f32(base + ((long)ys.i0 * Wi + xs.i1) * ldx);
+    const float v10 = ld_as_f32(base + ((long)ys.i1 * Wi + xs.i0) * ldx);
+    const float v11 = ld_as_f32(base + ((long)ys.i1 * Wi + xs.i1) * ldx);
+    const float o = ys.l0 * (xs.l0 * v00 + xs.l1 * v01) + ys.l1 * (xs.l0 * v10 + xs.l1 * v11);
+    st_from_f32(y + ((long)(b * Ho + oy) * Wo + ox) * ldy + c, o);
+  }
+}
+
+// candidate output range that can reference input index i
+__device__ __forceinline__ void cand_range(int i, float scale, int out_size, int* lo, int* hi) {
+  const float inv = 1.f / scale;
+  int a = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  int b = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  *lo = a < 0 ? 0 : a;
+  *hi = b > out_size - 1 ? out_size - 1 : b;
+}
+__device__ __forceinline__ float weight_for(int o, float scale, int in_size, int i) {
+  const Src s = src_index(o, scale, in_size);
+  float w = 0.f;
+  if (s.i0 == i) w += s.l0;
+  if (s.i1 == i) w += s.l1;
+  return w;
+}
+
+// ---- backward gather, 8 bf16 channels per thread
+__global__ void bilinear_bwd_v8(const bf16_t* __restrict__ dy, int B, int Ho, int Wo, int C,
+                                int lddy, bf16_t* __restrict__ dx, int Hi, int Wi, int lddx, float sh,
+                                float sw) {
+  const int VC = C >> 3;
+  const long n = (long)B * Hi * Wi * VC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % VC);
+    long t = i / VC;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, sh, Ho, &ylo, &yhi);
+    cand_range(ix, sw, Wo, &xlo, &xhi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const bf16_t* base = dy + (long)b * Ho * Wo * lddy + cg * 8;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = weight_for(oy, sh, Hi, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = weight_for(ox, sw, Wi, ix);
+        if (wx == 0.f) continue;
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(base + ((long)oy * Wo + ox) * lddy), g);
+        const float w = wy * wx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + cg * 8) = pack8(acc);
+  }
+}
+
+template <typename InT, typename OutT>
+__global__ void bilinear_bwd_s(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
+                               OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw) {
+  const long n = (long)B * Hi * Wi * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, sh, Ho, &ylo, &yhi);
+    cand_range(ix, sw, Wo, &xlo, &xhi);
+    float acc = 0.f;
+    const InT* base = dy + (long)b * Ho * Wo * lddy + c;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = weight_for(oy, sh, Hi, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = weight_for(ox, sw, Wi, ix);
+        if (wx == 0.f) continue;
+        acc += wy * wx * ld_as_f32(base + ((long)oy * Wo + ox) * lddy);
+      }
+    }
+    st_from_f32(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + c, acc);
+  }
+}
+
+// NCHW fp32 image -> (optionally resized) NHWC bf16, channels zero padded.
+// ResizeX(x, s) of network/mynn.py:101-114 fused with the layout change.
+__global__ void image_resize_kernel(const float* __restrict__ x, int B, int C, int Hi, int Wi,
+                                    bf16_t* __restrict__ y, int Ho, int Wo, int cpad, float sh,
+                                    float sw) {
+  const long n = (long)B * Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const Src ys = src_index(oy, sh, Hi), xs = src_index(ox, sw, Wi);
+    bf16_t* dst = y + i * cpad;
+    for (int c0 = 0; c0 < cpad; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        float v = 0.f;
+        if (c < C) {
+          const float* pl = x + ((long)b * C + c) * Hi * Wi;
+          const float v00 = pl[(long)ys.i0 * Wi + xs.i0], v01 = pl[(long)ys.i0 * Wi + xs.i1];
+          const float v10 = pl[(long)ys.i1 * Wi + xs.i0], v11 = pl[(long)ys.i1 * Wi + xs.i1];
+          v = ys.l0 * (xs.l0 * v00 + xs.l1 * v01) + ys.l1 * (xs.l0 * v10 + xs.l1 * v11);
+        }
+        f[j] = v;
+      }
+      *reinterpret_cast<uint4*>(dst + c0) = pack8(f);
+    }
+  }
+}
+
+inline int grid_for(long n) {
+  long b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C, int ldx, void* y,
+                     int out_dtype, int Ho, int Wo, int ldy, void* stream) {
+  if (!x || !y || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  const long n = (long)B * Ho * Wo * C;
+  if (in_dtype == 0 && out_dtype == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0) {
+    hipLaunchKernelGGL(bilinear_fwd_v8, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, B,
+                       Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
+  } else if (in_dtype == 0 && out_dtype == 0) {
+    hipLaunchKernelGGL((bilinear_fwd_s<bf16_t, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const bf16_t*)x, B, Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
+  } else if (in_dtype == 0 && out_dtype == 1) {
+    hipLaunchKernelGGL((bilinear_fwd_s<bf16_t, float>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const bf16_t*)x, B, Hi, Wi, C, ldx, (float*)y, Ho, Wo, ldy, sh, sw);
+  } else if (in_dtype == 1 && out_dtype == 1) {
+    hipLaunchKernelGGL((bilinear_fwd_s<float, float>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const float*)x, B, Hi, Wi, C, ldx, (float*)y, Ho, Wo, ldy, sh, sw);
+  } else if (in_dtype == 1 && out_dtype == 0) {
+    hipLaunchKernelGGL((bilinear_fwd_s<float, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const float*)x, B, Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
+  } else {
+    return SSA_EINVAL;
+  }
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C, int lddy, void* dx,
+                     int dx_dtype, int Hi, int Wi, int lddx, void* stream) {
+  if (!dy || !dx || B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || C <= 0) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  const long n = (long)B * Hi * Wi * C;
+  if (dy_dtype == 0 && dx_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0) {
+    hipLaunchKernelGGL(bilinear_bwd_v8, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)dy,
+                       B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
+  } else if (dy_dtype == 1 && dx_dtype == 1) {
+    hipLaunchKernelGGL((bilinear_bwd_s<float, float>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const float*)dy, B, Ho, Wo, C, lddy, (float*)dx, Hi, Wi, lddx, sh, sw);
+  } else if (dy_dtype == 1 && dx_dtype == 0) {
+    hipLaunchKernelGGL((bilinear_bwd_s<float, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const float*)dy, B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
+  } else if (dy_dtype == 0 && dx_dtype == 0) {
+    hipLaunchKernelGGL((bilinear_bwd_s<bf16_t, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
+                       (const bf16_t*)dy, B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
+  } else {
+    return SSA_EINVAL;
+  }
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_image_resize_to_nhwc_bf16(const float* x, int B, int C, int Hi, int Wi, void* y, int Ho,
+                                  int Wo, int cpad, void* stream) {
+  if (!x || !y || cpad % 8 || cpad < C || Ho <= 0 || Wo <= 0) return SSA_EINVAL;
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL(image_resize_kernel, dim3(grid_for((long)B * Ho * Wo)), dim3(256), 0,
+                     (hipStream_t)stream, x, B, C, Hi, Wi, (bf16_t*)y, Ho, Wo, cpad, sh, sw);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+}  // extern "C"

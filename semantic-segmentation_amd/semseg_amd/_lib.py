@@ -1,0 +1,115 @@
+"""ctypes binding of libsemseg_hip.so (the C ABI declared in include/semseg_hip.h).
+
+The library is the product: there is no Python/ATen fallback.  If the shared
+object is missing the loader raises, and every wrapper raises RuntimeError on a
+non-zero return code (the reference's own convention is plain Python
+exceptions, e.g. network/ocrnet.py:105).
+"""
+import ctypes
+import os
+from ctypes import c_int, c_long, c_float, c_double, c_void_p, c_size_t, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsemseg_hip.so"))
+
+_LIB = None
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ssa_conv_desc."""
+    _fields_ = [(n, c_int) for n in (
+        "B", "H", "W", "Cin", "ldx", "Ho", "Wo", "Cout", "ldy", "KH", "KW",
+        "stride", "pad", "dil", "transposed", "Kpad", "out_f32", "cfg")]
+
+
+_P = c_void_p
+_SIGS = {
+    "ssa_version": ([], c_int),
+    "ssa_conv2d_igemm": ([POINTER(ConvDesc), _P, _P, _P, _P, _P], c_int),
+    "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
+    "ssa_conv2d_wgrad_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
+    "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, _P], c_int),
+    "ssa_colsum_bf16": ([_P, c_long, c_int, c_int, _P, _P, _P], c_int),
+    "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
+    "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, _P], c_int),
+    "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,
+                         _P, _P, _P, _P, _P], c_int),
+    "ssa_bn_apply": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
+                      c_long, _P], c_int),
+    "ssa_bn_bwd_reduce": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
+                           c_long, _P, _P], c_int),
+    "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
+                          _P, _P, _P, _P, c_double, c_int, _P, c_long, _P], c_int),
+    "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
+    "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
+    "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),
+    "ssa_nchw_f32_to_nhwc_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "ssa_image_resize_to_nhwc_bf16": ([_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P], c_int),
+    "ssa_bilinear_fwd": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                          c_int, _P], c_int),
+    "ssa_bilinear_bwd": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,
+                          c_int, _P], c_int),
+    "ssa_softmax_hw_stats": ([_P, c_int, c_long, c_int, _P, _P], c_int),
+    "ssa_softmax_hw_probs": ([_P, c_int, c_long, c_int, _P, _P, c_int, _P], c_int),
+    "ssa_rowdot_f32": ([_P, _P, c_int, c_int, _P, _P], c_int),
+    "ssa_softmax_hw_bwd": ([_P, c_int, c_long, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P], c_int),
+    "ssa_softmax_lastdim_fwd": ([_P, c_int, c_long, c_int, c_float, _P, c_int, _P], c_int),
+    "ssa_softmax_lastdim_bwd": ([_P, c_int, c_long, c_int, c_float, _P, c_int, _P, c_int, _P], c_int),
+    "ssa_pack_matrix": ([_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P], c_int),
+    "ssa_sigmoid_fwd": ([_P, _P, c_long, _P], c_int),
+    "ssa_sigmoid_bwd": ([_P, _P, _P, c_long, _P], c_int),
+    "ssa_bcast_mul_fwd": ([_P, _P, _P, c_long, c_int, _P], c_int),
+    "ssa_bcast_mul_bwd": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
+    "ssa_attn_blend_fwd": ([_P, _P, _P, _P, c_long, c_int, _P], c_int),
+    "ssa_attn_blend_bwd": ([_P, _P, _P, _P, _P, c_long, c_int, c_int, _P], c_int),
+    "ssa_ce_fwd": ([_P, c_int, _P, c_long, c_int, c_int, _P, _P, _P], c_int),
+    "ssa_bce_fwd": ([_P, c_int, _P, c_long, c_int, _P, _P, _P], c_int),
+    "ssa_loss_finalize": ([_P, c_double, _P, _P], c_int),
+    "ssa_scale_grad": ([_P, c_long, _P, c_double, _P, c_double, _P], c_int),
+    "ssa_rmi_pool": ([_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P], c_int),
+    "ssa_rmi_gram": ([_P, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "ssa_rmi_solve": ([_P, c_int, c_int, c_int, _P, _P, _P], c_int),
+    "ssa_rmi_finalize": ([_P, c_int, c_int, _P, _P], c_int),
+    "ssa_rmi_bwd_pooled": ([_P, _P, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "ssa_rmi_bwd_logits": ([_P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P,
+                            c_double, _P, c_int, _P], c_int),
+    "ssa_axpy_f32": ([_P, c_float, _P, c_long, c_int, _P], c_int),
+    "ssa_probe_mfma32": ([_P, _P, _P, _P], c_int),
+    "ssa_probe_tr16": ([_P, c_int, _P], c_int),
+}
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libsemseg_hip.so (once).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libsemseg_hip.so not found at %s -- the HIP extension is required "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no "
+                "fallback path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        missing = []
+        for name, (argtypes, restype) in _SIGS.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.argtypes = argtypes
+            fn.restype = restype
+        if missing:
+            raise RuntimeError("libsemseg_hip.so is stale, missing symbols: %s" % ", ".join(missing))
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, "hipError %d" % rc)
+        raise RuntimeError("%s failed: %s" % (what, kind))
