@@ -1,0 +1,638 @@
+"""HIP backend: autograd.Function wrappers over the C ABI of libsemseg_hip.so.
+
+Every tensor-valued op of the HRNet-OCR-MScale hot path goes through here; the
+arithmetic lives in csrc/*.hip.  Activations are NHWC ([B,H,W,C]) bf16, logits
+and losses fp32.  PyTorch provides device memory, streams and autograd
+bookkeeping only.  Nothing here falls back to ATen math: a missing or stale
+library raises in `_lib.lib()`.
+
+hipGraph-capture safe: no host synchronisation, no `.item()`, allocations come
+from torch's caching allocator, kernels are enqueued on the current stream.
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from ._lib import lib, check, ConvDesc
+
+ACT_DTYPE = torch.bfloat16
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _pixels(t):
+    """Return (tensor, ld) with `tensor` [B,H,W,C] laid out as dense pixels of
+    stride `ld` elements and unit channel stride (a channel slice of a wider
+    NHWC buffer qualifies).  Copies only if the layout does not qualify."""
+    assert t.dim() == 4
+    B, H, W, C = t.shape
+    sb, sh, sw, sc = t.stride()
+    ok = (sc == 1 or C == 1)
+    ld = None
+    for size, stride, mult in ((W, sw, 1), (H, sh, W), (B, sb, H * W)):
+        if size > 1:
+            if stride % mult:
+                ok = False
+                break
+            cand = stride // mult
+            if ld is None:
+                ld = cand
+            elif cand != ld:
+                ok = False
+                break
+    if ld is None:
+        ld = C
+    if not ok or ld < C:
+        t = t.contiguous()
+        ld = C
+    return t, ld
+
+
+# --------------------------------------------------------------------------
+# packed filter cache (cleared at the start of every top-level forward so the
+# packing kernels are re-issued -- and captured -- once per step)
+# --------------------------------------------------------------------------
+_PACKED = {}
+
+
+def clear_pack_cache():
+    _PACKED.clear()
+
+
+def _packed_filter(weight, mode, cin_pad, cout_pad):
+    key = (weight.data_ptr(), weight._version, mode, cin_pad, cout_pad)
+    hit = _PACKED.get(key)
+    if hit is not None:
+        return hit
+    Cout, Cin, KH, KW = weight.shape
+    if mode == 0:
+        rows, kdim = Cout, KH * KW * cin_pad
+    else:
+        rows, kdim = Cin, KH * KW * cout_pad
+    Kpad = _roundup(kdim, 32)
+    out = torch.empty((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    check(lib().ssa_pack_filter(_p(w), _p(out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, _s()),
+          "ssa_pack_filter")
+    _PACKED[key] = (out, Kpad)
+    return out, Kpad
+
+
+def _pack_matrix(src, R, C, ld, transpose, rows_out, Kpad):
+    out = torch.empty((rows_out, Kpad), dtype=ACT_DTYPE, device=src.device)
+    dt = 0 if src.dtype == ACT_DTYPE else 1
+    check(lib().ssa_pack_matrix(_p(src), dt, R, C, ld, int(transpose), _p(out), rows_out, Kpad, _s()),
+          "ssa_pack_matrix")
+    return out
+
+
+def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
+           cfg=-1):
+    """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
+    B, H, W, Cin = geom_in
+    Ho, Wo = geom_out
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE, device=x.device)
+    d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, int(transposed),
+                 Kpad, int(out_f32), cfg)
+    check(lib().ssa_conv2d_igemm(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _s()), "ssa_conv2d_igemm")
+    return y
+
+
+def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real):
+    """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)]."""
+    B, H, W, Cin = geom_in
+    Ho, Wo = geom_out
+    d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, 0, 0, 0, -1)
+    nsplit = ctypes.c_int(0)
+    ws = ctypes.c_size_t(0)
+    L = lib()
+    check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
+          "ssa_conv2d_wgrad_plan")
+    partial = torch.empty((ws.value // 4,), dtype=torch.float32, device=x.device)
+    check(L.ssa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), lddy, cout_pad, nsplit.value, _p(partial), _s()),
+          "ssa_conv2d_wgrad")
+    dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
+    check(L.ssa_conv2d_wgrad_reduce(_p(partial), nsplit.value, cout_pad, Cout, Cin, Cin_real, k[0], k[1],
+                                    _p(dw), _s()), "ssa_conv2d_wgrad_reduce")
+    return dw
+
+
+def _grad_as_bf16(dy, Cout):
+    """Incoming gradient -> bf16 [B,H,W,cout_pad] dense pixels."""
+    cout_pad = _roundup(Cout, 8)
+    if dy.dtype == ACT_DTYPE and cout_pad == Cout:
+        dyb, ld = _pixels(dy)
+        if ld % 8 or dyb.data_ptr() % 16:
+            dyb, ld = dyb.contiguous(), Cout
+        return dyb, ld, cout_pad
+    dyf = dy.float()
+    dyf, ldf = _pixels(dyf)
+    B, H, W, _ = dyf.shape
+    out = torch.empty((B, H, W, cout_pad), dtype=ACT_DTYPE, device=dy.device)
+    check(lib().ssa_pad_cast_f32_bf16(_p(dyf), B * H * W, Cout, ldf, _p(out), cout_pad, _s()),
+          "ssa_pad_cast_f32_bf16")
+    return out, cout_pad, cout_pad
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward (groups=1).  x NHWC bf16, weight OIHW fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil, out_f32):
+        x, ldx = _pixels(x)
+        B, H, W, Cin = x.shape
+        Cout, Cin_real, KH, KW = weight.shape
+        assert Cin >= Cin_real and Cin % 8 == 0, (Cin, Cin_real)
+        Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        wp, Kpad = _packed_filter(weight, 0, Cin, 0)
+        b = None
+        if bias is not None:
+            b = bias.detach()
+            if b.dtype != torch.float32:
+                b = b.float()
+        if not out_f32:
+            assert Cout % 8 == 0, "bf16 conv outputs need Cout % 8 == 0"
+        y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
+                   out_f32)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (ldx, stride, pad, dil, bias is not None, (Ho, Wo))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        ldx, stride, pad, dil, has_bias, (Ho, Wo) = ctx.meta
+        B, H, W, Cin = x.shape
+        Cout, Cin_real, KH, KW = weight.shape
+        dyb, lddy, cout_pad = _grad_as_bf16(dy, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            assert Cin == Cin_real
+            wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
+            dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
+                        dil * (KH - 1) - pad, dil, stride > 1, False)
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(x, ldx, (B, H, W, Cin), dyb, lddy, cout_pad, (Ho, Wo), (KH, KW), stride, pad, dil,
+                        Cout, Cin_real)
+            if dw.dtype != weight.dtype:
+                dw = dw.to(weight.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            out = torch.empty((cout_pad,), dtype=torch.float32, device=x.device)
+            scratch = torch.empty((2 * cout_pad,), dtype=torch.float64, device=x.device)
+            check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()),
+                  "ssa_colsum_bf16")
+            db = out[:Cout]
+        return dx, dw, db, None, None, None, None
+
+
+# --------------------------------------------------------------------------
+# batch norm (+ residual add + ReLU + per-(b,c) post scale = Dropout2d mask)
+# --------------------------------------------------------------------------
+def _sync_world(sync):
+    if sync and dist.is_available() and dist.is_initialized():
+        ws = dist.get_world_size()
+        return ws if ws > 1 else 0
+    return 0
+
+
+class BatchNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, momentum, eps, training,
+                relu, sync):
+        L = lib()
+        x, ldx = _pixels(x)
+        B, H, W, C = x.shape
+        P = B * H * W
+        dev = x.device
+        g = gamma.detach().float() if gamma is not None else None
+        bta = beta.detach().float() if beta is not None else None
+        coef = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
+        world = _sync_world(sync) if training else 0
+        count = float(P)
+        if training:
+            sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+            check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), _s()), "ssa_bn_stats")
+            if world:
+                dist.all_reduce(sums)
+                count = float(P * world)
+            check(L.ssa_bn_finalize(_p(sums), count, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
+                                    float(momentum), float(eps), 0, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                    _p(coef[3]), _s()), "ssa_bn_finalize")
+        else:
+            check(L.ssa_bn_finalize(None, 1.0, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
+                                    float(momentum), float(eps), 1, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                    _p(coef[3]), _s()), "ssa_bn_finalize")
+        res = ldr = None
+        if residual is not None:
+            res, ldr = _pixels(residual)
+        z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
+        pst = post.float().contiguous() if post is not None else None
+        check(L.ssa_bn_apply(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(coef[0]), _p(coef[1]),
+                             int(relu), _p(pst), H * W, _s()), "ssa_bn_apply")
+        ctx.save_for_backward(x, z if relu else None, g, coef, pst)
+        ctx.meta = (ldx, relu, training, world, residual is not None, count)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = lib()
+        x, z, g, coef, pst = ctx.saved_tensors
+        ldx, relu, training, world, has_res, count = ctx.meta
+        B, H, W, C = x.shape
+        P = B * H * W
+        dev = x.device
+        dz, lddz = _pixels(dz if dz.dtype == ACT_DTYPE else dz.to(ACT_DTYPE))
+        if lddz % 8 or dz.data_ptr() % 16:
+            dz, lddz = dz.contiguous(), C
+        sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
+                                  int(relu), _p(pst), H * W, _p(sums), _s()), "ssa_bn_bwd_reduce")
+        dgamma = dbeta = None
+        if g is not None:
+            pg = torch.empty((2, C), dtype=torch.float32, device=dev)
+            check(L.ssa_bn_param_grads(_p(sums), C, _p(pg[0]), _p(pg[1]), _s()), "ssa_bn_param_grads")
+            dgamma, dbeta = pg[0], pg[1]
+        if training:
+            if world:
+                dist.all_reduce(sums)
+        else:
+            sums = torch.zeros_like(sums)  # eval-mode BN: statistics are constants
+        dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
+        dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if has_res else None
+        check(L.ssa_bn_bwd_apply(_p(x), ldx, _p(dz), lddz, _p(z), C, _p(dx), C, _p(dres), C, P, C, _p(g),
+                                 _p(coef[2]), _p(coef[3]), _p(sums), count, int(relu), _p(pst), H * W, _s()),
+              "ssa_bn_bwd_apply")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+
+
+class SumActFn(torch.autograd.Function):
+    """z = relu(sum of up to 4 same-shape bf16 tensors): HRNet fuse sum."""
+
+    @staticmethod
+    def forward(ctx, relu, *ts):
+        assert 1 <= len(ts) <= 4
+        cs = [t.contiguous() for t in ts]
+        z = torch.empty_like(cs[0])
+        n = z.numel()
+        args = [_p(c) for c in cs] + [None] * (4 - len(cs))
+        check(lib().ssa_sum_act(args[0], args[1], args[2], args[3], _p(z), n, int(relu), _s()), "ssa_sum_act")
+        ctx.relu = relu
+        ctx.n_in = len(ts)
+        if relu:
+            ctx.save_for_backward(z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        dz = dz.contiguous()
+        if ctx.relu:
+            (z,) = ctx.saved_tensors
+            g = torch.empty_like(z)
+            check(lib().ssa_relu_bwd(_p(dz), _p(z), _p(g), z.numel(), _s()), "ssa_relu_bwd")
+        else:
+            g = dz
+        return (None,) + (g,) * ctx.n_in
+
+
+def _dt(t):
+    if t.dtype == ACT_DTYPE:
+        return 0
+    if t.dtype == torch.float32:
+        return 1
+    raise TypeError(t.dtype)
+
+
+class BilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, out_f32):
+        x, ldx = _pixels(x)
+        B, Hi, Wi, C = x.shape
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        check(lib().ssa_bilinear_fwd(_p(x), _dt(x), B, Hi, Wi, C, ldx, _p(y), _dt(y), Ho, Wo, C, _s()),
+              "ssa_bilinear_fwd")
+        ctx.meta = (B, Hi, Wi, C, Ho, Wo, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Hi, Wi, C, Ho, Wo, in_dtype = ctx.meta
+        dy, lddy = _pixels(dy)
+        if dy.dtype == ACT_DTYPE and (lddy % 8 or dy.data_ptr() % 16):
+            dy, lddy = dy.contiguous(), C
+        dx = torch.empty((B, Hi, Wi, C), dtype=in_dtype, device=dy.device)
+        check(lib().ssa_bilinear_bwd(_p(dy), _dt(dy), B, Ho, Wo, C, lddy, _p(dx), _dt(dx), Hi, Wi, C, _s()),
+              "ssa_bilinear_bwd")
+        return dx, None, None, None
+
+
+def image_to_nhwc(images, out_hw=None, cpad=16):
+    """NCHW fp32 image batch -> NHWC bf16, optionally bilinearly resized."""
+    images = images.detach()
+    if images.dtype != torch.float32 or not images.is_contiguous():
+        images = images.float().contiguous()
+    B, C, H, W = images.shape
+    Ho, Wo = out_hw if out_hw is not None else (H, W)
+    y = torch.empty((B, Ho, Wo, cpad), dtype=ACT_DTYPE, device=images.device)
+    check(lib().ssa_image_resize_to_nhwc_bf16(_p(images), B, C, H, W, _p(y), Ho, Wo, cpad, _s()),
+          "ssa_image_resize_to_nhwc_bf16")
+    return y
+
+
+# --------------------------------------------------------------------------
+# OCR
+# --------------------------------------------------------------------------
+class OcrGatherFn(torch.autograd.Function):
+    """ctx[b,k,c] = sum_p softmax_HW(logits)[b,p,k] * feats[b,p,c].
+    feats bf16 [B,H,W,C]; logits fp32 [B,H,W,K]; returns fp32 [B,K,C]."""
+
+    @staticmethod
+    def forward(ctx, feats, logits):
+        L = lib()
+        feats, ldf = _pixels(feats)
+        logits, ldl = _pixels(logits.float())
+        B, H, W, C = feats.shape
+        K = logits.shape[3]
+        Kp = _roundup(K, 32)
+        HW = H * W
+        dev = feats.device
+        rowstat = torch.empty((B, K, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((B, K, C), dtype=torch.float32, device=dev)
+        for b in range(B):
+            check(L.ssa_softmax_hw_stats(_p(logits[b]), ldl, HW, K, _p(rowstat[b]), _s()), "ssa_softmax_hw_stats")
+            probs = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
+            check(L.ssa_softmax_hw_probs(_p(logits[b]), ldl, HW, K, _p(rowstat[b]), _p(probs), Kp, _s()),
+                  "ssa_softmax_hw_probs")
+            dw = _wgrad(feats[b], ldf, (1, H, W, C), probs, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, C)
+            out[b] = dw.view(K, C)
+        ctx.save_for_backward(feats, logits, rowstat, out)
+        ctx.meta = (ldf, ldl)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        L = lib()
+        feats, logits, rowstat, out = ctx.saved_tensors
+        ldf, ldl = ctx.meta
+        B, H, W, C = feats.shape
+        K = logits.shape[3]
+        Kp = _roundup(K, 32)
+        HW = H * W
+        dev = feats.device
+        dctx = dctx.float().contiguous()
+        dfeats = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if ctx.needs_input_grad[0] else None
+        dlogits = torch.empty((B, H, W, K), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        for b in range(B):
+            if dfeats is not None:
+                probs = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
+                check(L.ssa_softmax_hw_probs(_p(logits[b]), ldl, HW, K, _p(rowstat[b]), _p(probs), Kp, _s()),
+                      "ssa_softmax_hw_probs")
+                wp = _pack_matrix(dctx[b], K, C, C, True, C, Kp)          # [C][Kp]: dctx^T
+                dfeats[b] = _igemm(probs, Kp, (1, H, W, Kp), wp, Kp, None, (H, W), C, (1, 1), 1, 0, 1, False,
+                                   False)[0]
+            if dlogits is not None:
+                Cp = _roundup(C, 32)
+                wp = _pack_matrix(dctx[b], K, C, C, False, K, Cp)         # [K][Cp]
+                dprobs = _igemm(feats[b], ldf, (1, H, W, C), wp, Cp, None, (H, W), K, (1, 1), 1, 0, 1, False,
+                                True)
+                dot = torch.empty((K,), dtype=torch.float32, device=dev)
+                check(L.ssa_rowdot_f32(_p(out[b]), _p(dctx[b]), K, C, _p(dot), _s()), "ssa_rowdot_f32")
+                check(L.ssa_softmax_hw_bwd(_p(logits[b]), ldl, HW, K, _p(rowstat[b]), _p(dprobs), K, _p(dot),
+                                           _p(dlogits[b]), K, 0, _s()), "ssa_softmax_hw_bwd")
+        return dfeats, dlogits
+
+
+class OcrAttnFn(torch.autograd.Function):
+    """out = softmax_k(scale * q k^T) v per image.  q [B,H,W,D] bf16; k,v [B,K,D] bf16."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        L = lib()
+        q, ldq = _pixels(q)
+        k = k.contiguous()
+        v = v.contiguous()
+        B, H, W, D = q.shape
+        K = k.shape[1]
+        Kp = _roundup(K, 32)
+        Dp = _roundup(D, 32)
+        dev = q.device
+        out = torch.empty((B, H, W, D), dtype=ACT_DTYPE, device=dev)
+        sim = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
+        for b in range(B):
+            wk = _pack_matrix(k[b], K, D, D, False, K, Dp)                 # [K][Dp]
+            sim[b] = _igemm(q[b], ldq, (1, H, W, D), wk, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True)[0]
+            probs = torch.empty((H * W, Kp), dtype=ACT_DTYPE, device=dev)
+            check(L.ssa_softmax_lastdim_fwd(_p(sim[b]), K, H * W, K, float(scale), _p(probs), Kp, _s()),
+                  "ssa_softmax_lastdim_fwd")
+            wv = _pack_matrix(v[b], K, D, D, True, D, Kp)                  # [D][Kp]: v^T
+            out[b] = _igemm(probs, Kp, (1, H, W, Kp), wv, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+        ctx.save_for_backward(q, k, v, sim)
+        ctx.meta = (ldq, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = lib()
+        q, k, v, sim = ctx.saved_tensors
+        ldq, scale = ctx.meta
+        B, H, W, D = q.shape
+        K = k.shape[1]
+        Kp = _roundup(K, 32)
+        Dp = _roundup(D, 32)
+        HW = H * W
+        dev = q.device
+        dout, lddo = _pixels(dout if dout.dtype == ACT_DTYPE else dout.to(ACT_DTYPE))
+        if lddo % 8 or dout.data_ptr() % 16:
+            dout, lddo = dout.contiguous(), D
+        dq = torch.empty((B, H, W, D), dtype=ACT_DTYPE, device=dev)
+        dk = torch.empty((B, K, D), dtype=torch.float32, device=dev)
+        dv = torch.empty((B, K, D), dtype=torch.float32, device=dev)
+        for b in range(B):
+            probs = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
+            check(L.ssa_softmax_lastdim_fwd(_p(sim[b]), K, HW, K, scale, _p(probs), Kp, _s()),
+                  "ssa_softmax_lastdim_fwd")
+            wv = _pack_matrix(v[b], K, D, D, False, K, Dp)                 # [K][Dp]
+            dprobs = _igemm(dout[b], lddo, (1, H, W, D), wv, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True)
+            dv[b] = _wgrad(dout[b], lddo, (1, H, W, D), probs, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
+            dsim = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
+            check(L.ssa_softmax_lastdim_bwd(_p(sim[b]), K, HW, K, scale, _p(dprobs), K, _p(dsim), Kp, _s()),
+                  "ssa_softmax_lastdim_bwd")
+            wk = _pack_matrix(k[b], K, D, D, True, D, Kp)                  # [D][Kp]: k^T
+            dq[b] = _igemm(dsim, Kp, (1, H, W, Kp), wk, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+            dk[b] = _wgrad(q[b], ldq, (1, H, W, D), dsim, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
+        return dq, dk.to(k.dtype), dv.to(v.dtype), None
+
+
+# --------------------------------------------------------------------------
+# scale-attention fusion pieces (fp32, [B,H,W,C] with a [B,H,W,1] attention map)
+# --------------------------------------------------------------------------
+class SigmoidFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float().contiguous()
+        y = torch.empty_like(x)
+        check(lib().ssa_sigmoid_fwd(_p(x), _p(y), x.numel(), _s()), "ssa_sigmoid_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(y)
+        check(lib().ssa_sigmoid_bwd(_p(y), _p(dy), _p(dx), y.numel(), _s()), "ssa_sigmoid_bwd")
+        return dx
+
+
+class BcastMulFn(torch.autograd.Function):
+    """out[b,h,w,c] = a[b,h,w,0] * x[b,h,w,c]"""
+
+    @staticmethod
+    def forward(ctx, a, x):
+        a = a.float().contiguous()
+        x = x.float().contiguous()
+        out = torch.empty_like(x)
+        P, C = a.numel(), x.shape[-1]
+        check(lib().ssa_bcast_mul_fwd(_p(a), _p(x), _p(out), P, C, _s()), "ssa_bcast_mul_fwd")
+        ctx.save_for_backward(a, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, x = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        da = torch.empty_like(a)
+        dx = torch.empty_like(x)
+        check(lib().ssa_bcast_mul_bwd(_p(a), _p(x), _p(dout), _p(da), _p(dx), a.numel(), x.shape[-1], _s()),
+              "ssa_bcast_mul_bwd")
+        return da, dx
+
+
+class AttnBlendFn(torch.autograd.Function):
+    """joint = lo + (1 - a) * hi"""
+
+    @staticmethod
+    def forward(ctx, lo, a, hi):
+        lo = lo.float().contiguous()
+        a = a.float().contiguous()
+        hi = hi.float().contiguous()
+        out = torch.empty_like(hi)
+        check(lib().ssa_attn_blend_fwd(_p(lo), _p(a), _p(hi), _p(out), a.numel(), hi.shape[-1], _s()),
+              "ssa_attn_blend_fwd")
+        ctx.save_for_backward(a, hi)
+        return out
+
+    @staticmethod
+    def backward(ctx, dj):
+        a, hi = ctx.saved_tensors
+        dj = dj.float().contiguous()
+        da = torch.empty_like(a)
+        dhi = torch.empty_like(hi)
+        check(lib().ssa_attn_blend_bwd(_p(a), _p(hi), _p(dj), _p(da), _p(dhi), a.numel(), hi.shape[-1], 0, _s()),
+              "ssa_attn_blend_bwd")
+        return dj, da, dhi
+
+
+# --------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        logits, ld = _pixels(logits.float())
+        B, H, W, C = logits.shape
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        dev = logits.device
+        acc = torch.empty((2,), dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if need else None
+        check(lib().ssa_ce_fwd(_p(logits), ld, _p(labels), B * H * W, C, int(ignore_index), _p(acc), _p(dl), _s()),
+              "ssa_ce_fwd")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        check(lib().ssa_loss_finalize(_p(acc), 0.0, _p(loss), _s()), "ssa_loss_finalize")
+        ctx.save_for_backward(dl, acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, up):
+        dl, acc = ctx.saved_tensors
+        up = up.float().contiguous()
+        g = dl.clone()
+        check(lib().ssa_scale_grad(_p(g), g.numel(), _p(up), 1.0, _p(acc), 0.0, _s()), "ssa_scale_grad")
+        return g, None, None
+
+
+class BceRmiFn(torch.autograd.Function):
+    """RMILoss.forward_sigmoid: masked BCE, optionally 0.5*bce + 0.5*rmi."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, do_rmi, weight_lambda):
+        L = lib()
+        logits, ld = _pixels(logits.float())
+        B, H, W, C = logits.shape
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        dev = logits.device
+        acc = torch.empty((2,), dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if need else None
+        check(L.ssa_bce_fwd(_p(logits), ld, _p(labels), B * H * W, C, _p(acc), _p(dl), _s()), "ssa_bce_fwd")
+        bce = torch.empty((), dtype=torch.float32, device=dev)
+        check(L.ssa_loss_finalize(_p(acc), 1.0, _p(bce), _s()), "ssa_loss_finalize")
+        ctx.do_rmi = bool(do_rmi)
+        ctx.lam = float(weight_lambda)
+        if not do_rmi:
+            ctx.save_for_backward(dl, acc)
+            return bce
+        Hp, Wp = H // 4 + 1, W // 4 + 1
+        ppr = torch.empty((B * C, Hp, Wp), dtype=torch.float32, device=dev)
+        pla = torch.empty((B * C, Hp, Wp), dtype=torch.float32, device=dev)
+        check(L.ssa_rmi_pool(_p(logits), ld, _p(labels), B, H, W, C, _p(ppr), _p(pla), Hp, Wp, _s()), "ssa_rmi_pool")
+        gram = torch.empty((B * C, 189), dtype=torch.float64, device=dev)
+        check(L.ssa_rmi_gram(_p(ppr), _p(pla), B * C, Hp, Wp, _p(gram), _s()), "ssa_rmi_gram")
+        loss_bc = torch.empty((B * C,), dtype=torch.float64, device=dev)
+        gmat = torch.empty((B * C, 180), dtype=torch.float64, device=dev)
+        check(L.ssa_rmi_solve(_p(gram), B * C, Hp, Wp, _p(loss_bc), _p(gmat), _s()), "ssa_rmi_solve")
+        rmi = torch.empty((), dtype=torch.float32, device=dev)
+        check(L.ssa_rmi_finalize(_p(loss_bc), B, C, _p(rmi), _s()), "ssa_rmi_finalize")
+        ctx.save_for_backward(dl, acc, logits, labels, ppr, pla, gmat)
+        ctx.ld = ld
+        return ctx.lam * bce + (1.0 - ctx.lam) * rmi
+
+    @staticmethod
+    def backward(ctx, up):
+        L = lib()
+        up = up.float().contiguous()
+        if not ctx.do_rmi:
+            dl, acc = ctx.saved_tensors
+            g = dl.clone()
+            check(L.ssa_scale_grad(_p(g), g.numel(), _p(up), 1.0, _p(acc), 1.0, _s()), "ssa_scale_grad")
+            return g, None, None, None
+        dl, acc, logits, labels, ppr, pla, gmat = ctx.saved_tensors
+        B, H, W, C = logits.shape
+        Hp, Wp = ppr.shape[1], ppr.shape[2]
+        g = dl.clone()
+        check(L.ssa_scale_grad(_p(g), g.numel(), _p(up), ctx.lam, _p(acc), 1.0, _s()), "ssa_scale_grad")
+        dpool = torch.empty_like(ppr)
+        check(L.ssa_rmi_bwd_pooled(_p(ppr), _p(pla), _p(gmat), B * C, Hp, Wp, _p(dpool), _s()), "ssa_rmi_bwd_pooled")
+        coef = (1.0 - ctx.lam) / (9.0 * B)
+        check(L.ssa_rmi_bwd_logits(_p(logits), ctx.ld, _p(labels), B, H, W, C, _p(dpool), Hp, Wp, _p(up), coef,
+                                   _p(g), 1, _s()), "ssa_rmi_bwd_logits")
+        return g, None, None, None

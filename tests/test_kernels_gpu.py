@@ -1,0 +1,396 @@
+"""Op-level parity: every HIP kernel (through the C ABI) against the oracle
+(oracle/ops.py, CPU fp32/fp64) on identical seeded inputs.
+
+Tolerance (stated once): activations are bf16, accumulation fp32.  Inputs and
+weights are rounded to bf16 before BOTH paths, so the only differences are the
+fp32 accumulation order and one bf16 rounding of the output (2^-9 relative):
+max error <= 1e-2 * max|ref|, mean error <= 4e-3 * mean|ref|.  fp32-out ops
+use 2e-3 / 5e-4, fp64 RMI statistics 1e-4.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+from util import bf16_round, check_close, report, nhwc, nchw
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _hb():
+    from semseg_amd import hip_backend
+    return hip_backend
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf16_round(torch.randn(*shape, generator=g) * scale)
+
+
+# ----------------------------------------------------------------- probes
+def test_probe_mfma32(out_dir):
+    from semseg_amd._lib import lib, check
+    import ctypes
+    a = _rand(32, 16, seed=1)
+    b = _rand(16, 32, seed=2)       # asymmetric on purpose
+    a_d = a.to(DEV).to(torch.bfloat16).contiguous()
+    bt_d = b.t().contiguous().to(DEV).to(torch.bfloat16)
+    c_d = torch.zeros(32, 32, device=DEV)
+    check(lib().ssa_probe_mfma32(ctypes.c_void_p(a_d.data_ptr()), ctypes.c_void_p(bt_d.data_ptr()),
+                                 ctypes.c_void_p(c_d.data_ptr()), None), "probe")
+    torch.cuda.synchronize()
+    check_close("mfma32", c_d, a @ b, 1e-5, 1e-5)
+
+
+def test_probe_tr16(out_dir):
+    from semseg_amd._lib import lib, check
+    import ctypes
+    with open(os.path.join(out_dir, "probe_tr16.txt"), "w") as f:
+        for mode in (0, 1, 2):
+            out = torch.zeros(256, dtype=torch.int16, device=DEV)
+            check(lib().ssa_probe_tr16(ctypes.c_void_p(out.data_ptr()), mode, None), "probe_tr16")
+            torch.cuda.synchronize()
+            v = out.cpu().view(64, 4).tolist()
+            f.write("mode %d\n" % mode)
+            for l, row in enumerate(v):
+                f.write("lane %2d: %s\n" % (l, row))
+    assert True
+
+
+# ------------------------------------------------------------------- conv
+CONV_CASES = [
+    # B, H, W, Cin(real), Cout, k, stride, pad, dil, bias, out_f32
+    (2, 40, 56, 48, 48, 3, 1, 1, 1, False, False),
+    (1, 64, 64, 3, 64, 3, 2, 1, 1, False, False),
+    (2, 33, 47, 64, 256, 1, 1, 0, 1, False, False),
+    (1, 48, 40, 96, 192, 3, 2, 1, 1, False, False),
+    (1, 24, 24, 720, 512, 3, 1, 1, 1, True, False),
+    (2, 32, 32, 512, 19, 1, 1, 0, 1, True, True),
+    (1, 32, 32, 256, 1, 1, 1, 0, 1, False, True),
+    (1, 40, 40, 64, 32, 3, 1, 12, 12, False, False),
+    (1, 16, 16, 384, 384, 3, 1, 1, 1, False, False),
+    (1, 37, 29, 96, 96, 3, 1, 1, 1, False, False),
+    (1, 19, 1, 512, 256, 1, 1, 0, 1, False, False),
+]
+
+
+def _conv_inputs(case, seed=0):
+    B, H, W, Cin, Cout, k, s, p, d, bias, out_f32 = case
+    x = _rand(B, Cin, H, W, seed=seed)
+    w = _rand(Cout, Cin, k, k, seed=seed + 1, scale=1.0 / math.sqrt(Cin * k * k))
+    b = _rand(Cout, seed=seed + 2) if bias else None
+    return x, w, b
+
+
+def _to_dev_nhwc(x, cpad=None):
+    t = nhwc(x)
+    if cpad is not None and cpad > t.shape[3]:
+        t = torch.nn.functional.pad(t, (0, cpad - t.shape[3]))
+    return t.to(DEV).to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case):
+    from oracle import ops as O
+    hb = _hb()
+    B, H, W, Cin, Cout, k, s, p, d, bias, out_f32 = case
+    x, w, b = _conv_inputs(case)
+    cin_pad = (Cin + 7) // 8 * 8 if Cin >= 8 else 16
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if b is not None else None
+    yr = O.conv2d(xr, wr, br, s, p, d)
+    gy = _rand(*yr.shape, seed=7)
+    yr.backward(gy)
+
+    xd = _to_dev_nhwc(x, cin_pad).requires_grad_(cin_pad == Cin)
+    wd = w.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).requires_grad_(True) if b is not None else None
+    hb.clear_pack_cache()
+    yd = hb.Conv2dFn.apply(xd, wd, bd, s, p, d, out_f32)
+    torch.cuda.synchronize()
+    tol = (2e-3, 5e-4) if out_f32 else (1e-2, 4e-3)
+    check_close("conv_fwd %s" % (case,), nchw(yd.float()), yr, *tol)
+    gyd = nhwc(gy).to(DEV)
+    if not out_f32:
+        gyd = gyd.to(torch.bfloat16)
+    yd.backward(gyd)
+    torch.cuda.synchronize()
+    if cin_pad == Cin:
+        check_close("conv_dgrad %s" % (case,), nchw(xd.grad.float()), xr.grad)
+    # weight grads: fp32 out, but dy is rounded to bf16 for the fp32 heads
+    check_close("conv_wgrad %s" % (case,), wd.grad, wr.grad, 1e-2, 4e-3)
+    if b is not None:
+        check_close("conv_bgrad %s" % (case,), bd.grad, br.grad, 1e-2, 4e-3)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+def test_conv_all_tile_configs(cfg):
+    """Every tile configuration on a shape with ragged M and N tails."""
+    import ctypes
+    from oracle import ops as O
+    hb = _hb()
+    B, H, W, Cin, Cout = 1, 37, 45, 72, 88
+    x = _rand(B, Cin, H, W, seed=3)
+    w = _rand(Cout, Cin, 3, 3, seed=4, scale=0.04)
+    yr = O.conv2d(x, w, None, 1, 1, 1)
+    xd = _to_dev_nhwc(x)
+    wd = w.to(DEV)
+    hb.clear_pack_cache()
+    wp, Kpad = hb._packed_filter(wd, 0, Cin, 0)
+    y = hb._igemm(xd, Cin, (B, H, W, Cin), wp, Kpad, None, (H, W), Cout, (3, 3), 1, 1, 1, False, False, cfg=cfg)
+    torch.cuda.synchronize()
+    check_close("conv cfg%d" % cfg, nchw(y.float()), yr)
+
+
+def test_conv_channel_slice_input():
+    """Input given as a channel slice of a wider NHWC buffer (ld > C)."""
+    from oracle import ops as O
+    hb = _hb()
+    B, H, W = 1, 20, 24
+    full = _rand(B, 96, H, W, seed=5)
+    w = _rand(64, 48, 3, 3, seed=6, scale=0.05)
+    yr = O.conv2d(full[:, 48:96], w, None, 1, 1, 1)
+    fd = _to_dev_nhwc(full)
+    hb.clear_pack_cache()
+    y = hb.Conv2dFn.apply(fd[..., 48:96], w.to(DEV), None, 1, 1, 1, False)
+    torch.cuda.synchronize()
+    check_close("conv slice", nchw(y.float()), yr)
+
+
+# --------------------------------------------------------------------- BN
+@pytest.mark.parametrize("C,relu,res,post", [(48, True, True, False), (96, True, False, False),
+                                             (720, True, False, False), (256, False, False, False),
+                                             (512, True, False, True)])
+def test_bn_train(C, relu, res, post):
+    from oracle import ops as O
+    hb = _hb()
+    B, H, W = 2, 17, 23
+    x = _rand(B, C, H, W, seed=1) * 1.7 + 0.3
+    x = bf16_round(x)
+    gamma = torch.rand(C) + 0.5
+    beta = torch.randn(C) * 0.1
+    r = _rand(B, C, H, W, seed=2) if res else None
+    pm = None
+    if post:
+        pm = (torch.rand(B, C) > 0.3).float() / 0.7
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    y = O.batch_norm(xr, gr, br, rm, rv, True, 0.1, 1e-5)
+    if res:
+        y = y + rr
+    if relu:
+        y = torch.relu(y)
+    if post:
+        y = y * pm[:, :, None, None]
+    gy = _rand(B, C, H, W, seed=3)
+    y.backward(gy)
+
+    xd = _to_dev_nhwc(x).requires_grad_(True)
+    gd = gamma.to(DEV).requires_grad_(True)
+    bd = beta.to(DEV).requires_grad_(True)
+    rd = _to_dev_nhwc(r).requires_grad_(True) if res else None
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    pmd = pm.to(DEV) if post else None
+    z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, 0.1, 1e-5, True, relu, False)
+    z.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    check_close("bn_fwd", nchw(z.float()), y)
+    check_close("bn_running_mean", rmd, rm, 1e-4, 1e-4)
+    check_close("bn_running_var", rvd, rv, 1e-4, 1e-4)
+    check_close("bn_dx", nchw(xd.grad.float()), xr.grad, 2e-2, 6e-3)
+    check_close("bn_dgamma", gd.grad, gr.grad, 1e-2, 4e-3)
+    check_close("bn_dbeta", bd.grad, br.grad, 1e-2, 4e-3)
+    if res:
+        check_close("bn_dres", nchw(rd.grad.float()), rr.grad)
+
+
+def test_bn_eval():
+    from oracle import ops as O
+    hb = _hb()
+    B, C, H, W = 1, 64, 9, 11
+    x = _rand(B, C, H, W, seed=1)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    rm, rv = torch.randn(C) * 0.2, torch.rand(C) + 0.5
+    y = torch.relu(O.batch_norm(x, gamma, beta, rm.clone(), rv.clone(), False))
+    z = hb.BatchNormActFn.apply(_to_dev_nhwc(x), gamma.to(DEV), beta.to(DEV), None, None, rm.to(DEV),
+                                rv.to(DEV), 0.1, 1e-5, False, True, False)
+    torch.cuda.synchronize()
+    check_close("bn_eval", nchw(z.float()), y)
+
+
+# --------------------------------------------------------------- bilinear
+@pytest.mark.parametrize("C,hi,wi,ho,wo,f32", [(48, 16, 20, 64, 80, False), (96, 15, 9, 30, 18, False),
+                                               (19, 32, 32, 128, 128, True), (1, 24, 40, 96, 160, True),
+                                               (19, 64, 64, 32, 32, True), (192, 8, 8, 64, 64, False),
+                                               (19, 33, 45, 67, 91, True)])
+def test_bilinear(C, hi, wi, ho, wo, f32):
+    from oracle import ops as O
+    hb = _hb()
+    B = 2
+    x = _rand(B, C, hi, wi, seed=1)
+    xr = x.clone().requires_grad_(True)
+    y = O.bilinear(xr, (ho, wo))
+    gy = _rand(B, C, ho, wo, seed=2)
+    y.backward(gy)
+    xd = nhwc(x).to(DEV)
+    gyd = nhwc(gy).to(DEV)
+    if not f32:
+        xd, gyd = xd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+    xd.requires_grad_(True)
+    yd = hb.BilinearFn.apply(xd, ho, wo, f32)
+    yd.backward(gyd)
+    torch.cuda.synchronize()
+    tol = (1e-5, 1e-5) if f32 else (1e-2, 4e-3)
+    check_close("bilinear_fwd", nchw(yd.float()), y, *tol)
+    check_close("bilinear_bwd", nchw(xd.grad.float()), xr.grad, *tol)
+
+
+def test_image_resize():
+    from oracle import ops as O
+    hb = _hb()
+    x = torch.randn(2, 3, 64, 96)
+    y = hb.image_to_nhwc(x.to(DEV), None)
+    torch.cuda.synchronize()
+    check_close("image copy", nchw(y.float())[:, :3], bf16_round(x), 1e-6, 1e-6)
+    assert float(y[..., 3:].abs().max()) == 0.0
+    y2 = hb.image_to_nhwc(x.to(DEV), (32, 48))
+    torch.cuda.synchronize()
+    check_close("image resize", nchw(y2.float())[:, :3], O.resize_x(x, 0.5), 1e-2, 4e-3)
+
+
+def test_sum_act():
+    hb = _hb()
+    ts = [_rand(2, 12, 10, 48, seed=i) for i in range(3)]
+    tr = [t.clone().requires_grad_(True) for t in ts]
+    y = torch.relu(tr[0] + tr[1] + tr[2])
+    gy = _rand(2, 12, 10, 48, seed=9)
+    y.backward(gy)
+    td = [t.to(DEV).to(torch.bfloat16).requires_grad_(True) for t in ts]
+    z = hb.SumActFn.apply(True, *td)
+    z.backward(gy.to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    check_close("sum_act", z.float(), y)
+    for i in range(3):
+        check_close("sum_act_grad%d" % i, td[i].grad.float(), tr[i].grad)
+
+
+# -------------------------------------------------------------------- OCR
+def test_ocr_gather():
+    from oracle import ops as O
+    hb = _hb()
+    B, C, K, H, W = 2, 512, 19, 24, 28
+    feats = _rand(B, C, H, W, seed=1)
+    logits = torch.randn(B, K, H, W) * 2.0
+    fr = feats.clone().requires_grad_(True)
+    lr = logits.clone().requires_grad_(True)
+    ctx = O.spatial_gather(fr, lr)            # [B,C,K,1]
+    g = torch.randn(B, C, K, 1)
+    ctx.backward(g)
+    fd = _to_dev_nhwc(feats).requires_grad_(True)
+    ld = nhwc(logits).to(DEV).requires_grad_(True)
+    out = hb.OcrGatherFn.apply(fd, ld)        # [B,K,C]
+    out.backward(g[..., 0].permute(0, 2, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    check_close("gather_fwd", out.permute(0, 2, 1), ctx[..., 0], 1e-2, 4e-3)
+    check_close("gather_dfeats", nchw(fd.grad.float()), fr.grad, 2e-2, 6e-3)
+    check_close("gather_dlogits", nchw(ld.grad), lr.grad, 2e-2, 8e-3)
+
+
+def test_ocr_attention():
+    from oracle import ops as O
+    hb = _hb()
+    B, D, K, H, W = 2, 256, 19, 20, 24
+    q = _rand(B, H * W, D, seed=1)
+    k = _rand(B, K, D, seed=2)
+    v = _rand(B, K, D, seed=3)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    out = O.object_attention(qr, kr.permute(0, 2, 1), vr, D)
+    g = _rand(B, H * W, D, seed=4)
+    out.backward(g)
+    qd = q.view(B, H, W, D).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    kd = k.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    vd = v.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    od = hb.OcrAttnFn.apply(qd, kd, vd, D ** -0.5)
+    od.backward(g.view(B, H, W, D).to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    check_close("attn_fwd", od.float().view(B, H * W, D), out, 2e-2, 8e-3)
+    check_close("attn_dq", qd.grad.float().view(B, H * W, D), qr.grad, 3e-2, 1.5e-2)
+    check_close("attn_dk", kd.grad.float(), kr.grad, 3e-2, 1.5e-2)
+    check_close("attn_dv", vd.grad.float(), vr.grad, 2e-2, 8e-3)
+
+
+# ----------------------------------------------------------------- fusion
+def test_scale_fusion_ops():
+    hb = _hb()
+    B, H, W, C = 2, 16, 20, 19
+    a = torch.rand(B, H, W, 1)
+    lo = torch.randn(B, H, W, C)
+    hi = torch.randn(B, H, W, C)
+    x = torch.randn(B, H, W, 1)
+    ar, lor, hir, xr = (t.clone().requires_grad_(True) for t in (a, lo, hi, x))
+    s = torch.sigmoid(xr)
+    m = ar * lor
+    j = m + (1 - s) * hir
+    gj = torch.randn(B, H, W, C)
+    j.backward(gj)
+    ad, lod, hid, xd = (t.to(DEV).requires_grad_(True) for t in (a, lo, hi, x))
+    sd = hb.SigmoidFn.apply(xd)
+    md = hb.BcastMulFn.apply(ad, lod)
+    jd = hb.AttnBlendFn.apply(md, sd, hid)
+    jd.backward(gj.to(DEV))
+    torch.cuda.synchronize()
+    check_close("fusion_fwd", jd, j, 1e-5, 1e-5)
+    for n, d, r in (("a", ad, ar), ("lo", lod, lor), ("hi", hid, hir), ("x", xd, xr)):
+        check_close("fusion_d" + n, d.grad, r.grad, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------ losses
+def _labels(B, H, W, C, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    blocks = torch.randint(0, C, (B, (H + 7) // 8, (W + 7) // 8), generator=g)
+    lab = blocks.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :H, :W].clone()
+    ign = torch.rand(B, H, W, generator=g) < 0.1
+    lab[ign] = 255
+    return lab.long()
+
+
+def test_cross_entropy():
+    from oracle import ops as O
+    hb = _hb()
+    B, C, H, W = 2, 19, 40, 56
+    logits = torch.randn(B, C, H, W) * 3
+    lab = _labels(B, H, W, C)
+    lr = logits.clone().requires_grad_(True)
+    loss = O.cross_entropy(lr, lab, 255)
+    (loss * 1.7).backward()
+    ld = nhwc(logits).to(DEV).requires_grad_(True)
+    out = hb.CrossEntropyFn.apply(ld, lab.to(DEV), 255)
+    (out * 1.7).backward()
+    torch.cuda.synchronize()
+    check_close("ce", out.view(1), loss.view(1), 1e-5, 1e-5)
+    check_close("ce_grad", nchw(ld.grad), lr.grad, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("do_rmi", [False, True])
+def test_bce_rmi(do_rmi):
+    from oracle import ops as O
+    hb = _hb()
+    B, C, H, W = 2, 19, 64, 96
+    logits = torch.randn(B, C, H, W) * 2
+    lab = _labels(B, H, W, C, seed=3)
+    lr = logits.clone().requires_grad_(True)
+    loss = O.rmi_loss(lr, lab, C, do_rmi=do_rmi)
+    (loss * 0.4).backward()
+    ld = nhwc(logits).to(DEV).requires_grad_(True)
+    out = hb.BceRmiFn.apply(ld, lab.to(DEV), do_rmi, 0.5)
+    (out * 0.4).backward()
+    torch.cuda.synchronize()
+    check_close("bce_rmi(%s)" % do_rmi, out.view(1), loss.view(1), 1e-4, 1e-4)
+    check_close("bce_rmi_grad(%s)" % do_rmi, nchw(ld.grad), lr.grad, 2e-3, 1e-3)

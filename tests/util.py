@@ -1,0 +1,40 @@
+"""Shared helpers for the parity tests."""
+import torch
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def report(name, got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    mx = err.max().item()
+    scale = ref.abs().max().item()
+    mean_err = err.mean().item()
+    mean_ref = ref.abs().mean().item()
+    idx = err.flatten().argmax().item()
+    print("[%s] max_err=%.4g (ref_max=%.4g) mean_err=%.4g (ref_mean=%.4g) worst@%d got=%.6g ref=%.6g" % (
+        name, mx, scale, mean_err, mean_ref, idx, got.flatten()[idx].item(), ref.flatten()[idx].item()))
+    return mx, scale, mean_err, mean_ref
+
+
+def check_close(name, got, ref, rel_max=1e-2, rel_mean=4e-3):
+    """max error <= rel_max * max|ref| and mean error <= rel_mean * mean|ref|.
+    Defaults are the bf16 tolerance: one bf16 rounding of the output is 2^-9
+    relative (0.2%), plus fp32 accumulation-order noise."""
+    assert torch.isfinite(got.detach().float()).all(), name + ": non-finite output"
+    mx, scale, mean_err, mean_ref = report(name, got, ref)
+    assert mx <= rel_max * scale + 1e-30, "%s: max err %.4g > %.4g" % (name, mx, rel_max * scale)
+    assert mean_err <= rel_mean * mean_ref + 1e-30, "%s: mean err %.4g > %.4g" % (name, mean_err, rel_mean * mean_ref)
+
+
+def nhwc(t):
+    """NCHW -> NHWC contiguous"""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
