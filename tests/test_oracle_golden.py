@@ -1,0 +1,98 @@
+"""Pin the oracle (oracle/ops.py, oracle/model.py) against golden vectors that
+tests/golden/make_golden.py produced by running the REAL reference
+(/root/reference: loss/rmi.py, loss/utils.py, network/ocrnet.py) on CPU.
+CPU-only; runs everywhere."""
+import os
+
+import pytest
+import torch
+
+from util import check_close
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(G, name), map_location="cpu", weights_only=False)
+
+
+def _shapes():
+    out = []
+    with open(os.path.join(G, "keys.txt")) as f:
+        for line in f:
+            k, _, s = line.strip().partition(" ")
+            out.append((k, tuple(int(v) for v in s.split(",")) if s else ()))
+    return out
+
+
+def test_keys_inventory():
+    shapes = _shapes()
+    assert len(shapes) == 1903
+    assert shapes[0][0] == "backbone.conv1.weight"
+    assert shapes[-1][0] == "scale_attn.conv2.weight"
+
+
+@pytest.mark.parametrize("do_rmi", [False, True])
+def test_rmi_loss_matches_reference(do_rmi):
+    from oracle import ops as O
+    g = _load("rmi_golden.pt")
+    lg = g["logits"].clone().requires_grad_(True)
+    loss = O.rmi_loss(lg, g["gts"], 19, do_rmi=do_rmi)
+    loss.backward()
+    check_close("rmi loss", loss.view(1), g["loss_rmi%d" % do_rmi].view(1), 1e-6, 1e-6)
+    check_close("rmi grad", lg.grad, g["grad_rmi%d" % do_rmi], 1e-5, 1e-5)
+
+
+def test_cross_entropy_matches_reference():
+    from oracle import ops as O
+    g = _load("ce_golden.pt")
+    lg = g["logits"].clone().requires_grad_(True)
+    loss = O.cross_entropy(lg, g["gts"], 255)
+    loss.backward()
+    check_close("ce loss", loss.view(1), g["loss"].view(1), 1e-6, 1e-6)
+    check_close("ce grad", lg.grad, g["grad"], 1e-6, 1e-6)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return _load("mscale_golden.pt")
+
+
+def _oracle_net(training, **kw):
+    from oracle.model import Net, seeded_state_dict
+    sd = seeded_state_dict(_shapes(), seed=0)
+    for k, v in sd.items():
+        if v.is_floating_point() and not ("running_" in k):
+            v.requires_grad_(training)
+    used = set()
+    return Net(sd, 19, training=training, used=used, **kw), sd, used
+
+
+def test_mscale_train_step_matches_reference(gold):
+    net, sd, used = _oracle_net(True, mscale_wt=0.05)
+    loss = net.two_scale_forward(gold["images"], gold["gts"])
+    loss.backward()
+    assert used == set(sd.keys()), sorted(set(sd.keys()) ^ used)[:10]
+    check_close("train loss", loss.detach().view(1), gold["train_loss"].view(1), 1e-5, 1e-5)
+    worst = 0.0
+    for name, (idx, vals, norm) in gold["grads"].items():
+        gflat = sd[name].grad.flatten()
+        rel = float((gflat.norm() - norm).abs() / (norm + 1e-12))
+        worst = max(worst, rel)
+        assert rel < 2e-3, (name, rel)
+        assert torch.allclose(gflat[idx], vals, rtol=5e-3, atol=1e-6 + 2e-3 * float(vals.abs().max())), name
+    print("worst grad-norm rel err", worst)
+    for k, v in gold["running_sample"].items():
+        assert torch.allclose(sd[k].flatten()[:4], v, rtol=1e-4, atol=1e-5), k
+
+
+def test_mscale_eval_matches_reference(gold):
+    net, sd, _ = _oracle_net(False)
+    with torch.no_grad():
+        o = net.two_scale_forward(gold["images"])
+    for k, v in gold["eval"].items():
+        check_close("eval " + k, o[k][:, :, ::8, ::8], v, 1e-4, 1e-4)
+    with torch.no_grad():
+        o = net.nscale_forward(gold["images"], [0.5, 1.0, 2.0])
+    for k, v in gold["eval_nscale"].items():
+        check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 1e-4, 1e-4)
