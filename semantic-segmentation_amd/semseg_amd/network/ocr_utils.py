@@ -1,0 +1,87 @@
+"""OCR (object-contextual representations) head on the HIP operator surface.
+Module tree = network/ocr_utils.py of the reference (same state_dict keys)."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..nn import Conv2d, BNReLU, conv_bn
+
+
+class SpatialGather_Module(nn.Module):
+    """network/ocr_utils.py:17-46.  feats [B,H,W,C] bf16, probs (aux logits)
+    [B,H,W,K] fp32 -> object-region context [B,K,1,C] (the reference's
+    [B,C,K,1], channels-last)."""
+
+    def __init__(self, cls_num=0, scale=1):
+        super().__init__()
+        self.cls_num = cls_num
+        self.scale = scale
+        assert scale == 1
+
+    def forward(self, feats, probs):
+        B = ops.backend()
+        ctx = B.ocr_gather(feats, probs)            # [B,K,C] fp32
+        return B.to_act(ctx).unsqueeze(2)           # [B,K,1,C]
+
+
+def _conv_bnrelu_stack(cin, cout, n):
+    layers = []
+    for i in range(n):
+        layers += [Conv2d(cin if i == 0 else cout, cout, kernel_size=1, stride=1, padding=0, bias=False),
+                   BNReLU(cout)]
+    return nn.Sequential(*layers)
+
+
+def _run_stack(stack, x):
+    for i in range(0, len(stack), 2):
+        x = conv_bn(stack[i], stack[i + 1][0], x, relu=True)
+    return x
+
+
+class ObjectAttentionBlock(nn.Module):
+    """network/ocr_utils.py:49-119"""
+
+    def __init__(self, in_channels, key_channels, scale=1):
+        super().__init__()
+        assert scale == 1
+        self.scale = scale
+        self.in_channels = in_channels
+        self.key_channels = key_channels
+        self.pool = nn.MaxPool2d(kernel_size=(scale, scale))
+        self.f_pixel = _conv_bnrelu_stack(in_channels, key_channels, 2)
+        self.f_object = _conv_bnrelu_stack(in_channels, key_channels, 2)
+        self.f_down = _conv_bnrelu_stack(in_channels, key_channels, 1)
+        self.f_up = _conv_bnrelu_stack(key_channels, in_channels, 1)
+
+    def forward(self, x, proxy):
+        B = ops.backend()
+        q = _run_stack(self.f_pixel, x)                     # [B,H,W,D]
+        k = _run_stack(self.f_object, proxy)                # [B,K,1,D]
+        v = _run_stack(self.f_down, proxy)                  # [B,K,1,D]
+        ctx = B.ocr_attention(q, k.squeeze(2), v.squeeze(2), self.key_channels ** -0.5)
+        return _run_stack(self.f_up, ctx)
+
+
+class SpatialOCR_Module(nn.Module):
+    """network/ocr_utils.py:122-158.  Dropout2d(p) is applied as a per-(image,
+    channel) multiplier fused into the BN+ReLU pass."""
+
+    def __init__(self, in_channels, key_channels, out_channels, scale=1, dropout=0.1):
+        super().__init__()
+        self.object_context_block = ObjectAttentionBlock(in_channels, key_channels, scale)
+        self.conv_bn_dropout = nn.Sequential(
+            Conv2d(2 * in_channels, out_channels, kernel_size=1, padding=0, bias=False),
+            BNReLU(out_channels),
+            nn.Dropout2d(dropout))
+
+    def forward(self, feats, proxy_feats):
+        B = ops.backend()
+        context = self.object_context_block(feats, proxy_feats)
+        x = B.cat([context, feats])
+        drop = self.conv_bn_dropout[2]
+        post = None
+        if self.training and drop.p > 0:
+            n, c = x.shape[0], self.conv_bn_dropout[0].out_channels
+            keep = 1.0 - drop.p
+            post = (torch.rand(n, c, device=x.device) < keep).to(torch.float32) / keep
+        return conv_bn(self.conv_bn_dropout[0], self.conv_bn_dropout[1][0], x, relu=True, post=post)

@@ -99,7 +99,20 @@ def main():
         if k.endswith("running_mean") or k.endswith("running_var"):
             rs[k] = v.flatten()[:4].clone()
     gold["running_sample"] = rs
+    # eval: calibrate the BN running stats on this input first (momentum 1.0:
+    # running = batch statistics of the last (1.0x) pass), otherwise eval-mode
+    # activations of a random-weight residual net overflow (~1e10 logits).
     net.load_state_dict(sd)
+    net.train()
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        net({"images": images, "gts": gts})
+    for m in bns:
+        m.momentum = 0.1
+    gold["calib_buffers"] = {k: v.clone() for k, v in net.state_dict().items()
+                             if k.endswith("running_mean") or k.endswith("running_var")}
     net.eval()
     with torch.no_grad():
         o = net({"images": images, "gts": gts})

@@ -1,0 +1,105 @@
+"""Module wiring of semseg_amd.network (the product's nn.Modules) checked on
+CPU against golden vectors from the REAL reference, with the oracle's
+operators injected behind the ops interface (tests/oracle_backend.py).
+The HIP kernels themselves are checked by the -m gpu tests."""
+import os
+
+import pytest
+import torch
+
+from util import check_close
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def oracle_ops():
+    from semseg_amd import ops
+    from oracle_backend import OracleBackend
+    prev = ops._BACKEND
+    ops._set_backend_for_tests(OracleBackend())
+    yield
+    ops._set_backend_for_tests(prev)
+
+
+def _shapes():
+    out = []
+    with open(os.path.join(G, "keys.txt")) as f:
+        for line in f:
+            k, _, s = line.strip().partition(" ")
+            out.append((k, tuple(int(v) for v in s.split(",")) if s else ()))
+    return out
+
+
+def _net(train):
+    from semseg_amd.config import cfg
+    from semseg_amd.loss import RMILoss
+    from semseg_amd.network import ocrnet
+    from oracle.model import seeded_state_dict
+    cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
+    cfg.MODEL.N_SCALES = None
+    net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255))
+    net.load_state_dict(seeded_state_dict(_shapes(), seed=0))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    net.train(train)
+    return net, cfg
+
+
+def test_state_dict_is_the_references():
+    net, _ = _net(False)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == _shapes()
+
+
+def test_train_step_wiring(oracle_ops):
+    """fp32: loss equals the reference's golden value.  fp64: every parameter
+    gradient equals the oracle's (itself pinned to the reference in
+    test_oracle_golden.py).  The fp64 leg is needed because this small case
+    (B=1, 128x128: the stride-32 branch of the 0.5x pass is 2x2 pixels, BN over
+    4 samples) amplifies rounding noise ~3e5x -- measured: 1e-16 -> 3e-11."""
+    from oracle.model import Net, seeded_state_dict
+    gold = torch.load(os.path.join(G, "mscale_golden.pt"), map_location="cpu", weights_only=False)
+    net, _ = _net(True)
+    loss = net({"images": gold["images"], "gts": gold["gts"]})
+    check_close("train loss", loss.detach().view(1), gold["train_loss"].view(1), 1e-5, 1e-5)
+    sd = net.state_dict()
+    assert int(sd["backbone.bn1.num_batches_tracked"]) == 2   # two passes (0.5x, 1.0x)
+
+    net, _ = _net(True)
+    net.double()
+    img = gold["images"].double()
+    loss = net({"images": img, "gts": gold["gts"]})
+    loss.backward()
+    osd = {k: (v.double() if v.is_floating_point() else v) for k, v in seeded_state_dict(_shapes(), 0).items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    oloss = Net(osd, 19, training=True, mscale_wt=0.05).two_scale_forward(img, gold["gts"])
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-10
+    for name, p in net.named_parameters():
+        ref = osd[name].grad
+        if float(ref.norm()) < 1e-12:      # conv bias in front of BN: analytically zero
+            continue
+        rel = float((p.grad - ref).norm() / ref.norm())
+        assert rel < 1e-8, (name, rel)
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            assert torch.allclose(v, osd[k], rtol=1e-9, atol=1e-12), k
+
+
+def test_eval_wiring(oracle_ops):
+    gold = torch.load(os.path.join(G, "mscale_golden.pt"), map_location="cpu", weights_only=False)
+    net, cfg = _net(False)
+    net.load_state_dict(gold["calib_buffers"], strict=False)
+    with torch.no_grad():
+        o = net({"images": gold["images"], "gts": gold["gts"]})
+        assert tuple(o["pred"].shape) == (1, 19, 128, 128)
+        for k, v in gold["eval"].items():
+            check_close("eval " + k, o[k][:, :, ::8, ::8], v, 1e-3, 1e-3)
+        cfg.MODEL.N_SCALES = [0.5, 1.0, 2.0]
+        o = net({"images": gold["images"], "gts": gold["gts"]})
+        cfg.MODEL.N_SCALES = None
+        for k, v in gold["eval_nscale"].items():
+            check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 1e-3, 1e-3)
