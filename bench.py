@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/s of HRNet-OCR-MScale at 1024x1024 crop
+(BASELINE.json metric), synthetic Cityscapes-shaped data, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU,
+RCCL); RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.
+
+One "step" = zero_grad + forward (0.5x and 1.0x passes, attention fusion,
+RMI + BCE losses as in scripts/train_cityscapes_sota.yml) + backward (+ DDP
+gradient all-reduce and SyncBN when N > 1) + SGD step, on one 1x3x1024x1024
+batch per GPU that is already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# SURVEY.md section 8d / BASELINE.md section 2: conv FLOPs per training image at
+# 1024x1024 (two scales, 638 convs), measured from the reference on `meta`.
+FLOP_FWD_BWD_PER_IMAGE = 5.7274e12
+PEAK_BF16_MFMA = 2.5e15          # dense, MI355X_MICROARCH.md
+TILE_NAMES = {0: "conv_igemm_kernel<2,2,2,2> (128x128)", 1: "conv_igemm_kernel<4,1,2,2> (256x64)",
+              2: "conv_igemm_kernel<4,1,1,3> (128x96)", 3: "conv_igemm_kernel<4,1,2,1> (256x32)",
+              4: "conv_igemm_kernel<2,2,1,1> (64x64)", 5: "conv_igemm_kernel<2,2,2,1> (128x64)"}
+
+
+def synth_batch(B, H, W, rank, device):
+    """N(0,1) image, 64x64 blocks of uniform class ids,
+    ~10% ignore (255); seed 1234 + rank."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randn(B, 3, H, W, generator=g)
+    bs = 64
+    blocks = torch.randint(0, 19, (B, (H + bs - 1) // bs, (W + bs - 1) // bs), generator=g)
+    gts = blocks.repeat_interleave(bs, 1).repeat_interleave(bs, 2)[:, :H, :W].clone()
+    gts[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    return images.to(device), gts.long().to(device)
+
+
+def build_model(world):
+    from semseg_amd.config import cfg
+    from semseg_amd.loss import RMILoss
+    from semseg_amd.network import ocrnet
+    from semseg_amd import nn as snn
+    cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05        # scripts/train_cityscapes_sota.yml
+    cfg.LOSS.OCR_AUX_RMI = False
+    cfg.MODEL.N_SCALES = None
+    cfg.MODEL.BNFUNC = snn.SyncBatchNorm if world > 1 else None
+    torch.manual_seed(0)
+    net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255))
+    for m in net.modules():                     # random init at a realistic scale
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+    return net.cuda().train()
+
+
+def cpu_baseline(crop=512, timed=2):
+    """The oracle (CPU restatement of the reference's modules) timed on this
+    host's cores on a bounded sample of the same workload."""
+    from oracle.model import Net, seeded_state_dict
+    from semseg_amd.network import ocrnet
+    from semseg_amd.loss import RMILoss
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19))
+    shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    del net
+    sd = seeded_state_dict(shapes, seed=0)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    images, gts = synth_batch(1, crop, crop, 0, "cpu")
+    times = []
+    for i in range(1 + timed):
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss = Net(sd, 19, training=True, mscale_wt=0.05).two_scale_forward(images, gts)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    per_iter = sum(times[1:]) / timed
+    scale = (1024.0 / crop) ** 2
+    return {"value": 1.0 / (per_iter * scale), "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": "oracle (CPU port of the reference modules) fwd+bwd, fp32, %d timed iters after 1 warm-up at "
+                      "%dx%d crop (%.3f s/iter); value = that rate / %.0f (pixel-count ratio to 1024x1024)"
+                      % (timed, crop, crop, per_iter, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--crop", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")
+
+    net = build_model(world)
+    model = net
+    if world > 1:
+        from semseg_amd.parallel import DistributedDataParallel
+        model = DistributedDataParallel(net)
+    optim = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    images, gts = synth_batch(args.batch, args.crop, args.crop, rank, "cuda")
+    inputs = {"images": images, "gts": gts}
+    static_loss = torch.zeros((), device="cuda")
+
+    def step():
+        optim.zero_grad(set_to_none=True)
+        loss = model(inputs)
+        loss.backward()
+        optim.step()
+        static_loss.copy_(loss.detach())
+
+    graph = None
+    use_graph = (not args.no_graph) and world == 1
+    graph_error = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            optim.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:  # fall back to eager launches
+            graph_error = repr(e)[:200]
+            graph = None
+            torch.cuda.synchronize()
+
+    run = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(static_loss.item())
+    ms = dt / args.steps * 1e3
+    ips = args.batch * world * args.steps / dt
+    flop_scale = (args.crop / 1024.0) ** 2
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        from semseg_amd import hip_backend as hb
+        store = []
+        hb.set_profile(store)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        hb.set_profile(None)
+        agg = {}
+        for kind, tile, flops, e0, e1, shape in store:
+            key = (kind, tile)
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        tot_t = sum(a[1] for a in agg.values())
+        dom = max(agg.items(), key=lambda kv: kv[1][1])      # most time
+        (kind, tile), (fl, tt, n) = dom
+        name = TILE_NAMES.get(tile, "conv_wgrad_kernel") if kind == "igemm" else "conv_wgrad_kernel"
+        roof = {"bound": "mfma", "kernel": name, "achieved": fl / tt / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
+                "unit": "TFLOP/s", "frac": fl / tt / PEAK_BF16_MFMA, "traffic": None,
+                "launches_per_step": n // 2, "avg_launch_us": tt / n * 1e6,
+                "flop_per_launch": fl / n, "gemm_time_share_of_step": tot_t / 2 / (ms * 1e-3),
+                "all_gemm_kernels": {("%s/%s" % (k[0], TILE_NAMES.get(k[1], "-"))): {
+                    "tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
+                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "train images/sec HRNet-OCR-MScale 1024x1024 crop",
+            "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "train_cityscapes_sota: HRNet-OCR-MScale two-scale train step, RMI+BCE loss, "
+                                   "crop %dx%d, batch %d/GPU, SGD, synthetic Cityscapes-shaped batch, random init"
+                                   % (args.crop, args.crop, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "hipgraph": graph is not None, "loss": loss_val},
+            "model_flops_util": ips / world * FLOP_FWD_BWD_PER_IMAGE * flop_scale / PEAK_BF16_MFMA,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if graph_error:
+            out["config"]["hipgraph_error"] = graph_error
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

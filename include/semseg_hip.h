@@ -60,6 +60,10 @@ typedef struct ssa_conv_desc {
 int ssa_conv2d_igemm(const ssa_conv_desc* d, const void* x, const void* w_packed,
                      const float* bias, void* y, void* stream);
 
+/* Tile configuration ssa_conv2d_igemm would use for this problem
+ * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
+int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);
+
 /* Filter packing: OIHW fp32 parameter -> bf16 [rows][Kpad] GEMM operand.
  * mode 0 (forward): rows = Cout, k = (kh,kw,ci) with ci < cin_pad.
  * mode 1 (dgrad)  : rows = Cin,  k = (kh',kw',co) with co < cout_pad, taps

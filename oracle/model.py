@@ -25,7 +25,7 @@ class Net:
     """Holds the parameters and the mode; every method restates one reference block."""
 
     def __init__(self, sd, num_classes=19, training=True, dropout_mask=None, mscale_wt=0.0,
-                 aux_rmi=False, criterion="rmi", ignore_index=255, used=None):
+                 aux_rmi=False, criterion="rmi", ignore_index=255, used=None, bn_momentum=0.1):
         self.sd = sd
         self.nc = num_classes
         self.training = training
@@ -36,6 +36,7 @@ class Net:
         self.ignore_index = ignore_index
         self.used = used if used is not None else set()
         self._pass = 0
+        self.bn_momentum = bn_momentum
 
     # -- primitives
     def p(self, name):
@@ -50,7 +51,7 @@ class Net:
         self.used.add(name + ".num_batches_tracked")
         y = O.batch_norm(x, self.p(name + ".weight"), self.p(name + ".bias"),
                          self.p(name + ".running_mean"), self.p(name + ".running_var"),
-                         self.training, 0.1, 1e-5)
+                         self.training, self.bn_momentum, 1e-5)
         return torch.relu(y) if relu else y
 
     # -- network/hrnetv2.py:37-66

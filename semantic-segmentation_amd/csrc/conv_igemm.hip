@@ -505,6 +505,12 @@ int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packe
   }
 }
 
+int ssa_conv2d_igemm_tile(const ssa_conv_desc* dp) {
+  if (!dp) return SSA_EINVAL;
+  if (dp->cfg >= 0) return dp->cfg;
+  return choose_fwd_tile((long)dp->B * dp->Ho * dp->Wo, dp->Cout);
+}
+
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
                     int cin_pad, int cout_pad, int Kpad, int mode, void* stream) {
   if (!w_oihw || !w_packed || Kpad % BK) return SSA_EINVAL;

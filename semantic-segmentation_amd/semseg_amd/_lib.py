@@ -26,6 +26,7 @@ _P = c_void_p
 _SIGS = {
     "ssa_version": ([], c_int),
     "ssa_conv2d_igemm": ([POINTER(ConvDesc), _P, _P, _P, _P, _P], c_int),
+    "ssa_conv2d_igemm_tile": ([POINTER(ConvDesc)], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
     "ssa_conv2d_wgrad_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),

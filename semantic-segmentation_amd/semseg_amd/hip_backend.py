@@ -100,6 +100,16 @@ def _pack_matrix(src, R, C, ld, transpose, rows_out, Kpad):
     return out
 
 
+# Optional per-launch timing (bench.py's roofline leg): a list that receives
+# (kind, tile, flops, start_event, end_event) for every GEMM-class launch.
+_PROFILE = None
+
+
+def set_profile(store):
+    global _PROFILE
+    _PROFILE = store
+
+
 def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
            cfg=-1):
     """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
@@ -108,7 +118,16 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE, device=x.device)
     d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, int(transposed),
                  Kpad, int(out_f32), cfg)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tile = lib().ssa_conv2d_igemm_tile(ctypes.byref(d))
+        e0.record()
     check(lib().ssa_conv2d_igemm(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _s()), "ssa_conv2d_igemm")
+    if _PROFILE is not None:
+        e1.record()
+        # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
+        taps = k[0] * k[1] / (stride * stride if transposed else 1)
+        _PROFILE.append(("igemm", tile, 2.0 * B * Ho * Wo * Cout * Cin * taps, e0, e1, (k[0], stride, Cin, Cout, Ho, Wo)))
     return y
 
 
@@ -123,8 +142,15 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
     check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
           "ssa_conv2d_wgrad_plan")
     partial = torch.empty((ws.value // 4,), dtype=torch.float32, device=x.device)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.ssa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), lddy, cout_pad, nsplit.value, _p(partial), _s()),
           "ssa_conv2d_wgrad")
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("wgrad", -1, 2.0 * B * Ho * Wo * Cout * Cin_real * k[0] * k[1], e0, e1,
+                         (k[0], stride, Cin, Cout, Ho, Wo)))
     dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
     check(L.ssa_conv2d_wgrad_reduce(_p(partial), nsplit.value, cout_pad, Cout, Cin, Cin_real, k[0], k[1],
                                     _p(dw), _s()), "ssa_conv2d_wgrad_reduce")

@@ -1,0 +1,82 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU.
+
+`DistributedDataParallel` stands in for apex.parallel.DistributedDataParallel
+(network/__init__.py:37-39 of the reference): gradients are averaged over ranks
+with bucketed all-reduces that are launched from autograd hooks while backward
+is still running (reverse-registration order, >= `message_size` elements per
+bucket, as apex's default of 1e7).  `backend='nccl'` is RCCL on ROCm.
+SyncBN lives in semseg_amd.nn.SyncBatchNorm.
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class DistributedDataParallel(nn.Module):
+    def __init__(self, module, message_size=10_000_000, delay_allreduce=False, process_group=None, **_):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        self.delay_allreduce = delay_allreduce
+        params = [p for p in module.parameters() if p.requires_grad]
+        if self.world > 1:
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, 0, group=self.group)
+        # buckets in reverse parameter order: the order backward produces grads
+        self.buckets, cur, n = [], [], 0
+        for p in reversed(params):
+            cur.append(p)
+            n += p.numel()
+            if n >= message_size:
+                self.buckets.append(cur)
+                cur, n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[p] = bi
+        self._pending = [0] * len(self.buckets)
+        self._inflight = []
+        self._callback_queued = False
+        if self.world > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def forward(self, *args, **kwargs):
+        self._pending = [len(b) for b in self.buckets]
+        self._inflight = []
+        self._callback_queued = False
+        return self.module(*args, **kwargs)
+
+    # -- autograd-thread side
+    def _on_grad(self, p):
+        if not self._callback_queued:
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+            self._callback_queued = True
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self.delay_allreduce:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        ps = self.buckets[bi]
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        work = dist.all_reduce(flat, group=self.group, async_op=True)
+        self._inflight.append((bi, flat, work))
+
+    def _finalize(self):
+        launched = {bi for bi, _, _ in self._inflight}
+        for bi in range(len(self.buckets)):
+            if bi not in launched and all(p.grad is not None for p in self.buckets[bi]):
+                self._launch(bi)
+        for bi, flat, work in self._inflight:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in self.buckets[bi]:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._inflight = []

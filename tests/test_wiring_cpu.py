@@ -97,9 +97,9 @@ def test_eval_wiring(oracle_ops):
         o = net({"images": gold["images"], "gts": gold["gts"]})
         assert tuple(o["pred"].shape) == (1, 19, 128, 128)
         for k, v in gold["eval"].items():
-            check_close("eval " + k, o[k][:, :, ::8, ::8], v, 1e-3, 1e-3)
+            check_close("eval " + k, o[k][:, :, ::8, ::8], v, 2e-3, 5e-3)
         cfg.MODEL.N_SCALES = [0.5, 1.0, 2.0]
         o = net({"images": gold["images"], "gts": gold["gts"]})
         cfg.MODEL.N_SCALES = None
         for k, v in gold["eval_nscale"].items():
-            check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 1e-3, 1e-3)
+            check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 2e-3, 5e-3)
