@@ -230,10 +230,8 @@ class Conv2dFn(torch.autograd.Function):
 # batch norm (+ residual add + ReLU + per-(b,c) post scale = Dropout2d mask)
 # --------------------------------------------------------------------------
 def _sync_world(sync):
-    if sync and dist.is_available() and dist.is_initialized():
-        ws = dist.get_world_size()
-        return ws if ws > 1 else 0
-    return 0
+    from .parallel import sync_world
+    return sync_world(sync)
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -254,8 +252,8 @@ class BatchNormActFn(torch.autograd.Function):
             sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
             check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), _s()), "ssa_bn_stats")
             if world:
-                dist.all_reduce(sums)
-                count = float(P * world)
+                from .parallel import allreduce_bn_sums
+                count = allreduce_bn_sums(sums, P)
             check(L.ssa_bn_finalize(_p(sums), count, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
                                     float(momentum), float(eps), 0, _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                     _p(coef[3]), _s()), "ssa_bn_finalize")
@@ -295,7 +293,8 @@ class BatchNormActFn(torch.autograd.Function):
             dgamma, dbeta = pg[0], pg[1]
         if training:
             if world:
-                dist.all_reduce(sums)
+                from .parallel import allreduce_bn_sums
+                allreduce_bn_sums(sums, P)
         else:
             sums = torch.zeros_like(sums)  # eval-mode BN: statistics are constants
         dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)

@@ -12,6 +12,27 @@ import torch.distributed as dist
 from torch import nn
 
 
+def sync_world(enabled=True, group=None):
+    """World size to synchronise BN statistics over (0 = no synchronisation)."""
+    if enabled and dist.is_available() and dist.is_initialized():
+        ws = dist.get_world_size(group)
+        return ws if ws > 1 else 0
+    return 0
+
+
+def allreduce_bn_sums(sums, local_count, group=None):
+    """SyncBN exchange (apex.parallel.SyncBatchNorm, config.py:216-222): SUM the
+    per-channel fp64 partial sums over ranks in place and return the global
+    sample count.  Every rank runs the same crop size, so count = local * world.
+    With (sum x, sum x^2) this makes the statistics those of the concatenated
+    global batch; with (sum dy, sum dy*xhat) likewise for the backward."""
+    world = sync_world(True, group)
+    if not world:
+        return float(local_count)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return float(local_count) * world
+
+
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, message_size=10_000_000, delay_allreduce=False, process_group=None, **_):
         super().__init__()
