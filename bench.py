@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("SSA_DEBUG_HANG"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SSA_DEBUG_HANG"]), repeat=True, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -343,6 +343,174 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(
     }
 }
 
+// ----------------------------------------------------------------------------
+// weight-gradient kernel v1: [pixel][channel] LDS images (16-byte stores, exactly
+// as loaded) + ds_read_b64_tr_b16 transposing fragment reads.
+//
+// ds_read_b64_tr_b16 lane map (probed on gfx950, tests/test_kernels_gpu.py::
+// test_probe_tr16): inside a 16-lane group, lane i supplies the address of an
+// 8-byte piece (4 bf16); result lane c, element j = element (c&3) of the piece
+// supplied by lane 4j + (c>>2).  With lane i = 4j+q pointing at
+// (pixel p0+j, channels n0+4q..+3), lane c receives channel n0+c at pixels
+// p0..p0+3 -- the MFMA operand layout (8 consecutive k per lane = two reads).
+// Row stride S of the LDS image satisfies S % 256 == 64 bytes, which spreads
+// the 32 lanes the LDS services together over 32 distinct 8-byte slots.
+// ----------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int tr_row_stride(int cols) {  // in elements
+  int bytes = cols * 2;
+  int s = (bytes + 255) / 256 * 256 + 64;
+  if (s - 256 >= bytes) s -= 256;
+  return s / 2;
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int stride, int row0, int kbase,
+                                            int lane) {
+  const int i = lane & 15, j = i >> 2, q = i & 3;
+  const int col = row0 + 16 * ((lane >> 4) & 1) + 4 * q;
+  const int pix = kbase + 8 * (lane >> 5) + j;
+  const bf16_t* p0 = tile + pix * stride + col;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(p0));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * stride));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int WGM, int WGN, int MI, int NI>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
+    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
+    int cout_pad, float* __restrict__ partial, int tiles_n, int chunk) {
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
+  constexpr int SA = tr_row_stride(BM), SB = tr_row_stride(BN);
+  constexpr int PA = BM / 8, PB = BN / 8;          // 16-byte pieces per pixel row
+  constexpr int A_PIECES = 32 * PA, B_PIECES = 32 * PB;
+  constexpr int A_IT = (A_PIECES + NT - 1) / NT, B_IT = (B_PIECES + NT - 1) / NT;
+  constexpr int STAGE = 32 * (SA + SB);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int P = d.B * d.Ho * d.Wo, HoWo = d.Ho * d.Wo;
+  const int Kflat = d.KH * d.KW * d.Cin;
+  const int p_begin = blockIdx.y * chunk;
+  const int p_end = min(P, p_begin + chunk);
+
+  // piece -> (pixel row, channel piece): channel piece fastest => coalesced global loads
+  int a_pix[A_IT], a_co[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int idx = tid + i * NT;
+    a_pix[i] = idx / PA;
+    a_co[i] = (idx - a_pix[i] * PA) * 8;
+    a_ok[i] = (idx < A_PIECES) && (m0 + a_co[i] < cout_pad);
+  }
+  int b_pix[B_IT], b_col[B_IT], b_ci[B_IT], b_dy[B_IT], b_dx[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int idx = tid + j * NT;
+    b_pix[j] = idx / PB;
+    b_col[j] = (idx - b_pix[j] * PB) * 8;
+    const int kcol = n0 + b_col[j];
+    b_ok[j] = (idx < B_PIECES) && (kcol < Kflat);
+    const int tap = kcol / d.Cin;
+    b_ci[j] = kcol - tap * d.Cin;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    b_dy[j] = kh * d.dil - d.pad;
+    b_dx[j] = kw * d.dil - d.pad;
+  }
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  uint4 ra[A_IT], rb[B_IT];
+  auto gload = [&](int kt) {
+    const int pbase = p_begin + kt * 32;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int p = pbase + a_pix[i];
+      const bool ok = a_ok[i] && p < p_end;
+      const bf16_t* ptr = dy + (long)(ok ? p : 0) * lddy + m0 + a_co[i];
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(ptr) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      const int p = pbase + b_pix[j];
+      bool ok = b_ok[j] && p < p_end;
+      const int pp = ok ? p : 0;
+      const int b = pp / HoWo, rem = pp - b * HoWo;
+      const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+      const int iy = oy * d.stride + b_dy[j], ix = ox * d.stride + b_dx[j];
+      ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+      const long pix = ok ? (long)((b * d.H + iy) * d.W + ix) : 0;
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(x + pix * d.ldx + b_ci[j]) : zero4;
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* As = lds + buf * STAGE;
+    bf16_t* Bs = As + 32 * SA;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      if (tid + i * NT < A_PIECES) *reinterpret_cast<uint4*>(As + a_pix[i] * SA + a_co[i]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      if (tid + j * NT < B_PIECES) *reinterpret_cast<uint4*>(Bs + b_pix[j] * SB + b_col[j]) = rb[j];
+  };
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nk = (p_end - p_begin + 31) / 32;
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      const bf16_t* As = lds + buf * STAGE;
+      const bf16_t* Bs = As + 32 * SA;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = tr_frag(As, SA, wm * MI * 32 + mi * 32, ks * 16, lane);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bfr[ni] = tr_frag(Bs, SB, wn * NI * 32 + ni * 32, ks * 16, lane);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+      }
+      if (kt + 1 < nk) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  float* out = partial + (long)blockIdx.y * cout_pad * Kflat;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int kcol = n0 + wn * NI * 32 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad && kcol < Kflat) out[(long)co * Kflat + kcol] = acc[mi][ni][r];
+      }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int cout_pad,
                                     int Cout, int Cin_pad, int Cin, int KH, int KW,
                                     float* __restrict__ dw) {
@@ -440,6 +608,19 @@ template <int WGM, int WGN, int MI, int NI>
 int launch_wgrad(const ssa_conv_desc& d, const void* x, const void* dy, int lddy, int cout_pad,
                  int nsplit, float* partial, hipStream_t s) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
+  if (d.cfg != 100) {   // default: transposing-read kernel; cfg 100 selects the v0 kernel
+    const int Kflat = d.KH * d.KW * d.Cin;
+    const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
+    const long P = (long)d.B * d.Ho * d.Wo;
+    long chunk = (P + nsplit - 1) / nsplit;
+    chunk = (chunk + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * 32 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n, nsplit),
+                       dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
+                       cout_pad, partial, tiles_n, (int)chunk);
+    SSA_LAUNCH_CHECK();
+    return SSA_OK;
+  }
   const int Kflat = d.KH * d.KW * d.Cin;
   const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
   const long P = (long)d.B * d.Ho * d.Wo;

@@ -1,0 +1,66 @@
+"""Drop-in installation under the reference's own entry points.
+
+    import semseg_amd.dropin as dropin; dropin.install()      # before train.py imports network/loss
+
+registers this package's modules under the names the reference resolves at run
+time, so `train.py`, `config.py` and `scripts/*.yml` run unchanged:
+
+  network.ocrnet / network.hrnetv2 / network.ocr_utils / network.utils / network.mynn
+        -> semseg_amd.network.*      (importlib target of --arch, network/__init__.py:45-54)
+  loss.utils.get_loss, loss.rmi.RMILoss
+        -> semseg_amd.loss.*         (train.py:341)
+  apex.parallel.SyncBatchNorm / DistributedDataParallel, apex.amp
+        -> semseg_amd.nn.SyncBatchNorm / semseg_amd.parallel.DistributedDataParallel /
+           a bf16 no-op amp shim     (config.py:218-220, network/__init__.py:37-39, train.py:381,504)
+
+After the reference's `assert_and_infer_cfg(args)` has run, call
+`sync_config()` so our cfg mirrors the fields the hot path reads.
+"""
+import contextlib
+import sys
+import types
+
+
+def _amp_shim():
+    amp = types.ModuleType("apex.amp")
+    amp.float_function = lambda f: f
+    amp.half_function = lambda f: f
+    amp.disable_casts = contextlib.nullcontext
+    amp.initialize = lambda model, optimizers=None, opt_level="O1", **kw: (model, optimizers)
+
+    @contextlib.contextmanager
+    def scale_loss(loss, optimizers, **kw):   # bf16 needs no loss scaling
+        yield loss
+    amp.scale_loss = scale_loss
+    return amp
+
+
+def install(replace_apex=True):
+    from . import nn as snn, parallel, network, loss
+    from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn
+    if replace_apex:
+        apex = types.ModuleType("apex")
+        par = types.ModuleType("apex.parallel")
+        par.SyncBatchNorm = snn.SyncBatchNorm
+        par.DistributedDataParallel = parallel.DistributedDataParallel
+        apex.parallel = par
+        apex.amp = _amp_shim()
+        sys.modules["apex"] = apex
+        sys.modules["apex.parallel"] = par
+        sys.modules["apex.amp"] = apex.amp
+    for name, mod in (("network.ocrnet", ocrnet), ("network.hrnetv2", hrnetv2),
+                      ("network.ocr_utils", ocr_utils), ("network.utils", nutils),
+                      ("network.mynn", mynn)):
+        sys.modules[name] = mod
+    return network, loss
+
+
+def sync_config():
+    """Mirror the reference's frozen cfg (after assert_and_infer_cfg) and pick
+    the norm layer the way config.py:216-225 does."""
+    from config import cfg as ref_cfg          # the reference's config.py on sys.path
+    from .config import cfg, sync_from_reference
+    from . import nn as snn
+    sync_from_reference(ref_cfg)
+    cfg.MODEL.BNFUNC = snn.SyncBatchNorm if getattr(ref_cfg.MODEL, "BN", "") == "syncnorm" or \
+        "SyncBatchNorm" in getattr(ref_cfg.MODEL.BNFUNC, "__name__", "") else snn.BatchNorm2d
