@@ -63,13 +63,35 @@ def build_model(world):
     return net.cuda().train()
 
 
-def cpu_baseline(crop=512, timed=2):
+def cpu_baseline(timeout_s=150):
+    """Run the CPU baseline in a child process under a hard time limit so that a
+    misbehaving host (oversubscribed cores) can never stall the benchmark."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"],
+                             capture_output=True, text=True, timeout=timeout_s,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "error": (out.stderr or out.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "cpu baseline exceeded %d s" % timeout_s}
+
+
+def _cpu_baseline_impl(crop=256, timed=2):
     """The oracle (CPU restatement of the reference's modules) timed on this
-    host's cores on a bounded sample of the same workload."""
+    host's cores on a bounded sample of the same workload.  Thread count is
+    torch's default for this process (the CPUs the container may actually use:
+    forcing os.cpu_count() threads on a cgroup-limited box oversubscribes it)."""
     from oracle.model import Net, seeded_state_dict
     from semseg_amd.network import ocrnet
     from semseg_amd.loss import RMILoss
-    ncores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(torch.get_num_threads(), avail))
     torch.set_num_threads(ncores)
     net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19))
     shapes = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
@@ -105,7 +127,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(_cpu_baseline_impl()))
+        return
 
     if os.environ.get("SSA_DEBUG_HANG"):
         import faulthandler

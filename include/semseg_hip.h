@@ -84,6 +84,18 @@ int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad,
                             int Cout, int Cin_pad, int Cin, int KH, int KW,
                             float* dw_oihw, void* stream);
 
+/* All filters of a network repacked in ONE launch (the parameters change every
+ * optimizer step; 1,276 separate pack launches cost more than the packing).
+ * jobs_dev: device array of ssa_pack_job; same semantics as ssa_pack_filter.  */
+typedef struct ssa_pack_job {
+  const float* w_oihw;
+  void* w_packed;
+  long elem_begin;   /* unused by the kernel (reserved)                        */
+  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, pad_;
+} ssa_pack_job;
+int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job,
+                             void* stream);
+
 /* Column sum over pixels: out[c] = sum_p x[p, c]  (bias gradient). x bf16. */
 int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out,
                     double* scratch2c, void* stream);
@@ -95,8 +107,22 @@ int ssa_pad_cast_f32_bf16(const float* x, long P, int C, int ldx, void* y,
 /* --------------------------------------------------------------- batchnorm --
  * Replaces cfg.MODEL.BNFUNC (nn.BatchNorm2d / apex SyncBatchNorm) selected at
  * config.py:216-225 and instantiated by network/mynn.py:18-24 (K7, C3).      */
-/* sums[0:C] = sum_p x, sums[C:2C] = sum_p x^2 (fp64).  sums is zeroed inside. */
-int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, void* stream);
+/* sums[0:C] += sum_p x, sums[C:2C] += sum_p x^2 (fp64).  zero_sums=1 clears sums
+ * first (one memset per call); callers that carve sums out of an arena they
+ * clear once per step pass 0.                                                  */
+int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_sums,
+                 void* stream);
+/* Training-mode normalisation with the finalize step fused in (one launch):
+ * z = post*act(bn(x) + residual) with batch statistics from `sums`/`count`
+ * (possibly all-reduced: SyncBN); writes coef = [scale|shift|mean|invstd] (4*C
+ * fp32) for the backward pass, updates running_mean/var (momentum, unbiased
+ * variance) and increments *num_batches_tracked (int64) when given.           */
+int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z,
+                       int ldz, long P, int C, const double* sums, double count,
+                       const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, long* num_batches_tracked, float momentum,
+                       float eps, float* coef, int relu, const float* post,
+                       long pix_per_img, void* stream);
 /* From (possibly all-reduced) sums and total count: scale/shift for the apply
  * pass, mean/invstd for backward, running-stat update (momentum, unbiased var).
  * use_running=1 (eval): scale/shift from running stats, sums ignored.          */
@@ -112,15 +138,18 @@ int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz,
                       const void* z, int ldz, long P, int C, const float* mean,
                       const float* invstd, int relu, const float* post,
-                      long pix_per_img, double* sums, void* stream);
+                      long pix_per_img, double* sums, int zero_sums, void* stream);
 /* backward pass 2: dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N);
- * dres (optional) = g.  sums may have been all-reduced; count is global.     */
+ * dres (optional) = g.  sums may have been all-reduced; count is global.
+ * dgamma/dbeta (optional): = param_grad_scale * sums[C:2C] / sums[0:C]
+ * (1/world under SyncBN, so that DDP's mean over ranks is unchanged).         */
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      const void* z, int ldz, void* dx, int lddx, void* dres,
                      int lddres, long P, int C, const float* gamma,
                      const float* mean, const float* invstd, const double* sums,
                      double count, int relu, const float* post,
-                     long pix_per_img, void* stream);
+                     long pix_per_img, float* dgamma, float* dbeta,
+                     float param_grad_scale, void* stream);
 /* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);

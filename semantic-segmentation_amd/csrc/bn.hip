@@ -134,6 +134,82 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(
   }
 }
 
+// Training-mode apply with the finalize step fused in: every thread derives
+// scale/shift for its 8 channels from the fp64 sums (2 loads + a few fp64 ops per
+// channel), block 0 additionally publishes mean/invstd/scale/shift for the
+// backward pass, updates the running statistics and bumps num_batches_tracked.
+__global__ __launch_bounds__(NT) void bn_apply_train_kernel(
+    const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
+    bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ running_mean, float* __restrict__ running_var,
+    long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
+    int relu, const float* __restrict__ post, long pix_per_img, long pix_per_block) {
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0) {
+    for (int c = t; c < C; c += NT) {
+      const double mean = sums[c] / count;
+      double var = sums[C + c] / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)eps);
+      const double g = gamma ? (double)gamma[c] : 1.0;
+      const double b = beta ? (double)beta[c] : 0.0;
+      coef[c] = (float)(g * invstd);
+      coef[C + c] = (float)(b - mean * g * invstd);
+      coef[2 * C + c] = (float)mean;
+      coef[3 * C + c] = (float)invstd;
+      if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+    if (t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+  if (t >= NA) return;
+  const int cg = t % VC, pr = t / VC;
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cg * 8 + j;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    const double bb = beta ? (double)beta[c] : 0.0;
+    a[j] = (float)(g * invstd);
+    b[j] = (float)(bb - mean * g * invstd);
+  }
+  const long p0 = blockIdx.x * pix_per_block;
+  const long p1 = min(P, p0 + pix_per_block);
+  for (long p = p0 + pr; p < p1; p += RP) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
+    if (res) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(res + p * ldr + cg * 8);
+      float r[8];
+      unpack8(rv, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    if (post) {
+      const float* pp = post + (p / pix_per_img) * C + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= pp[j];
+    }
+    *reinterpret_cast<uint4*>(z + p * ldz + cg * 8) = pack8(f);
+  }
+}
+
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
@@ -183,9 +259,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ sums, double count, int relu, const float* __restrict__ post,
-    long pix_per_img, long pix_per_block) {
+    long pix_per_img, long pix_per_block, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float param_grad_scale) {
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
+  if (blockIdx.x == 0 && (dgamma || dbeta)) {
+    for (int c = t; c < C; c += NT) {
+      if (dbeta) dbeta[c] = (float)(sums[c] * param_grad_scale);
+      if (dgamma) dgamma[c] = (float)(sums[C + c] * param_grad_scale);
+    }
+  }
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
   float mu[8], is[8], a[8], c1[8], c2[8];
@@ -286,11 +369,13 @@ bool ok_c(int C) { return C > 0 && C % 8 == 0 && C <= 2048; }
 
 extern "C" {
 
-int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, void* stream) {
+int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_sums, void* stream) {
   if (!x || !sums || !ok_c(C) || ld % 8 || P <= 0) return SSA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
-  if (e != hipSuccess) return (int)e;
+  if (zero_sums) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+    if (e != hipSuccess) return (int)e;
+  }
   const Grid g = plan_grid(P, C);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, P, C, ld, sums, g.ppb);
@@ -324,14 +409,34 @@ int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
   return SSA_OK;
 }
 
+int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz,
+                       long P, int C, const double* sums, double count, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var,
+                       long* num_batches_tracked, float momentum, float eps, float* coef, int relu,
+                       const float* post, long pix_per_img, void* stream) {
+  if (!x || !z || !sums || !coef || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
+      count <= 0 || (running_mean && !running_var))
+    return SSA_EINVAL;
+  const Grid g = plan_grid(P, C);
+  hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
+                     sums, count, gamma, beta, running_mean, running_var, num_batches_tracked,
+                     momentum, eps, coef, relu, post, pix_per_img, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                       long P, int C, const float* mean, const float* invstd, int relu,
-                      const float* post, long pix_per_img, double* sums, void* stream) {
+                      const float* post, long pix_per_img, double* sums, int zero_sums,
+                      void* stream) {
   if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
-  if (e != hipSuccess) return (int)e;
+  if (zero_sums) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+    if (e != hipSuccess) return (int)e;
+  }
   const Grid g = plan_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
@@ -343,14 +448,15 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                      void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
                      const float* mean, const float* invstd, const double* sums, double count,
-                     int relu, const float* post, long pix_per_img, void* stream) {
+                     int relu, const float* post, long pix_per_img, float* dgamma, float* dbeta,
+                     float param_grad_scale, void* stream) {
   if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz,
                      (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums,
-                     count, relu, post, pix_per_img, g.ppb);
+                     count, relu, post, pix_per_img, g.ppb, dgamma, dbeta, param_grad_scale);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

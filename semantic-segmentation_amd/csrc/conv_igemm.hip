@@ -511,22 +511,71 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int cout_pad,
-                                    int Cout, int Cin_pad, int Cin, int KH, int KW,
-                                    float* __restrict__ dw) {
-  // one thread per OIHW element
-  const long n = (long)Cout * Cin * KH * KW;
-  const long Kflat = (long)KH * KW * Cin_pad;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    long t = i;
-    const int kw = t % KW; t /= KW;
-    const int kh = t % KH; t /= KH;
-    const int ci = t % Cin; t /= Cin;
-    const int co = (int)t;
-    const long src = (long)co * Kflat + (long)(kh * KW + kw) * Cin_pad + ci;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * cout_pad * Kflat + src];
-    dw[i] = s;
+// One workgroup per output channel: sum the nsplit partial rows (coalesced
+// reads, k = (kh,kw,ci) fastest), transpose (kh,kw,ci) -> (ci,kh,kw) through
+// LDS, write the OIHW row with coalesced stores.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
+    const float* __restrict__ partial, int nsplit, int cout_pad, int Cout, int Cin_pad, int Cin,
+    int KH, int KW, float* __restrict__ dw) {
+  extern __shared__ float row[];
+  const int co = blockIdx.x;
+  const int taps = KH * KW;
+  const int Kflat = taps * Cin_pad;
+  const long split_stride = (long)cout_pad * Kflat;
+  const float* src = partial + (long)co * Kflat;
+  for (int k = threadIdx.x; k < Kflat; k += 256) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {
+      s0 += src[(long)sp * split_stride + k];
+      s1 += src[(long)(sp + 1) * split_stride + k];
+      s2 += src[(long)(sp + 2) * split_stride + k];
+      s3 += src[(long)(sp + 3) * split_stride + k];
+    }
+    for (; sp < nsplit; ++sp) s0 += src[(long)sp * split_stride + k];
+    const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
+    if (ci < Cin) row[ci * taps + tap] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  const int n = Cin * taps;
+  float* dst = dw + (long)co * n;
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = row[i];
+}
+
+struct PackJob {           // mirror of ssa_pack_job (include/semseg_hip.h)
+  const float* w;
+  bf16_t* out;
+  long elem_begin;         // first flat output element of this job in the batch
+  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, pad_;
+};
+
+__device__ __forceinline__ bf16_t pack_one(const float* __restrict__ w, int Cout, int Cin, int KH,
+                                           int KW, int cin_pad, int cout_pad, int mode, int r, int k) {
+  float v = 0.f;
+  if (mode == 0) {
+    const int tap = k / cin_pad, ci = k - tap * cin_pad;
+    if (tap < KH * KW && ci < Cin && r < Cout) {
+      const int kh = tap / KW, kw = tap - kh * KW;
+      v = w[(((long)r * Cin + ci) * KH + kh) * KW + kw];
+    }
+  } else {
+    const int tap = k / cout_pad, co = k - tap * cout_pad;
+    if (tap < KH * KW && co < Cout && r < Cin) {
+      const int khp = tap / KW, kwp = tap - khp * KW;
+      const int kh = KH - 1 - khp, kw = KW - 1 - kwp;
+      v = w[(((long)co * Cin + r) * KH + kh) * KW + kw];
+    }
+  }
+  return f2bf(v);
+}
+
+// All filters of the network in one launch: blockIdx.y = job, grid-stride in x.
+__global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob* __restrict__ jobs) {
+  const PackJob j = jobs[blockIdx.y];
+  const long n = (long)j.rows * j.Kpad;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / j.Kpad), k = (int)(i - (long)r * j.Kpad);
+    j.out[i] = pack_one(j.w, j.Cout, j.Cin, j.KH, j.KW, j.cin_pad, j.cout_pad, j.mode, r, k);
   }
 }
 
@@ -536,22 +585,7 @@ __global__ void pack_filter_kernel(const float* __restrict__ w, bf16_t* __restri
   const long n = (long)rows * Kpad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / Kpad), k = (int)(i - (long)r * Kpad);
-    float v = 0.f;
-    if (mode == 0) {
-      const int tap = k / cin_pad, ci = k - tap * cin_pad;
-      if (tap < KH * KW && ci < Cin && r < Cout) {
-        const int kh = tap / KW, kw = tap - kh * KW;
-        v = w[(((long)r * Cin + ci) * KH + kh) * KW + kw];
-      }
-    } else {
-      const int tap = k / cout_pad, co = k - tap * cout_pad;
-      if (tap < KH * KW && co < Cout && r < Cin) {
-        const int khp = tap / KW, kwp = tap - khp * KW;
-        const int kh = KH - 1 - khp, kw = KW - 1 - kwp;
-        v = w[(((long)co * Cin + r) * KH + kh) * KW + kw];
-      }
-    }
-    out[i] = f2bf(v);
+    out[i] = pack_one(w, Cout, Cin, KH, KW, cin_pad, cout_pad, mode, r, k);
   }
 }
 
@@ -742,11 +776,20 @@ int ssa_conv2d_wgrad(const ssa_conv_desc* dp, const void* x, const void* dy, int
 
 int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int Cout, int Cin_pad,
                             int Cin, int KH, int KW, float* dw_oihw, void* stream) {
-  if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad) return SSA_EINVAL;
-  const long n = (long)Cout * Cin * KH * KW;
-  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial,
+  if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad || nsplit < 1) return SSA_EINVAL;
+  const size_t lds = (size_t)Cin * KH * KW * sizeof(float);
+  if (lds > 64 * 1024) return SSA_EUNSUPPORTED;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds, (hipStream_t)stream, partial,
                      nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, dw_oihw);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job, void* stream) {
+  if (!jobs_dev || njobs < 1 || blocks_per_job < 1) return SSA_EINVAL;
+  static_assert(sizeof(PackJob) == 64, "ssa_pack_job layout");
+  hipLaunchKernelGGL(pack_filters_batched_kernel, dim3(blocks_per_job, njobs), dim3(256), 0,
+                     (hipStream_t)stream, (const PackJob*)jobs_dev);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

@@ -15,6 +15,12 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsemseg_hip.so")
 _LIB = None
 
 
+class PackJob(ctypes.Structure):
+    """Mirror of ssa_pack_job (64 bytes)."""
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("elem_begin", c_long)] + [(n, c_int) for n in (
+        "Cout", "Cin", "KH", "KW", "cin_pad", "cout_pad", "Kpad", "mode", "rows", "pad_")]
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of ssa_conv_desc."""
     _fields_ = [(n, c_int) for n in (
@@ -33,15 +39,18 @@ _SIGS = {
     "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, _P], c_int),
     "ssa_colsum_bf16": ([_P, c_long, c_int, c_int, _P, _P, _P], c_int),
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
-    "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, _P], c_int),
+    "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
+    "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_double, _P, _P, _P, _P,
+                            _P, c_float, c_float, _P, c_int, _P, c_long, _P], c_int),
+    "ssa_pack_filters_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,
                          _P, _P, _P, _P, _P], c_int),
     "ssa_bn_apply": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
                       c_long, _P], c_int),
     "ssa_bn_bwd_reduce": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
-                           c_long, _P, _P], c_int),
+                           c_long, _P, c_int, _P], c_int),
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
-                          _P, _P, _P, _P, c_double, c_int, _P, c_long, _P], c_int),
+                          _P, _P, _P, _P, c_double, c_int, _P, c_long, _P, _P, c_float, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
     "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
     "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),

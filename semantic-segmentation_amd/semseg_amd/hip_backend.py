@@ -61,35 +61,118 @@ def _pixels(t):
 
 
 # --------------------------------------------------------------------------
-# packed filter cache (cleared at the start of every top-level forward so the
-# packing kernels are re-issued -- and captured -- once per step)
+# packed filters: persistent bf16 GEMM operands, one per (parameter, form).
+# They are re-derived from the fp32 parameters whenever those changed (every
+# optimizer step) by ONE batched launch at the start of the step -- captured in
+# the step's hipGraph -- instead of 1,276 separate pack launches.
 # --------------------------------------------------------------------------
+import weakref
+
+from ._lib import PackJob
+
+
+class _Packed:
+    __slots__ = ("wref", "out", "Kpad", "version", "job")
+
+
 _PACKED = {}
+_JOB_TABLE = {"key": None, "dev": None, "n": 0}
 
 
 def clear_pack_cache():
     _PACKED.clear()
+    _JOB_TABLE.update(key=None, dev=None, n=0)
+
+
+def _make_job(w, out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows):
+    return PackJob(w.data_ptr(), out.data_ptr(), 0, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, 0)
+
+
+def refresh_packed_filters():
+    """Re-pack every registered filter whose parameter changed since it was
+    packed.  One launch for all of them."""
+    stale = []
+    for key, e in list(_PACKED.items()):
+        w = e.wref()
+        if w is None or w.data_ptr() != key[0]:
+            del _PACKED[key]
+            continue
+        if w._version != e.version:
+            stale.append((key, e, w))
+    if not stale:
+        return
+    tkey = tuple(k for k, _, _ in stale)
+    if _JOB_TABLE["key"] != tkey:
+        arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        _JOB_TABLE.update(key=tkey, dev=host.to(stale[0][2].device), n=len(stale))
+    check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 8, _s()),
+          "ssa_pack_filters_batched")
+    for _, e, w in stale:
+        e.version = w._version
 
 
 def _packed_filter(weight, mode, cin_pad, cout_pad):
-    key = (weight.data_ptr(), weight._version, mode, cin_pad, cout_pad)
-    hit = _PACKED.get(key)
-    if hit is not None:
-        return hit
+    key = (weight.data_ptr(), mode, cin_pad, cout_pad)
+    e = _PACKED.get(key)
+    if e is not None and e.wref() is weight and e.version == weight._version:
+        return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
     if mode == 0:
         rows, kdim = Cout, KH * KW * cin_pad
     else:
         rows, kdim = Cin, KH * KW * cout_pad
     Kpad = _roundup(kdim, 32)
-    out = torch.empty((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)
     w = weight.detach()
-    if w.dtype != torch.float32 or not w.is_contiguous():
+    direct = w.dtype == torch.float32 and w.is_contiguous()
+    if not direct:
         w = w.float().contiguous()
-    check(lib().ssa_pack_filter(_p(w), _p(out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, _s()),
+    if e is None or e.wref() is not weight:
+        e = _Packed()
+        e.out = torch.empty((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)
+        e.Kpad = Kpad
+        e.wref = weakref.ref(weight)
+        e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows)
+        if direct:              # only parameters packed straight from their own storage are batched
+            _PACKED[key] = e
+    check(lib().ssa_pack_filter(_p(w), _p(e.out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, _s()),
           "ssa_pack_filter")
-    _PACKED[key] = (out, Kpad)
-    return out, Kpad
+    e.version = weight._version
+    return e.out, e.Kpad
+
+
+# --------------------------------------------------------------------------
+# fp64 statistics arena: BN (and bias-gradient) partial sums are carved out of
+# one buffer that is cleared with a single memset per step instead of one
+# memset per BatchNorm call (1,262 per training step).
+# --------------------------------------------------------------------------
+class _Arena:
+    def __init__(self):
+        self.buf = None
+        self.cur = 0
+
+    def reset(self, device):
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.empty((1 << 20,), dtype=torch.float64, device=device)   # 8 MB
+        self.buf.zero_()
+        self.cur = 0
+
+    def take(self, n, device):
+        n = _roundup(n, 32)
+        if self.buf is None or self.buf.device != device or self.cur + n > self.buf.numel():
+            self.reset(device)
+        out = self.buf[self.cur:self.cur + n]
+        self.cur += n
+        return out
+
+
+_ARENA = _Arena()
+
+
+def begin_step(device=None):
+    refresh_packed_filters()
+    if device is not None:
+        _ARENA.reset(device)
 
 
 def _pack_matrix(src, R, C, ld, transpose, rows_out, Kpad):
@@ -236,7 +319,7 @@ def _sync_world(sync):
 
 class BatchNormActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, momentum, eps, training,
+    def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, nbt, momentum, eps, training,
                 relu, sync):
         L = lib()
         x, ldx = _pixels(x)
@@ -248,26 +331,27 @@ class BatchNormActFn(torch.autograd.Function):
         coef = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
         world = _sync_world(sync) if training else 0
         count = float(P)
-        if training:
-            sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-            check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), _s()), "ssa_bn_stats")
-            if world:
-                from .parallel import allreduce_bn_sums
-                count = allreduce_bn_sums(sums, P)
-            check(L.ssa_bn_finalize(_p(sums), count, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
-                                    float(momentum), float(eps), 0, _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                    _p(coef[3]), _s()), "ssa_bn_finalize")
-        else:
-            check(L.ssa_bn_finalize(None, 1.0, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
-                                    float(momentum), float(eps), 1, _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                    _p(coef[3]), _s()), "ssa_bn_finalize")
         res = ldr = None
         if residual is not None:
             res, ldr = _pixels(residual)
         z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
         pst = post.float().contiguous() if post is not None else None
-        check(L.ssa_bn_apply(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(coef[0]), _p(coef[1]),
-                             int(relu), _p(pst), H * W, _s()), "ssa_bn_apply")
+        if training:
+            sums = _ARENA.take(2 * C, dev)
+            check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), 0, _s()), "ssa_bn_stats")
+            if world:
+                from .parallel import allreduce_bn_sums
+                count = allreduce_bn_sums(sums, P)
+            check(L.ssa_bn_apply_train(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(sums), count, _p(g),
+                                       _p(bta), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
+                                       float(eps), _p(coef), int(relu), _p(pst), H * W, _s()),
+                  "ssa_bn_apply_train")
+        else:
+            check(L.ssa_bn_finalize(None, 1.0, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
+                                    float(momentum), float(eps), 1, _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                    _p(coef[3]), _s()), "ssa_bn_finalize")
+            check(L.ssa_bn_apply(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(coef[0]), _p(coef[1]),
+                                 int(relu), _p(pst), H * W, _s()), "ssa_bn_apply")
         ctx.save_for_backward(x, z if relu else None, g, coef, pst)
         ctx.meta = (ldx, relu, training, world, residual is not None, count)
         return z
@@ -283,26 +367,32 @@ class BatchNormActFn(torch.autograd.Function):
         dz, lddz = _pixels(dz if dz.dtype == ACT_DTYPE else dz.to(ACT_DTYPE))
         if lddz % 8 or dz.data_ptr() % 16:
             dz, lddz = dz.contiguous(), C
-        sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        sums = _ARENA.take(2 * C, dev)
         check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
-                                  int(relu), _p(pst), H * W, _p(sums), _s()), "ssa_bn_bwd_reduce")
-        dgamma = dbeta = None
-        if g is not None:
-            pg = torch.empty((2, C), dtype=torch.float32, device=dev)
-            check(L.ssa_bn_param_grads(_p(sums), C, _p(pg[0]), _p(pg[1]), _s()), "ssa_bn_param_grads")
-            dgamma, dbeta = pg[0], pg[1]
+                                  int(relu), _p(pst), H * W, _p(sums), 0, _s()), "ssa_bn_bwd_reduce")
+        pg = torch.empty((2, C), dtype=torch.float32, device=dev) if g is not None else None
+        pscale = 1.0
+        use_sums = sums
         if training:
             if world:
                 from .parallel import allreduce_bn_sums
                 allreduce_bn_sums(sums, P)
+                pscale = 1.0 / world
         else:
-            sums = torch.zeros_like(sums)  # eval-mode BN: statistics are constants
+            # eval-mode BN: statistics are constants -> no mean/projection terms, but
+            # the parameter gradients still come from the reduced sums
+            if pg is not None:
+                check(L.ssa_bn_param_grads(_p(sums), C, _p(pg[0]), _p(pg[1]), _s()), "ssa_bn_param_grads")
+            use_sums = _ARENA.take(2 * C, dev)
         dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
         dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if has_res else None
+        fuse_pg = pg is not None and training
         check(L.ssa_bn_bwd_apply(_p(x), ldx, _p(dz), lddz, _p(z), C, _p(dx), C, _p(dres), C, P, C, _p(g),
-                                 _p(coef[2]), _p(coef[3]), _p(sums), count, int(relu), _p(pst), H * W, _s()),
+                                 _p(coef[2]), _p(coef[3]), _p(use_sums), count, int(relu), _p(pst), H * W,
+                                 _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale, _s()),
               "ssa_bn_bwd_apply")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None
+        dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
 
 
 class SumActFn(torch.autograd.Function):

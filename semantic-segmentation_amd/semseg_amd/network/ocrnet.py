@@ -76,7 +76,7 @@ class OCRNet(_Base):
         self.ocr = OCR_block(high_level_ch)
 
     def forward(self, inputs):
-        ops.backend().begin_step()
+        ops.backend().begin_step(inputs["images"].device)
         x, size = self._images(inputs)
         _, _, feats = self.backbone(x)
         cls_out, aux_out, _ = self.ocr(feats)
@@ -173,7 +173,7 @@ class MscaleOCR(_Base):
                 "attn_05x": _nchw(attn_05x)}
 
     def forward(self, inputs):
-        ops.backend().begin_step()
+        ops.backend().begin_step(inputs["images"].device)
         if cfg.MODEL.N_SCALES and not self.training:
             return self.nscale_forward(inputs, cfg.MODEL.N_SCALES)
         return self.two_scale_forward(inputs)

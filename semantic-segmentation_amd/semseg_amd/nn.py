@@ -23,8 +23,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     sync = False
 
     def forward(self, x, residual=None, relu=False, post=None):
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
+        # running statistics and num_batches_tracked are updated by the backend
+        # (inside the fused normalisation kernel on the HIP path)
         return ops.backend().batch_norm_act(x, self, residual, relu, post)
 
 

@@ -22,8 +22,8 @@ class HipBackend:
         self.hb = hb
         self.act_dtype = hb.ACT_DTYPE
 
-    def begin_step(self):
-        self.hb.clear_pack_cache()
+    def begin_step(self, device=None):
+        self.hb.begin_step(device)
 
     def image_to_nhwc(self, images, out_hw=None):
         return self.hb.image_to_nhwc(images, out_hw)
@@ -34,6 +34,7 @@ class HipBackend:
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
         return self.hb.BatchNormActFn.apply(
             x, bn.weight, bn.bias, residual, post, bn.running_mean, bn.running_var,
+            bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None,
             0.1 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu,
             getattr(bn, "sync", False))
 

@@ -1,0 +1,83 @@
+"""TEST-ONLY: the oracle's CPU operators with the product's STORAGE precision
+emulated -- every tensor the HIP path keeps in bf16 is rounded to bf16 here
+(forward values and the gradients flowing back), arithmetic stays fp32.
+
+Purpose: the end-to-end tests need a principled tolerance.  The network is
+~450 tensors deep and some of its layers (BatchNorm over the 19x1 object
+proxies, BatchNorm after the near-constant OCR context) amplify relative
+perturbations several-fold, so "HIP vs fp32 oracle" has a noise floor set by
+bf16 storage alone.  This backend measures that floor on the same weights and
+inputs; the e2e tests then require the HIP path to be no further from the fp32
+oracle than a stated multiple of it, op by op.  The product never imports it.
+"""
+import torch
+
+from oracle_backend import OracleBackend
+
+
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+R = _Round.apply
+
+
+class Bf16EmuBackend(OracleBackend):
+    name = "oracle-cpu-bf16-storage"
+
+    def image_to_nhwc(self, images, out_hw=None):
+        return R(super().image_to_nhwc(images, out_hw))
+
+    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False):
+        y = super().conv2d(x, R(weight), bias, stride, padding, dilation, out_f32)
+        return y if out_f32 else R(y)
+
+    def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
+        return R(super().batch_norm_act(x, bn, residual, relu, post))
+
+    def sum_act(self, tensors, relu=True):
+        return R(super().sum_act(tensors, relu))
+
+    def bilinear(self, x, size, out_f32=False):
+        if tuple(x.shape[1:3]) == tuple(size):
+            return x
+        y = super().bilinear(x, size, out_f32)
+        # class logits ([..,19]) and attention maps ([..,1]) are fp32 tensors on the
+        # HIP path too (everything here has dtype fp32, so go by channel count)
+        return y if (out_f32 or x.shape[3] in (1, 19)) else R(y)
+
+    def ocr_attention(self, q, k, v, scale):
+        return R(super().ocr_attention(q, k, v, scale))
+
+
+TRACED = ("image_to_nhwc", "conv2d", "batch_norm_act", "sum_act", "bilinear", "ocr_gather", "ocr_attention")
+
+
+def traced(backend, sink):
+    """Wrap `backend` so that every activation-producing op calls
+    sink(index, name, output).  Works for the HIP backend and the CPU ones."""
+    counter = [0]
+
+    class Traced(type(backend)):
+        pass
+
+    def mk(name):
+        f = getattr(type(backend), name)
+
+        def g(self, *a, **k):
+            y = f(self, *a, **k)
+            sink(counter[0], name, y)
+            counter[0] += 1
+            return y
+        return g
+
+    for name in TRACED:
+        setattr(Traced, name, mk(name))
+    backend.__class__ = Traced
+    return backend

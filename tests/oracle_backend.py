@@ -19,7 +19,7 @@ class OracleBackend:
     name = "oracle-cpu"
     act_dtype = torch.float32
 
-    def begin_step(self):
+    def begin_step(self, device=None):
         pass
 
     def image_to_nhwc(self, images, out_hw=None):
@@ -34,6 +34,8 @@ class OracleBackend:
         return _to_nhwc(O.conv2d(xin, weight, bias, stride, padding, dilation))
 
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
         y = O.batch_norm(_to_nchw(x), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
                          0.1 if bn.momentum is None else bn.momentum, bn.eps)
         y = _to_nhwc(y)

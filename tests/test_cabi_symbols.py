@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     d = _lib.ConvDesc(1, 8, 8, 12, 12, 8, 8, 16, 16, 3, 3, 1, 1, 1, 0, 128, 0, -1)   # Cin % 8 != 0
     assert L.ssa_conv2d_igemm(ctypes.byref(d), None, None, None, None, None) == -1
-    assert L.ssa_bn_stats(None, 10, 48, 48, None, None) == -1
+    assert L.ssa_bn_stats(None, 10, 48, 48, None, 1, None) == -1
     assert L.ssa_pack_filter(None, None, 1, 1, 1, 1, 8, 8, 32, 0, None) == -1
 
 

@@ -146,6 +146,28 @@ def test_conv_all_tile_configs(cfg):
     check_close("conv cfg%d" % cfg, nchw(y.float()), yr)
 
 
+def test_batched_filter_repack():
+    """refresh_packed_filters (one launch for all stale filters) == per-filter packing."""
+    hb = _hb()
+    hb.clear_pack_cache()
+    ws = [torch.randn(48, 48, 3, 3, device=DEV), torch.randn(19, 512, 1, 1, device=DEV),
+          torch.randn(96, 48, 3, 3, device=DEV), torch.randn(64, 3, 3, 3, device=DEV)]
+    specs = [(0, 48, 0), (1, 0, 48), (0, 512, 0), (1, 0, 24), (0, 48, 0), (1, 0, 96), (0, 16, 0)]
+    owners = [0, 0, 1, 1, 2, 2, 3]
+    first = [hb._packed_filter(ws[o], *sp)[0] for o, sp in zip(owners, specs)]
+    for w in ws:
+        w.mul_(-0.5).add_(0.25)                # in-place update, like an optimizer step
+    hb.refresh_packed_filters()
+    torch.cuda.synchronize()
+    batched = [t.clone() for t in first]       # same persistent buffers, refreshed in place
+    hb.clear_pack_cache()
+    for o, sp, got in zip(owners, specs, batched):
+        want = hb._packed_filter(ws[o], *sp)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (o, sp)
+    hb.clear_pack_cache()
+
+
 def test_conv_channel_slice_input():
     """Input given as a channel slice of a wider NHWC buffer (ld > C)."""
     from oracle import ops as O
@@ -198,12 +220,14 @@ def test_bn_train(C, relu, res, post):
     rd = _to_dev_nhwc(r).requires_grad_(True) if res else None
     rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     pmd = pm.to(DEV) if post else None
-    z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, 0.1, 1e-5, True, relu, False)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, nbt, 0.1, 1e-5, True, relu, False)
     z.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
     torch.cuda.synchronize()
     check_close("bn_fwd", nchw(z.float()), y)
     check_close("bn_running_mean", rmd, rm, 1e-4, 1e-4)
     check_close("bn_running_var", rvd, rv, 1e-4, 1e-4)
+    assert int(nbt) == 1
     check_close("bn_dx", nchw(xd.grad.float()), xr.grad, 2e-2, 6e-3)
     check_close("bn_dgamma", gd.grad, gr.grad, 1e-2, 4e-3)
     check_close("bn_dbeta", bd.grad, br.grad, 1e-2, 4e-3)
@@ -220,7 +244,7 @@ def test_bn_eval():
     rm, rv = torch.randn(C) * 0.2, torch.rand(C) + 0.5
     y = torch.relu(O.batch_norm(x, gamma, beta, rm.clone(), rv.clone(), False))
     z = hb.BatchNormActFn.apply(_to_dev_nhwc(x), gamma.to(DEV), beta.to(DEV), None, None, rm.to(DEV),
-                                rv.to(DEV), 0.1, 1e-5, False, True, False)
+                                rv.to(DEV), None, 0.1, 1e-5, False, True, False)
     torch.cuda.synchronize()
     check_close("bn_eval", nchw(z.float()), y)
 
