@@ -60,6 +60,18 @@ typedef struct ssa_conv_desc {
 int ssa_conv2d_igemm(const ssa_conv_desc* d, const void* x, const void* w_packed,
                      const float* bias, void* y, void* stream);
 
+/* Halo-tile convolution for the small-channel 3x3 stride-1 "same" convs of the
+ * HRNet branches (Cin in {48, 64, 96}): the input halo tile is staged in LDS
+ * once, all taps are computed from it, the filter streams from L2 in fragment
+ * order (ssa_pack_filter mode 2/3).  stats (optional): BatchNorm partial sums
+ * [ssa_bn_stat_replicas()][2][Cout] fp64, ACCUMULATED (caller clears), of the
+ * bf16-rounded outputs -- the conv epilogue replaces the ssa_bn_stats pass.
+ * ssa_conv2d_tile_supported: 1 if this descriptor can run on this kernel.     */
+int ssa_conv2d_tile_supported(const ssa_conv_desc* d);
+int ssa_conv2d_tile(const ssa_conv_desc* d, const void* x, const void* w_frag,
+                    const float* bias, void* y, double* stats, void* stream);
+int ssa_bn_stat_replicas(void);
+
 /* Tile configuration ssa_conv2d_igemm would use for this problem
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);
@@ -67,7 +79,10 @@ int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);
 /* Filter packing: OIHW fp32 parameter -> bf16 [rows][Kpad] GEMM operand.
  * mode 0 (forward): rows = Cout, k = (kh,kw,ci) with ci < cin_pad.
  * mode 1 (dgrad)  : rows = Cin,  k = (kh',kw',co) with co < cout_pad, taps
- *                   flipped (kh' = KH-1-kh) -- the transposed filter.          */
+ *                   flipped (kh' = KH-1-kh) -- the transposed filter.
+ * mode 2 / 3      : the same two operands in MFMA-fragment order for
+ *                   ssa_conv2d_tile: [n-block][k-step][lane][8], rows padded to
+ *                   a multiple of 32, Kpad = KH*KW*c_pad (a multiple of 16).   */
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin,
                     int KH, int KW, int cin_pad, int cout_pad, int Kpad,
                     int mode, void* stream);
@@ -114,11 +129,13 @@ int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_su
                  void* stream);
 /* Training-mode normalisation with the finalize step fused in (one launch):
  * z = post*act(bn(x) + residual) with batch statistics from `sums`/`count`
- * (possibly all-reduced: SyncBN); writes coef = [scale|shift|mean|invstd] (4*C
+ * (possibly all-reduced: SyncBN).  sums is [nrep][2][C]: nrep = 1 after
+ * ssa_bn_stats, ssa_bn_stat_replicas() after a conv epilogue
+ * (ssa_conv2d_tile) -- the replicas are summed here.  Writes coef = [scale|shift|mean|invstd] (4*C
  * fp32) for the backward pass, updates running_mean/var (momentum, unbiased
  * variance) and increments *num_batches_tracked (int64) when given.           */
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z,
-                       int ldz, long P, int C, const double* sums, double count,
+                       int ldz, long P, int C, const double* sums, int nrep, double count,
                        const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long* num_batches_tracked, float momentum,
                        float eps, float* coef, int relu, const float* post,

@@ -52,10 +52,23 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const bf16_t* __restrict__
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
   if (active) {
-    for (long p = p0 + pr; p < p1; p += RP) {
-      const uint4 v = *reinterpret_cast<const uint4*>(x + p * ld + cg * 8);
+    const bf16_t* xp = x + cg * 8;
+    long p = p0 + pr;
+    for (; p + 3L * RP < p1; p += 4L * RP) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(xp + (p + (long)u * RP) * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+      }
+    }
+    for (; p < p1; p += RP) {
       float f[8];
-      unpack8(v, f);
+      unpack8(*reinterpret_cast<const uint4*>(xp + p * ld), f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
     }
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(
   for (int j = 0; j < 8; ++j) { a[j] = scale[cg * 8 + j]; b[j] = shift[cg * 8 + j]; }
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
+#pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
     const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
     float f[8];
@@ -140,8 +154,8 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(
 // backward pass, updates the running statistics and bumps num_batches_tracked.
 __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
-    bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, double count,
-    const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, int nrep,
+    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     int relu, const float* __restrict__ post, long pix_per_img, long pix_per_block) {
@@ -149,8 +163,10 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
   const int t = threadIdx.x;
   if (blockIdx.x == 0) {
     for (int c = t; c < C; c += NT) {
-      const double mean = sums[c] / count;
-      double var = sums[C + c] / count - mean * mean;
+      double s1 = 0.0, s2 = 0.0;
+      for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+      const double mean = s1 / count;
+      double var = s2 / count - mean * mean;
       if (var < 0.0) var = 0.0;
       const double invstd = 1.0 / sqrt(var + (double)eps);
       const double g = gamma ? (double)gamma[c] : 1.0;
@@ -173,8 +189,10 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    const double mean = sums[c] / count;
-    double var = sums[C + c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const double g = gamma ? (double)gamma[c] : 1.0;
@@ -184,6 +202,7 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
   }
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
+#pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
     const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
     float f[8];
@@ -228,7 +247,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
     for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
     const long p0 = blockIdx.x * pix_per_block;
     const long p1 = min(P, p0 + pix_per_block);
-    for (long p = p0 + pr; p < p1; p += RP) {
+  #pragma unroll 4
+  for (long p = p0 + pr; p < p1; p += RP) {
       float g[8], xv[8];
       unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
       unpack8(*reinterpret_cast<const uint4*>(x + p * ldx + cg * 8), xv);
@@ -283,6 +303,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   }
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
+#pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
     float g[8], xv[8];
     unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const bf16_t* __restrict__ x
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
   if (active) {
-    for (long p = p0 + pr; p < p1; p += RP) {
+  #pragma unroll 4
+  for (long p = p0 + pr; p < p1; p += RP) {
       float f[8];
       unpack8(*reinterpret_cast<const uint4*>(x + p * ld + cg * 8), f);
 #pragma unroll
@@ -347,14 +369,15 @@ __global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ ou
 }
 
 struct Grid { int blocks; long ppb; };
-Grid plan_grid(long P, int C) {
+// rows_per_thread pixel rows per thread; at most max_blocks workgroups (the
+// reducing kernels end in 2C fp64 atomics per workgroup, so they get a lower cap).
+Grid plan_grid(long P, int C, int rows_per_thread = 4, long max_blocks = 16384) {
   const int VC = C >> 3;
   const int RP = active_threads(VC) / VC;
-  // ~8 pixel rows per thread per block, capped at 2048 blocks
-  long ppb = (long)RP * 8;
+  long ppb = (long)RP * rows_per_thread;
   long blocks = (P + ppb - 1) / ppb;
-  if (blocks > 2048) {
-    blocks = 2048;
+  if (blocks > max_blocks) {
+    blocks = max_blocks;
     ppb = (P + blocks - 1) / blocks;
     ppb = (ppb + RP - 1) / RP * RP;
     blocks = (P + ppb - 1) / ppb;
@@ -362,6 +385,7 @@ Grid plan_grid(long P, int C) {
   if (blocks < 1) blocks = 1;
   return {(int)blocks, ppb};
 }
+Grid plan_reduce_grid(long P, int C) { return plan_grid(P, C, 8, 1024); }
 
 bool ok_c(int C) { return C > 0 && C % 8 == 0 && C <= 2048; }
 
@@ -376,7 +400,7 @@ int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_su
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
   }
-  const Grid g = plan_grid(P, C);
+  const Grid g = plan_reduce_grid(P, C);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, P, C, ld, sums, g.ppb);
   SSA_LAUNCH_CHECK();
@@ -410,17 +434,17 @@ int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
 }
 
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz,
-                       long P, int C, const double* sums, double count, const float* gamma,
+                       long P, int C, const double* sums, int nrep, double count, const float* gamma,
                        const float* beta, float* running_mean, float* running_var,
                        long* num_batches_tracked, float momentum, float eps, float* coef, int relu,
                        const float* post, long pix_per_img, void* stream) {
   if (!x || !z || !sums || !coef || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
-      count <= 0 || (running_mean && !running_var))
+      count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
   hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
-                     sums, count, gamma, beta, running_mean, running_var, num_batches_tracked,
+                     sums, nrep, count, gamma, beta, running_mean, running_var, num_batches_tracked,
                      momentum, eps, coef, relu, post, pix_per_img, g.ppb);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
@@ -437,7 +461,7 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
   }
-  const Grid g = plan_grid(P, C);
+  const Grid g = plan_reduce_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
                      mean, invstd, relu, post, pix_per_img, sums, g.ppb);
@@ -475,7 +499,7 @@ int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out, double* sc
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(scratch2c, 0, sizeof(double) * 2 * C, s);
   if (e != hipSuccess) return (int)e;
-  const Grid g = plan_grid(P, C);
+  const Grid g = plan_reduce_grid(P, C);
   hipLaunchKernelGGL(colsum_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, P, C, ld, scratch2c, g.ppb);
   SSA_LAUNCH_CHECK();

@@ -511,35 +511,36 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
     }
 }
 
-// One workgroup per output channel: sum the nsplit partial rows (coalesced
-// reads, k = (kh,kw,ci) fastest), transpose (kh,kw,ci) -> (ci,kh,kw) through
-// LDS, write the OIHW row with coalesced stores.
+// Workgroup (co, k-chunk of 64): 64 k-columns x 4 split lanes; each thread sums
+// every 4th split (coalesced 256-byte rows), the 4 lanes meet in LDS, and the
+// chunk is written to its OIHW positions.  k = (kh,kw,ci) -> (ci,kh,kw).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(
     const float* __restrict__ partial, int nsplit, int cout_pad, int Cout, int Cin_pad, int Cin,
     int KH, int KW, float* __restrict__ dw) {
-  extern __shared__ float row[];
+  __shared__ float sh[4][64];
   const int co = blockIdx.x;
   const int taps = KH * KW;
   const int Kflat = taps * Cin_pad;
+  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int k = blockIdx.y * 64 + kk;
   const long split_stride = (long)cout_pad * Kflat;
-  const float* src = partial + (long)co * Kflat;
-  for (int k = threadIdx.x; k < Kflat; k += 256) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int sp = 0;
-    for (; sp + 4 <= nsplit; sp += 4) {
-      s0 += src[(long)sp * split_stride + k];
-      s1 += src[(long)(sp + 1) * split_stride + k];
-      s2 += src[(long)(sp + 2) * split_stride + k];
-      s3 += src[(long)(sp + 3) * split_stride + k];
+  float s0 = 0.f, s1 = 0.f;
+  if (k < Kflat) {
+    const float* src = partial + (long)co * Kflat + k;
+    int sp = sl;
+    for (; sp + 4 < nsplit; sp += 8) {
+      s0 += src[(long)sp * split_stride];
+      s1 += src[(long)(sp + 4) * split_stride];
     }
-    for (; sp < nsplit; ++sp) s0 += src[(long)sp * split_stride + k];
-    const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
-    if (ci < Cin) row[ci * taps + tap] = (s0 + s1) + (s2 + s3);
+    if (sp < nsplit) s0 += src[(long)sp * split_stride];
   }
+  sh[sl][kk] = s0 + s1;
   __syncthreads();
-  const int n = Cin * taps;
-  float* dst = dw + (long)co * n;
-  for (int i = threadIdx.x; i < n; i += 256) dst[i] = row[i];
+  if (sl == 0 && k < Kflat) {
+    const float v = (sh[0][kk] + sh[1][kk]) + (sh[2][kk] + sh[3][kk]);
+    const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
+    if (ci < Cin) dw[((long)co * Cin + ci) * taps + tap] = v;
+  }
 }
 
 struct PackJob {           // mirror of ssa_pack_job (include/semseg_hip.h)
@@ -570,12 +571,30 @@ __device__ __forceinline__ bf16_t pack_one(const float* __restrict__ w, int Cout
 }
 
 // All filters of the network in one launch: blockIdx.y = job, grid-stride in x.
+// flat output index -> (row, k) of the GEMM operand.  mode 0/1: row-major
+// [rows][Kpad].  mode 2/3 (MFMA-fragment order, conv_tile.hip):
+// [n-block][k-step][lane][8] with row = nb*32 + (lane&31), k = ks*16 + 8*(lane>>5) + j.
+__device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int* r, int* k) {
+  if (mode < 2) {
+    *r = (int)(i / Kpad);
+    *k = (int)(i - (long)*r * Kpad);
+  } else {
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+    const long blk = i >> 9;
+    const int ksteps = Kpad >> 4;
+    const int ks = (int)(blk % ksteps), nb = (int)(blk / ksteps);
+    *r = nb * 32 + (l & 31);
+    *k = ks * 16 + 8 * (l >> 5) + j;
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob* __restrict__ jobs) {
   const PackJob j = jobs[blockIdx.y];
   const long n = (long)j.rows * j.Kpad;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / j.Kpad), k = (int)(i - (long)r * j.Kpad);
-    j.out[i] = pack_one(j.w, j.Cout, j.Cin, j.KH, j.KW, j.cin_pad, j.cout_pad, j.mode, r, k);
+    int r, k;
+    pack_index(i, j.Kpad, j.mode, &r, &k);
+    j.out[i] = pack_one(j.w, j.Cout, j.Cin, j.KH, j.KW, j.cin_pad, j.cout_pad, j.mode & 1, r, k);
   }
 }
 
@@ -584,8 +603,9 @@ __global__ void pack_filter_kernel(const float* __restrict__ w, bf16_t* __restri
                                    int mode, int rows) {
   const long n = (long)rows * Kpad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(i / Kpad), k = (int)(i - (long)r * Kpad);
-    out[i] = pack_one(w, Cout, Cin, KH, KW, cin_pad, cout_pad, mode, r, k);
+    int r, k;
+    pack_index(i, Kpad, mode, &r, &k);
+    out[i] = pack_one(w, Cout, Cin, KH, KW, cin_pad, cout_pad, mode & 1, r, k);
   }
 }
 
@@ -728,10 +748,15 @@ int ssa_conv2d_igemm_tile(const ssa_conv_desc* dp) {
 
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
                     int cin_pad, int cout_pad, int Kpad, int mode, void* stream) {
-  if (!w_oihw || !w_packed || Kpad % BK) return SSA_EINVAL;
-  const int rows = mode == 0 ? Cout : Cin;
-  const long kneed = (long)KH * KW * (mode == 0 ? cin_pad : cout_pad);
-  if (Kpad < kneed) return SSA_EINVAL;
+  if (!w_oihw || !w_packed || mode < 0 || mode > 3) return SSA_EINVAL;
+  int rows = (mode & 1) == 0 ? Cout : Cin;
+  const long kneed = (long)KH * KW * ((mode & 1) == 0 ? cin_pad : cout_pad);
+  if (mode < 2) {
+    if (Kpad % BK || Kpad < kneed) return SSA_EINVAL;
+  } else {
+    if (Kpad != kneed || Kpad % 16) return SSA_EINVAL;
+    rows = (rows + 31) / 32 * 32;
+  }
   const long n = (long)rows * Kpad;
   const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(pack_filter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw,
@@ -747,7 +772,7 @@ int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, siz
   const int Kflat = d->KH * d->KW * d->Cin;
   const long tiles = (long)((cout_pad + bm - 1) / bm) * ((Kflat + bn - 1) / bn);
   const long P = (long)d->B * d->Ho * d->Wo;
-  long ns = (1024 + tiles - 1) / tiles;
+  long ns = (640 + tiles - 1) / tiles;
   const long max_by_pixels = (P + 127) / 128;  // at least 4 stages per split
   if (ns > max_by_pixels) ns = max_by_pixels;
   if (ns < 1) ns = 1;
@@ -777,10 +802,10 @@ int ssa_conv2d_wgrad(const ssa_conv_desc* dp, const void* x, const void* dy, int
 int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int Cout, int Cin_pad,
                             int Cin, int KH, int KW, float* dw_oihw, void* stream) {
   if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad || nsplit < 1) return SSA_EINVAL;
-  const size_t lds = (size_t)Cin * KH * KW * sizeof(float);
-  if (lds > 64 * 1024) return SSA_EUNSUPPORTED;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds, (hipStream_t)stream, partial,
-                     nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, dw_oihw);
+  const int Kflat = KH * KW * Cin_pad;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (Kflat + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, partial, nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW,
+                     dw_oihw);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

@@ -1,0 +1,308 @@
+// Halo-tile convolution for the small-channel HRNet branches (gfx950 / MI355X).
+//
+// The 48/64/96-channel 3x3 convs of the HRNetV2 trunk (network/hrnetv2.py:31-66,
+// SURVEY.md K1; 24 % of the step's FLOPs, 1,046 launches per training step) are
+// HBM/latency bound: K = 9*Cin is only 432..864, so a K-pipelined implicit GEMM
+// spends its time in 14..27 dependent global->LDS stages.  Here one workgroup
+//   * loads the (TH+2)x(TW+2) input halo tile ONCE (one burst of 16-byte loads,
+//     every input byte fetched from L2/HBM once per tile instead of 9 times),
+//   * runs all 9 taps x Cin straight out of LDS: the MFMA A fragment of tap
+//     (kh,kw) is the same LDS image read at a shifted pixel offset, no im2col,
+//   * takes the B operand (filter) from a copy packed in MFMA-fragment order
+//     ([n-block][k-step][lane][8], ssa_pack_filter mode 2/3): it is DMA'd into
+//     LDS with global_load_lds_dwordx4 (one 1-KiB fragment block per wave
+//     instruction, no VGPRs, issued together with the halo loads), whole for
+//     Cin <= 64, in 3-tap chunks double-buffered against the MFMAs for Cin = 96,
+//   * has one barrier per filter chunk (1 or 3 in the whole kernel),
+//   * optionally accumulates the BatchNorm batch statistics (sum, sum of squares
+//     of the bf16-rounded outputs) in the epilogue -> no separate stats pass.
+// The same kernel computes the data gradient (flipped, transposed filter).
+//
+// LDS image: [halo pixel][Cin] bf16 with pixel stride Cin*2+16 bytes: an odd
+// number of 16-byte slots, so the 16 lanes ds_read_b128 services together
+// (consecutive pixels, same channel offset) fall on 16 distinct slots.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+constexpr int kStatReplicas = 8;   // BN partial sums are spread over 8 replicas (atomic contention)
+
+// Filter chunk c (TPC taps) of the NB n-blocks -> LDS buffer, as direct
+// global->LDS DMA: one global_load_lds_dwordx4 per wave moves one 1-KiB
+// (n-block, k-step) fragment block; the LDS image is lane-linear, which is
+// exactly the order ds_read_b128 wants the B fragment in.
+template <int NB, int KSTEPS, int CHUNK_KS>
+__device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfrag, int nb0,
+                                                   int nb_total, int chunk, unsigned char* dst,
+                                                   int wave, int lane) {
+  constexpr int NFRAG = NB * CHUNK_KS;
+#pragma unroll
+  for (int f = 0; f < (NFRAG + 3) / 4; ++f) {
+    const int fi = f * 4 + wave;               // wave-uniform
+    if (fi < NFRAG) {
+      const int nb = fi / CHUNK_KS, ksl = fi - nb * CHUNK_KS;
+      const int nbg = min(nb0 + nb, nb_total - 1);   // n-blocks past the end re-read the last one (never stored)
+      const uint4* src = wfrag + ((long)nbg * KSTEPS + chunk * CHUNK_KS + ksl) * 64 + lane;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(dst + (size_t)fi * 1024), 16, 0, 0);
+    }
+  }
+}
+
+template <int CIN, int KS, int NB, int MI, int TW, int TPC>
+__global__ __launch_bounds__(256) void conv_tile_kernel(
+    const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wfrag,
+    const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
+    int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats) {
+  constexpr int R = KS / 2;
+  constexpr int BM = 4 * MI * 32;              // output pixels per workgroup
+  constexpr int TH = BM / TW;                  // tile rows
+  constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
+  constexpr int PSB = CIN * 2 + 16;            // halo pixel stride in bytes
+  constexpr int CP = CIN / 8;                  // 16-byte pieces per pixel
+  constexpr int NPIECE = HH_ * HW_ * CP;
+  constexpr int CSTEPS = CIN / 16;
+  constexpr int TAPS = KS * KS;
+  constexpr int KSTEPS = TAPS * CSTEPS;
+  constexpr int NCHUNK = TAPS / TPC;
+  static_assert(NCHUNK * TPC == TAPS, "taps per chunk must divide the tap count");
+  constexpr int CHUNK_KS = TPC * CSTEPS;       // k-steps per filter chunk
+  constexpr int CHUNK_BYTES = NB * CHUNK_KS * 1024;
+  constexpr int NBUF = NCHUNK > 1 ? 2 : 1;
+  constexpr int HALO_BYTES = (HH_ * HW_ * PSB + 1023) / 1024 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Bs = smem + HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x; bid /= tiles_x;
+  const int ty_i = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int nb0 = blockIdx.y * NB;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+
+  // ---- halo tile -> registers, filter chunk 0 -> LDS (DMA), halo -> LDS: one burst
+  {
+    const bf16_t* xb = x + (long)b * H * W * ldx;
+    constexpr int IT = (NPIECE + 255) / 256;
+    uint4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int piece = tid + i * 256;
+      const int pix = piece / CP, cp = piece - pix * CP;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      const int iy = y0 - R + hy, ix = x0 - R + hx;
+      const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      v[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cp * 8)
+                : make_uint4(0, 0, 0, 0);
+    }
+    stage_filter_chunk<NB, KSTEPS, CHUNK_KS>(wfrag, nb0, nb_total, 0, Bs, wave, lane);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int piece = tid + i * 256;
+      const int pix = piece / CP, cp = piece - pix * CP;
+      if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
+    }
+  }
+
+  // ---- per-lane A addressing: MFMA row block mi of this wave -> tile pixels
+  int a_off[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = (wave * MI + mi) * 32 + (lane & 31);
+    const int ty = m / TW, tx = m - ty * TW;
+    a_off[mi] = (ty * HW_ + tx) * PSB + (lane >> 5) * 16;
+  }
+
+  f32x16_t acc[MI][NB];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+
+  __syncthreads();                              // halo + filter chunk 0 landed (vmcnt(0) + barrier)
+
+#pragma unroll
+  for (int ch = 0; ch < NCHUNK; ++ch) {
+    if (ch + 1 < NCHUNK)
+      stage_filter_chunk<NB, KSTEPS, CHUNK_KS>(wfrag, nb0, nb_total, ch + 1,
+                                               Bs + ((ch + 1) % NBUF) * CHUNK_BYTES, wave, lane);
+    const unsigned char* Bc = Bs + (ch % NBUF) * CHUNK_BYTES + lane * 16;
+#pragma unroll
+    for (int ksl = 0; ksl < CHUNK_KS; ++ksl) {
+      const int tap = ch * TPC + ksl / CSTEPS, cs = ksl % CSTEPS;
+      const int kh = tap / KS, kw = tap - kh * KS;
+      bf16x8_t af[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        af[mi] = *reinterpret_cast<const bf16x8_t*>(smem + a_off[mi] + (kh * HW_ + kw) * PSB + cs * 32);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * CHUNK_KS + ksl) * 1024);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][nb], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < NCHUNK) __syncthreads();       // next chunk landed; this buffer is free for chunk ch+2
+  }
+
+  // ---- epilogue: (+bias) -> bf16 -> LDS -> coalesced 16-byte stores; BN statistics
+  __syncthreads();                              // everyone is done reading the halo image
+  constexpr int LDC = NB * 32 + 8;              // staging row stride (elements)
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 waves][2][NB*32]
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 32 + (lane & 31);
+    const int n = nb0 * 32 + col;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const bf16_t o = f2bf(acc[mi][nb][r] + bv);
+        Cs[row * LDC + col] = o;
+        if (stats != nullptr) {
+          const int ty = row / TW, tx = row - ty * TW;
+          const float f = (y0 + ty < H && x0 + tx < W) ? bf2f(o) : 0.f;
+          s += f;
+          q += f * f;
+        }
+      }
+    }
+    if (stats != nullptr) {
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        red[(wave * 2 + 0) * NB * 32 + col] = s;
+        red[(wave * 2 + 1) * NB * 32 + col] = q;
+      }
+    }
+  }
+  __syncthreads();
+  if (stats != nullptr) {
+    // stats layout: [replica][2][C]; replica = workgroup index mod kStatReplicas
+    double* st = stats + (long)(blockIdx.x % kStatReplicas) * 2 * Cout;
+    for (int i = tid; i < 2 * NB * 32; i += 256) {
+      const int which = i / (NB * 32), col = i - which * NB * 32;
+      const int n = nb0 * 32 + col;
+      if (n < Cout) {
+        const float v = (red[(0 * 2 + which) * NB * 32 + col] + red[(1 * 2 + which) * NB * 32 + col]) +
+                        (red[(2 * 2 + which) * NB * 32 + col] + red[(3 * 2 + which) * NB * 32 + col]);
+        atomicAdd(&st[which * Cout + n], (double)v);
+      }
+    }
+  }
+  bf16_t* yb = y + (long)b * H * W * ldy;
+  constexpr int CPR = NB * 4;                   // 16-byte pieces per staged row
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, cp = idx - row * CPR;
+    const int ty = row / TW, tx = row - ty * TW;
+    const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
+    if (oy >= H || ox >= W || n >= Cout) continue;
+    bf16_t* dst = yb + ((long)oy * W + ox) * ldy + n;
+    const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (n + 8 <= Cout) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+template <int CIN, int KS, int NB, int MI, int TW, int TPC>
+int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
+                double* stats, hipStream_t s) {
+  constexpr int R = KS / 2, BM = 4 * MI * 32, TH = BM / TW;
+  constexpr int NCHUNK = KS * KS / TPC;
+  constexpr size_t halo = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (CIN * 2 + 16) + 1023) / 1024 * 1024;
+  constexpr size_t filt = (size_t)(NCHUNK > 1 ? 2 : 1) * NB * TPC * (CIN / 16) * 1024;
+  constexpr size_t stage = (size_t)BM * (NB * 32 + 8) * 2 + 4 * 2 * NB * 32 * sizeof(float);
+  constexpr size_t lds = halo + filt > stage ? halo + filt : stage;
+  static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const int nb_total = (d.Cout + 31) / 32;
+  auto kern = conv_tile_kernel<CIN, KS, NB, MI, TW, TPC>;
+  if (lds > 64 * 1024) {
+    static bool once = false;                  // per template instantiation
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * d.B, (nb_total + NB - 1) / NB), dim3(256), lds, s,
+                     (const bf16_t*)x, d.ldx, (const uint4*)wfrag, bias, (bf16_t*)y, d.ldy, d.B, d.H,
+                     d.W, d.Cout, nb_total, tiles_x, tiles_y, stats);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+// tile shape by image width: TW = 32 where the image is at least 32 wide.
+// big: two MFMA row blocks per wave (256 pixels per workgroup) where LDS allows.
+template <int CIN, int KS, int NB, int TPC, bool BIG_OK>
+int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
+                  double* stats, hipStream_t s, bool want_big) {
+  if (d.W >= 32) {
+    if constexpr (BIG_OK) {
+      if (want_big) return launch_tile<CIN, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s);
+    }
+    return launch_tile<CIN, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s);
+  }
+  if (d.W >= 16) return launch_tile<CIN, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s);
+  return launch_tile<CIN, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_conv2d_tile_supported(const ssa_conv_desc* d) {
+  if (!d) return 0;
+  if (d->KH != d->KW || d->KH != 3) return 0;
+  if (d->stride != 1 || d->dil != 1 || d->transposed || d->pad != d->KH / 2) return 0;
+  if (d->Ho != d->H || d->Wo != d->W || d->out_f32) return 0;
+  if (d->Cout % 8 || d->ldy % 8 || d->ldx % 8) return 0;
+  return d->Cin == 48 || d->Cin == 64 || d->Cin == 96;
+}
+
+int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
+                    void* y, double* stats, void* stream) {
+  if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
+  if (!ssa_conv2d_tile_supported(dp)) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
+    return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  const int nbt = (d.Cout + 31) / 32;
+  // cfg (benchmark knob): bit 0 = force the 128-pixel tile, bit 1 = one n-block per workgroup
+  const int cfg = d.cfg < 0 ? 0 : d.cfg;
+  const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
+  const bool split_n = (cfg & 2) != 0;
+  switch (d.Cin) {
+    case 48:
+      if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<48, 3, 2, 9, true>(d, x, w_frag, bias, y, stats, s, big);
+      return dispatch_geom<48, 3, 3, 9, false>(d, x, w_frag, bias, y, stats, s, big);
+    case 64:
+      if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big);
+      return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big);
+    case 96:
+      if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big);
+      return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big);
+    default: return SSA_EUNSUPPORTED;
+  }
+}
+
+int ssa_bn_stat_replicas(void) { return kStatReplicas; }
+
+}  // extern "C"

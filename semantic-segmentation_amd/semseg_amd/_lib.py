@@ -33,6 +33,9 @@ _SIGS = {
     "ssa_version": ([], c_int),
     "ssa_conv2d_igemm": ([POINTER(ConvDesc), _P, _P, _P, _P, _P], c_int),
     "ssa_conv2d_igemm_tile": ([POINTER(ConvDesc)], c_int),
+    "ssa_conv2d_tile_supported": ([POINTER(ConvDesc)], c_int),
+    "ssa_conv2d_tile": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
+    "ssa_bn_stat_replicas": ([], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
     "ssa_conv2d_wgrad_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
@@ -40,7 +43,7 @@ _SIGS = {
     "ssa_colsum_bf16": ([_P, c_long, c_int, c_int, _P, _P, _P], c_int),
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
-    "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_double, _P, _P, _P, _P,
+    "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_int, c_double, _P, _P, _P, _P,
                             _P, c_float, c_float, _P, c_int, _P, c_long, _P], c_int),
     "ssa_pack_filters_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,

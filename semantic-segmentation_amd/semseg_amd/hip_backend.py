@@ -118,11 +118,14 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     if e is not None and e.wref() is weight and e.version == weight._version:
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
-    if mode == 0:
+    if mode & 1 == 0:
         rows, kdim = Cout, KH * KW * cin_pad
     else:
         rows, kdim = Cin, KH * KW * cout_pad
-    Kpad = _roundup(kdim, 32)
+    if mode < 2:
+        Kpad = _roundup(kdim, 32)
+    else:                       # MFMA-fragment order (conv_tile.hip): rows padded to 32, K exact
+        rows, Kpad = _roundup(rows, 32), kdim
     w = weight.detach()
     direct = w.dtype == torch.float32 and w.is_contiguous()
     if not direct:
@@ -214,6 +217,44 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     return y
 
 
+def _tile_desc(B, H, W, Cin, ldx, Cout, k, stride, pad, dil, Ho, Wo, out_f32):
+    return ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, 0, 0, int(out_f32), -1)
+
+
+def tile_supported(d):
+    return bool(lib().ssa_conv2d_tile_supported(ctypes.byref(d)))
+
+
+_STAT_REPLICAS = None
+
+
+def stat_replicas():
+    global _STAT_REPLICAS
+    if _STAT_REPLICAS is None:
+        _STAT_REPLICAS = int(lib().ssa_bn_stat_replicas())
+    return _STAT_REPLICAS
+
+
+def _tile_conv(d, x, wfrag, bias, stats):
+    """Halo-tile conv launch (small-channel 3x3 stride-1 convs and their data gradients)."""
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=ACT_DTYPE, device=x.device)
+    if _PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().ssa_conv2d_tile(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()),
+          "ssa_conv2d_tile")
+    if _PROFILE is not None:
+        e1.record()
+        _PROFILE.append(("tile", 100, 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW, e0, e1,
+                         (d.KH, 1, d.Cin, d.Cout, d.Ho, d.Wo)))
+    return y
+
+
+# (data_ptr of a conv output, its BN partial sums [nrep][2][C], nrep): handed from the conv
+# epilogue to the BatchNorm that consumes that output next (HipBackend.conv_bn_act)
+_PENDING_STATS = [None]
+
+
 def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real):
     """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)]."""
     B, H, W, Cin = geom_in
@@ -261,14 +302,13 @@ class Conv2dFn(torch.autograd.Function):
     """nn.Conv2d forward/backward (groups=1).  x NHWC bf16, weight OIHW fp32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, out_f32):
+    def forward(ctx, x, weight, bias, stride, pad, dil, out_f32, want_stats=False):
         x, ldx = _pixels(x)
         B, H, W, Cin = x.shape
         Cout, Cin_real, KH, KW = weight.shape
         assert Cin >= Cin_real and Cin % 8 == 0, (Cin, Cin_real)
         Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-        wp, Kpad = _packed_filter(weight, 0, Cin, 0)
         b = None
         if bias is not None:
             b = bias.detach()
@@ -276,8 +316,19 @@ class Conv2dFn(torch.autograd.Function):
                 b = b.float()
         if not out_f32:
             assert Cout % 8 == 0, "bf16 conv outputs need Cout % 8 == 0"
-        y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
-                   out_f32)
+        td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, out_f32)
+        if x.data_ptr() % 16 == 0 and tile_supported(td):
+            wp, _ = _packed_filter(weight, 2, Cin, 0)
+            stats = None
+            if want_stats:
+                stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
+            y = _tile_conv(td, x, wp, b, stats)
+            if want_stats:
+                _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
+        else:
+            wp, Kpad = _packed_filter(weight, 0, Cin, 0)
+            y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
+                       out_f32)
         ctx.save_for_backward(x, weight)
         ctx.meta = (ldx, stride, pad, dil, bias is not None, (Ho, Wo))
         return y
@@ -292,9 +343,15 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             assert Cin == Cin_real
-            wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
-            dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
-                        dil * (KH - 1) - pad, dil, stride > 1, False)
+            td = _tile_desc(B, Ho, Wo, cout_pad, lddy, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W,
+                            False)
+            if dyb.data_ptr() % 16 == 0 and tile_supported(td):
+                wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
+                dx = _tile_conv(td, dyb, wpt, None, None)
+            else:
+                wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
+                dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
+                            dil * (KH - 1) - pad, dil, stride > 1, False)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(x, ldx, (B, H, W, Cin), dyb, lddy, cout_pad, (Ho, Wo), (KH, KW), stride, pad, dil,
                         Cout, Cin_real)
@@ -306,7 +363,7 @@ class Conv2dFn(torch.autograd.Function):
             check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()),
                   "ssa_colsum_bf16")
             db = out[:Cout]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------
@@ -337,12 +394,16 @@ class BatchNormActFn(torch.autograd.Function):
         z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
         pst = post.float().contiguous() if post is not None else None
         if training:
-            sums = _ARENA.take(2 * C, dev)
-            check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), 0, _s()), "ssa_bn_stats")
+            pend, _PENDING_STATS[0] = _PENDING_STATS[0], None
+            if pend is not None and pend[0] == x.data_ptr() and pend[1].numel() >= pend[2] * 2 * C:
+                sums, nrep = pend[1], pend[2]          # accumulated by the producing conv's epilogue
+            else:
+                sums, nrep = _ARENA.take(2 * C, dev), 1
+                check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), 0, _s()), "ssa_bn_stats")
             if world:
                 from .parallel import allreduce_bn_sums
                 count = allreduce_bn_sums(sums, P)
-            check(L.ssa_bn_apply_train(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(sums), count, _p(g),
+            check(L.ssa_bn_apply_train(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(sums), nrep, count, _p(g),
                                        _p(bta), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
                                        float(eps), _p(coef), int(relu), _p(pst), H * W, _s()),
                   "ssa_bn_apply_train")

@@ -52,7 +52,10 @@ def BNReLU(ch):
 
 
 def conv_bn(conv, bn, x, residual=None, relu=False, post=None):
-    return bn(conv(x), residual=residual, relu=relu, post=post)
+    """conv -> norm (+ residual add, ReLU, Dropout2d mask) as one backend call, so
+    the backend may fuse the batch statistics into the conv epilogue."""
+    assert conv.groups == 1 and conv.padding_mode == "zeros"
+    return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post)
 
 
 def initialize_weights(*models):

@@ -28,8 +28,16 @@ class HipBackend:
     def image_to_nhwc(self, images, out_hw=None):
         return self.hb.image_to_nhwc(images, out_hw)
 
-    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False):
-        return self.hb.Conv2dFn.apply(x, weight, bias, stride, padding, dilation, out_f32)
+    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False, want_stats=False):
+        return self.hb.Conv2dFn.apply(x, weight, bias, stride, padding, dilation, out_f32, want_stats)
+
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+        """conv -> BatchNorm (+residual, ReLU, mask).  In training the conv epilogue
+        accumulates the batch statistics where the kernel supports it, and the
+        normalisation picks them up instead of re-reading the conv output."""
+        y = self.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], False,
+                        bool(bn.training))
+        return self.batch_norm_act(y, bn, residual, relu, post)
 
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
         return self.hb.BatchNormActFn.apply(

@@ -33,6 +33,10 @@ class OracleBackend:
         xin = _to_nchw(x)[:, :weight.shape[1]]
         return _to_nhwc(O.conv2d(xin, weight, bias, stride, padding, dilation))
 
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+        y = self.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0])
+        return self.batch_norm_act(y, bn, residual, relu, post)
+
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
         if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)

@@ -74,6 +74,13 @@ CONV_CASES = [
     (1, 16, 16, 384, 384, 3, 1, 1, 1, False, False),
     (1, 37, 29, 96, 96, 3, 1, 1, 1, False, False),
     (1, 19, 1, 512, 256, 1, 1, 0, 1, False, False),
+    # halo-tile kernel (conv_tile.hip): every (Cin, n-block, tile-width) dispatch class
+    (1, 70, 75, 64, 64, 3, 1, 1, 1, False, False),
+    (1, 130, 129, 48, 48, 3, 1, 1, 1, True, False),
+    (2, 20, 12, 48, 96, 3, 1, 1, 1, False, False),
+    (1, 9, 7, 96, 48, 3, 1, 1, 1, False, False),
+    (1, 33, 18, 64, 24, 3, 1, 1, 1, False, False),
+    (1, 128, 160, 96, 96, 3, 1, 1, 1, False, False),
 ]
 
 
@@ -144,6 +151,37 @@ def test_conv_all_tile_configs(cfg):
     y = hb._igemm(xd, Cin, (B, H, W, Cin), wp, Kpad, None, (H, W), Cout, (3, 3), 1, 1, 1, False, False, cfg=cfg)
     torch.cuda.synchronize()
     check_close("conv cfg%d" % cfg, nchw(y.float()), yr)
+
+
+@pytest.mark.parametrize("C,H,W", [(48, 50, 70), (96, 17, 33), (64, 128, 128)])
+def test_conv_bn_fused_stats(C, H, W):
+    """conv -> BN (training) with the batch statistics accumulated in the conv
+    epilogue (HipBackend.conv_bn_act) == oracle conv followed by batch_norm."""
+    from oracle import ops as O
+    from semseg_amd import ops, nn as snn
+    hb = _hb()
+    B = 2
+    x = _rand(B, C, H, W, seed=11)
+    conv = snn.Conv2d(C, C, 3, 1, 1, bias=False)
+    bn = snn.BatchNorm2d(C)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(C, C, 3, 3, seed=12, scale=0.05))
+        bn.weight.copy_(torch.rand(C) + 0.5)
+        bn.bias.copy_(torch.randn(C) * 0.1)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yr = O.conv2d(x, conv.weight.detach(), None, 1, 1, 1)
+    zr = torch.relu(O.batch_norm(bf16_round(yr), bn.weight.detach(), bn.bias.detach(), rm, rv, True, 0.1, 1e-5))
+    conv, bn = conv.to(DEV), bn.to(DEV).train()
+    hb.clear_pack_cache()
+    be = ops.HipBackend()
+    hb.begin_step(torch.device(DEV))
+    z = be.conv_bn_act(conv, bn, _to_dev_nhwc(x), relu=True)
+    torch.cuda.synchronize()
+    assert hb._PENDING_STATS[0] is None          # consumed by the normalisation
+    check_close("fused conv-bn", nchw(z.float()), zr, 2e-2, 6e-3)
+    check_close("fused running_mean", bn.running_mean, rm, 2e-3, 2e-3)
+    check_close("fused running_var", bn.running_var, rv, 2e-3, 2e-3)
+    assert int(bn.num_batches_tracked) == 1
 
 
 def test_batched_filter_repack():
