@@ -132,14 +132,29 @@ int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_su
  * (possibly all-reduced: SyncBN).  sums is [nrep][2][C]: nrep = 1 after
  * ssa_bn_stats, ssa_bn_stat_replicas() after a conv epilogue
  * (ssa_conv2d_tile) -- the replicas are summed here.  Writes coef = [scale|shift|mean|invstd] (4*C
- * fp32) for the backward pass, updates running_mean/var (momentum, unbiased
- * variance) and increments *num_batches_tracked (int64) when given.           */
+ * fp32) for the backward pass.  Running statistics: either updated here
+ * (running_mean/var + *num_batches_tracked given; momentum, unbiased variance)
+ * or deferred: pass_stats (2*C+1 fp32: mean, biased var, count) is filled and
+ * ssa_bn_update_running_batched applies every layer's passes in order later
+ * -- required when passes over the same layer run on concurrent streams.      */
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z,
                        int ldz, long P, int C, const double* sums, int nrep, double count,
                        const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long* num_batches_tracked, float momentum,
-                       float eps, float* coef, int relu, const float* post,
-                       long pix_per_img, void* stream);
+                       float eps, float* coef, float* pass_stats, int relu,
+                       const float* post, long pix_per_img, void* stream);
+typedef struct ssa_bn_update_job {
+  float* running_mean;
+  float* running_var;
+  long* num_batches_tracked;
+  const float* pass_stats[8];
+  int C, npass;
+  float momentum;
+  int pad_;
+} ssa_bn_update_job;
+/* jobs_dev: device array of ssa_bn_update_job; one launch for all layers.     */
+int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels,
+                                  void* stream);
 /* From (possibly all-reduced) sums and total count: scale/shift for the apply
  * pass, mean/invstd for backward, running-stat update (momentum, unbiased var).
  * use_running=1 (eval): scale/shift from running stats, sums ignored.          */

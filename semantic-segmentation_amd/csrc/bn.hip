@@ -158,7 +158,8 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
     double count, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
-    int relu, const float* __restrict__ post, long pix_per_img, long pix_per_block) {
+    float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
+    long pix_per_block) {
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -180,8 +181,13 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
       }
+      if (pass_stats) {
+        pass_stats[c] = (float)mean;
+        pass_stats[C + c] = (float)var;
+      }
     }
     if (t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (t == 0 && pass_stats) pass_stats[2 * C] = (float)count;
   }
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
@@ -368,6 +374,37 @@ __global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ ou
   if (i < n) out[i] = (float)in[i];
 }
 
+// Deferred running-statistics update: one launch for every BatchNorm layer of the
+// network, each layer's passes (the 0.5x and the 1.0x pass run on concurrent
+// streams) applied in issue order -- same result as the reference's sequential
+// in-place updates (momentum, unbiased variance), no race between the streams.
+struct BnUpdateJob {      // mirror of ssa_bn_update_job (include/semseg_hip.h), 96 bytes
+  float* running_mean;
+  float* running_var;
+  long* num_batches_tracked;
+  const float* pass_stats[8];   // each: mean[C], biased var[C], count
+  int C, npass;
+  float momentum;
+  int pad_;
+};
+
+__global__ __launch_bounds__(128) void bn_update_running_kernel(const BnUpdateJob* __restrict__ jobs) {
+  const BnUpdateJob j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  if (c == 0 && j.num_batches_tracked) *j.num_batches_tracked += j.npass;
+  if (c >= j.C) return;
+  double rm = j.running_mean[c], rv = j.running_var[c];
+  for (int p = 0; p < j.npass; ++p) {
+    const float* ps = j.pass_stats[p];
+    const double mean = ps[c], var = ps[j.C + c], count = ps[2 * j.C];
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rm = (float)((1.0 - j.momentum) * rm + j.momentum * mean);
+    rv = (float)((1.0 - j.momentum) * rv + j.momentum * unbiased);
+  }
+  j.running_mean[c] = (float)rm;
+  j.running_var[c] = (float)rv;
+}
+
 struct Grid { int blocks; long ppb; };
 // rows_per_thread pixel rows per thread; at most max_blocks workgroups (the
 // reducing kernels end in 2C fp64 atomics per workgroup, so they get a lower cap).
@@ -436,8 +473,9 @@ int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz,
                        long P, int C, const double* sums, int nrep, double count, const float* gamma,
                        const float* beta, float* running_mean, float* running_var,
-                       long* num_batches_tracked, float momentum, float eps, float* coef, int relu,
-                       const float* post, long pix_per_img, void* stream) {
+                       long* num_batches_tracked, float momentum, float eps, float* coef,
+                       float* pass_stats, int relu, const float* post, long pix_per_img,
+                       void* stream) {
   if (!x || !z || !sums || !coef || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
@@ -445,7 +483,16 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
   hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
                      sums, nrep, count, gamma, beta, running_mean, running_var, num_batches_tracked,
-                     momentum, eps, coef, relu, post, pix_per_img, g.ppb);
+                     momentum, eps, coef, pass_stats, relu, post, pix_per_img, g.ppb);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {
+  if (!jobs_dev || njobs < 1 || max_channels < 1) return SSA_EINVAL;
+  static_assert(sizeof(BnUpdateJob) == 104, "ssa_bn_update_job layout");
+  hipLaunchKernelGGL(bn_update_running_kernel, dim3((max_channels + 127) / 128, njobs), dim3(128), 0,
+                     (hipStream_t)stream, (const BnUpdateJob*)jobs_dev);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

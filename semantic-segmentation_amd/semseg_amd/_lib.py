@@ -21,6 +21,13 @@ class PackJob(ctypes.Structure):
         "Cout", "Cin", "KH", "KW", "cin_pad", "cout_pad", "Kpad", "mode", "rows", "pad_")]
 
 
+class BnUpdateJob(ctypes.Structure):
+    """Mirror of ssa_bn_update_job (104 bytes)."""
+    _fields_ = [("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
+                ("pass_stats", c_void_p * 8), ("C", c_int), ("npass", c_int), ("momentum", c_float),
+                ("pad_", c_int)]
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of ssa_conv_desc."""
     _fields_ = [(n, c_int) for n in (
@@ -44,7 +51,8 @@ _SIGS = {
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_int, c_double, _P, _P, _P, _P,
-                            _P, c_float, c_float, _P, c_int, _P, c_long, _P], c_int),
+                            _P, c_float, c_float, _P, _P, c_int, _P, c_long, _P], c_int),
+    "ssa_bn_update_running_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_pack_filters_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,
                          _P, _P, _P, _P, _P], c_int),

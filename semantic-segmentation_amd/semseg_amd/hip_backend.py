@@ -156,7 +156,7 @@ class _Arena:
 
     def reset(self, device):
         if self.buf is None or self.buf.device != device:
-            self.buf = torch.empty((1 << 20,), dtype=torch.float64, device=device)   # 8 MB
+            self.buf = torch.empty((1 << 22,), dtype=torch.float64, device=device)   # 32 MB
         self.buf.zero_()
         self.cur = 0
 
@@ -172,7 +172,67 @@ class _Arena:
 _ARENA = _Arena()
 
 
+# --------------------------------------------------------------------------
+# deferred BatchNorm running-statistics updates (see ssa_bn_update_running_batched)
+# --------------------------------------------------------------------------
+from ._lib import BnUpdateJob
+
+
+class _BnUpdates:
+    def __init__(self):
+        self.slots = {}       # id(bn) -> (bn, [persistent pass_stats tensors])
+        self.step = {}        # id(bn) -> passes issued in the current step (insertion ordered)
+        self.table_key = None
+        self.table = None
+        self.max_c = 1
+
+    def slot(self, bn):
+        """Persistent [2C+1] fp32 buffer for the next training pass over `bn` in this step."""
+        k = id(bn)
+        ent = self.slots.get(k)
+        if ent is None or ent[0] is not bn or ent[1][0].device != bn.running_mean.device:
+            ent = self.slots[k] = (bn, [])
+        n = self.step.get(k, 0)
+        assert n < 8, "more than 8 training passes over one BatchNorm layer in a step"
+        while len(ent[1]) <= n:
+            ent[1].append(torch.empty((2 * bn.num_features + 1,), dtype=torch.float32,
+                                      device=bn.running_mean.device))
+        self.step[k] = n + 1
+        return ent[1][n]
+
+    def flush(self):
+        if not self.step:
+            return
+        key = tuple(self.step.items())
+        if key != self.table_key:
+            jobs = []
+            for k, n in self.step.items():
+                bn, slots = self.slots[k]
+                ps = (ctypes.c_void_p * 8)(*[slots[i].data_ptr() for i in range(n)])
+                nbt = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
+                jobs.append(BnUpdateJob(bn.running_mean.data_ptr(), bn.running_var.data_ptr(), nbt, ps,
+                                        bn.num_features, n, 0.1 if bn.momentum is None else bn.momentum, 0))
+            arr = (BnUpdateJob * len(jobs))(*jobs)
+            dev = self.slots[next(iter(self.step))][0].running_mean.device
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.table_key = key
+            self.max_c = max(self.slots[k][0].num_features for k in self.step)
+        check(lib().ssa_bn_update_running_batched(_p(self.table), len(self.step), self.max_c, _s()),
+              "ssa_bn_update_running_batched")
+        self.step = {}
+
+
+_BN_UPDATES = _BnUpdates()
+
+
+def end_forward():
+    """Apply the running-statistics updates of every BatchNorm that ran in training
+    mode since begin_step (one launch, passes in issue order)."""
+    _BN_UPDATES.flush()
+
+
 def begin_step(device=None):
+    _BN_UPDATES.step = {}
     refresh_packed_filters()
     if device is not None:
         _ARENA.reset(device)
@@ -377,7 +437,7 @@ def _sync_world(sync):
 class BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, nbt, momentum, eps, training,
-                relu, sync):
+                relu, sync, pass_stats=None):
         L = lib()
         x, ldx = _pixels(x)
         B, H, W, C = x.shape
@@ -405,7 +465,7 @@ class BatchNormActFn(torch.autograd.Function):
                 count = allreduce_bn_sums(sums, P)
             check(L.ssa_bn_apply_train(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(sums), nrep, count, _p(g),
                                        _p(bta), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
-                                       float(eps), _p(coef), int(relu), _p(pst), H * W, _s()),
+                                       float(eps), _p(coef), _p(pass_stats), int(relu), _p(pst), H * W, _s()),
                   "ssa_bn_apply_train")
         else:
             check(L.ssa_bn_finalize(None, 1.0, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
@@ -453,7 +513,7 @@ class BatchNormActFn(torch.autograd.Function):
                                  _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale, _s()),
               "ssa_bn_bwd_apply")
         dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 
 class SumActFn(torch.autograd.Function):

@@ -123,7 +123,8 @@ class HighResolutionModule(nn.Module):
 
     def forward(self, xs):
         B = ops.backend()
-        xs = [self.branches[i](xs[i]) for i in range(self.num_branches)]
+        # the resolution branches are independent until the fuse layers
+        xs = B.parallel([(lambda i=i: self.branches[i](xs[i])) for i in range(self.num_branches)], level=2)
         if self.num_branches == 1:
             return xs
         outs = []

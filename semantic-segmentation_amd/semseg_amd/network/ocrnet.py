@@ -82,6 +82,7 @@ class OCRNet(_Base):
         cls_out, aux_out, _ = self.ocr(feats)
         aux_out = Upsample(aux_out, size)
         cls_out = Upsample(cls_out, size)
+        ops.backend().end_forward()
         if self.training:
             gts = inputs["gts"]
             aux_loss = self.criterion(_nchw(aux_out), gts, do_rmi=cfg.LOSS.OCR_AUX_RMI)
@@ -145,11 +146,18 @@ class MscaleOCR(_Base):
         """Training path: 0.5x and 1.0x passes fused by the 0.5x attention
         (network/ocrnet.py:264-327)."""
         B = ops.backend()
-        x_lo, lo_size = self._images(inputs, cfg.MODEL.MSCALE_LO_SCALE)
-        lo = self._fwd(x_lo, lo_size)
+
+        def lo_pass():
+            x_lo, lo_size = self._images(inputs, cfg.MODEL.MSCALE_LO_SCALE)
+            return self._fwd(x_lo, lo_size)
+
+        def hi_pass():
+            x_1x, size = self._images(inputs)
+            return self._fwd(x_1x, size), size
+
+        # the two scale passes share nothing but the weights: run them concurrently
+        (hi, size), lo = B.parallel([hi_pass, lo_pass])
         pred_05x, aux_lo, attn_05x = lo["cls_out"], lo["aux_out"], lo["logit_attn"]
-        x_1x, size = self._images(inputs)
-        hi = self._fwd(x_1x, size)
         pred_10x, aux_1x = hi["cls_out"], hi["aux_out"]
 
         p_lo = B.bilinear(B.bcast_mul(attn_05x, pred_05x), size)
@@ -175,8 +183,11 @@ class MscaleOCR(_Base):
     def forward(self, inputs):
         ops.backend().begin_step(inputs["images"].device)
         if cfg.MODEL.N_SCALES and not self.training:
-            return self.nscale_forward(inputs, cfg.MODEL.N_SCALES)
-        return self.two_scale_forward(inputs)
+            out = self.nscale_forward(inputs, cfg.MODEL.N_SCALES)
+        else:
+            out = self.two_scale_forward(inputs)
+        ops.backend().end_forward()       # deferred BN running-statistics updates
+        return out
 
 
 def HRNet(num_classes, criterion):

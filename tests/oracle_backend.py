@@ -22,6 +22,17 @@ class OracleBackend:
     def begin_step(self, device=None):
         pass
 
+    def end_forward(self):
+        pass
+
+    def parallel(self, thunks, level=1):
+        # issue order of HipBackend.parallel: thunks[1:] first, thunks[0] last
+        outs = [None] * len(thunks)
+        for i in range(1, len(thunks)):
+            outs[i] = thunks[i]()
+        outs[0] = thunks[0]()
+        return outs
+
     def image_to_nhwc(self, images, out_hw=None):
         x = images if images.dtype == torch.float64 else images.float()
         if out_hw is not None and tuple(out_hw) != tuple(x.shape[2:]):

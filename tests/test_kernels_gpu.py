@@ -176,6 +176,7 @@ def test_conv_bn_fused_stats(C, H, W):
     be = ops.HipBackend()
     hb.begin_step(torch.device(DEV))
     z = be.conv_bn_act(conv, bn, _to_dev_nhwc(x), relu=True)
+    be.end_forward()
     torch.cuda.synchronize()
     assert hb._PENDING_STATS[0] is None          # consumed by the normalisation
     check_close("fused conv-bn", nchw(z.float()), zr, 2e-2, 6e-3)
@@ -259,7 +260,7 @@ def test_bn_train(C, relu, res, post):
     rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     pmd = pm.to(DEV) if post else None
     nbt = torch.zeros((), dtype=torch.long, device=DEV)
-    z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, nbt, 0.1, 1e-5, True, relu, False)
+    z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, nbt, 0.1, 1e-5, True, relu, False, None)
     z.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
     torch.cuda.synchronize()
     check_close("bn_fwd", nchw(z.float()), y)
@@ -271,6 +272,40 @@ def test_bn_train(C, relu, res, post):
     check_close("bn_dbeta", bd.grad, br.grad, 1e-2, 4e-3)
     if res:
         check_close("bn_dres", nchw(rd.grad.float()), rr.grad)
+
+
+def test_bn_deferred_running_stats_two_passes():
+    """Two training passes over one BatchNorm layer (the 0.5x / 1.0x passes run on
+    concurrent streams): the deferred batched update must equal the reference's
+    sequential in-place updates, in issue order."""
+    from oracle import ops as O
+    from semseg_amd import ops, nn as snn
+    hb = _hb()
+    C = 48
+    bn = snn.BatchNorm2d(C, momentum=0.1)
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    with torch.no_grad():
+        bn.running_mean.copy_(rm)
+        bn.running_var.copy_(rv)
+    xa, xb = _rand(1, C, 12, 20, seed=21), _rand(2, C, 24, 40, seed=22) * 2.0 + 0.5
+    one = torch.ones(C)
+    zero = torch.zeros(C)
+    O.batch_norm(xa, one, zero, rm, rv, True, 0.1, 1e-5)
+    O.batch_norm(xb, one, zero, rm, rv, True, 0.1, 1e-5)
+    bn = bn.to(DEV).train()
+    be = ops.HipBackend()
+    hb.begin_step(torch.device(DEV))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        be.batch_norm_act(_to_dev_nhwc(xa), bn)
+    be.batch_norm_act(_to_dev_nhwc(xb), bn)
+    torch.cuda.current_stream().wait_stream(side)
+    be.end_forward()
+    torch.cuda.synchronize()
+    check_close("deferred running_mean", bn.running_mean, rm, 1e-4, 1e-4)
+    check_close("deferred running_var", bn.running_var, rv, 1e-4, 1e-4)
+    assert int(bn.num_batches_tracked) == 2
 
 
 def test_bn_eval():
