@@ -31,7 +31,9 @@ FLOP_FWD_BWD_PER_IMAGE = 5.7274e12
 PEAK_BF16_MFMA = 2.5e15          # dense, MI355X_MICROARCH.md
 TILE_NAMES = {0: "conv_igemm_kernel<2,2,2,2> (128x128)", 1: "conv_igemm_kernel<4,1,2,2> (256x64)",
               2: "conv_igemm_kernel<4,1,1,3> (128x96)", 3: "conv_igemm_kernel<4,1,2,1> (256x32)",
-              4: "conv_igemm_kernel<2,2,1,1> (64x64)", 5: "conv_igemm_kernel<2,2,2,1> (128x64)"}
+              4: "conv_igemm_kernel<2,2,1,1> (64x64)", 5: "conv_igemm_kernel<2,2,2,1> (128x64)",
+              100: "conv_tile_kernel (halo tile, 128/256 px x Cout)",
+              101: "conv_halo_gemm_kernel (256 px x 128 ch, halo chunks)", -1: "conv_wgrad_tr_kernel"}
 
 
 def synth_batch(B, H, W, rank, device):
@@ -221,13 +223,16 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        from semseg_amd import hip_backend as hb
+        from semseg_amd import hip_backend as hb, ops as sops
         store = []
+        be = sops.backend()
+        saved_conc, be.concurrency = be.concurrency, 0   # one stream: a launch's events bracket only that launch
         hb.set_profile(store)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         hb.set_profile(None)
+        be.concurrency = saved_conc
         agg = {}
         for kind, tile, flops, e0, e1, shape in store:
             key = (kind, tile)
@@ -238,7 +243,7 @@ def main():
         tot_t = sum(a[1] for a in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])      # most time
         (kind, tile), (fl, tt, n) = dom
-        name = TILE_NAMES.get(tile, "conv_wgrad_kernel") if kind == "igemm" else "conv_wgrad_kernel"
+        name = TILE_NAMES.get(tile, kind)
         roof = {"bound": "mfma", "kernel": name, "achieved": fl / tt / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
                 "unit": "TFLOP/s", "frac": fl / tt / PEAK_BF16_MFMA, "traffic": None,
                 "launches_per_step": n // 2, "avg_launch_us": tt / n * 1e6,

@@ -72,6 +72,16 @@ int ssa_conv2d_tile(const ssa_conv_desc* d, const void* x, const void* w_frag,
                     const float* bias, void* y, double* stats, void* stream);
 int ssa_bn_stat_replicas(void);
 
+/* Halo-chunk implicit GEMM for the large-channel 3x3 / 1x1 stride-1 "same" convs
+ * of the OCR and attention heads (Cin >= 192, Cin % 48 == 0 or % 64 == 0):
+ * 256-pixel x 128-channel workgroup tiles, the input halo tile of each 48/64
+ * channel chunk staged in LDS once for all 9 taps, the filter (fragment order,
+ * ssa_pack_filter mode 2/3) streamed by global_load_lds.  bf16 or fp32 output;
+ * stats as for ssa_conv2d_tile (bf16 output only).                             */
+int ssa_conv2d_halo_supported(const ssa_conv_desc* d);
+int ssa_conv2d_halo(const ssa_conv_desc* d, const void* x, const void* w_frag,
+                    const float* bias, void* y, double* stats, void* stream);
+
 /* Tile configuration ssa_conv2d_igemm would use for this problem
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);

@@ -43,6 +43,8 @@ _SIGS = {
     "ssa_conv2d_tile_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_tile": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_bn_stat_replicas": ([], c_int),
+    "ssa_conv2d_halo_supported": ([POINTER(ConvDesc)], c_int),
+    "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
     "ssa_conv2d_wgrad_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),

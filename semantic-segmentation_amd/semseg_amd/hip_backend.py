@@ -295,17 +295,25 @@ def stat_replicas():
     return _STAT_REPLICAS
 
 
-def _tile_conv(d, x, wfrag, bias, stats):
-    """Halo-tile conv launch (small-channel 3x3 stride-1 convs and their data gradients)."""
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=ACT_DTYPE, device=x.device)
+def halo_supported(d):
+    return bool(lib().ssa_conv2d_halo_supported(ctypes.byref(d)))
+
+
+def _tile_conv(d, x, wfrag, bias, stats, halo=False):
+    """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs) or
+    conv_halo_gemm.hip (large-channel 3x3 / 1x1 convs), and their data gradients."""
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
+                    device=x.device)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().ssa_conv2d_tile(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()),
-          "ssa_conv2d_tile")
+    fn = lib().ssa_conv2d_halo if halo else lib().ssa_conv2d_tile
+    check(fn(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()),
+          "ssa_conv2d_halo" if halo else "ssa_conv2d_tile")
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("tile", 100, 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW, e0, e1,
+        _PROFILE.append(("halo" if halo else "tile", 101 if halo else 100,
+                         2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW, e0, e1,
                          (d.KH, 1, d.Cin, d.Cout, d.Ho, d.Wo)))
     return y
 
@@ -377,13 +385,15 @@ class Conv2dFn(torch.autograd.Function):
         if not out_f32:
             assert Cout % 8 == 0, "bf16 conv outputs need Cout % 8 == 0"
         td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, out_f32)
-        if x.data_ptr() % 16 == 0 and tile_supported(td):
+        use_tile = x.data_ptr() % 16 == 0 and tile_supported(td)
+        use_halo = (not use_tile) and x.data_ptr() % 16 == 0 and halo_supported(td)
+        if use_tile or use_halo:
             wp, _ = _packed_filter(weight, 2, Cin, 0)
             stats = None
-            if want_stats:
+            if want_stats and not out_f32:
                 stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-            y = _tile_conv(td, x, wp, b, stats)
-            if want_stats:
+            y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
+            if stats is not None:
                 _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
         else:
             wp, Kpad = _packed_filter(weight, 0, Cin, 0)
@@ -405,9 +415,11 @@ class Conv2dFn(torch.autograd.Function):
             assert Cin == Cin_real
             td = _tile_desc(B, Ho, Wo, cout_pad, lddy, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W,
                             False)
-            if dyb.data_ptr() % 16 == 0 and tile_supported(td):
+            use_tile = dyb.data_ptr() % 16 == 0 and tile_supported(td)
+            use_halo = (not use_tile) and dyb.data_ptr() % 16 == 0 and halo_supported(td)
+            if use_tile or use_halo:
                 wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
-                dx = _tile_conv(td, dyb, wpt, None, None)
+                dx = _tile_conv(td, dyb, wpt, None, None, halo=use_halo)
             else:
                 wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
                 dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,

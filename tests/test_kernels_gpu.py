@@ -81,6 +81,11 @@ CONV_CASES = [
     (1, 9, 7, 96, 48, 3, 1, 1, 1, False, False),
     (1, 33, 18, 64, 24, 3, 1, 1, 1, False, False),
     (1, 128, 160, 96, 96, 3, 1, 1, 1, False, False),
+    # halo-chunk GEMM (conv_halo_gemm.hip): CK 48 / 64, 3x3 / 1x1, ragged tiles, partial n-blocks
+    (1, 130, 131, 192, 200, 3, 1, 1, 1, True, False),
+    (1, 128, 129, 240, 128, 3, 1, 1, 1, False, False),
+    (2, 96, 100, 256, 72, 1, 1, 0, 1, False, False),
+    (1, 140, 128, 336, 64, 1, 1, 0, 1, True, False),
 ]
 
 
@@ -153,7 +158,7 @@ def test_conv_all_tile_configs(cfg):
     check_close("conv cfg%d" % cfg, nchw(y.float()), yr)
 
 
-@pytest.mark.parametrize("C,H,W", [(48, 50, 70), (96, 17, 33), (64, 128, 128)])
+@pytest.mark.parametrize("C,H,W", [(48, 50, 70), (96, 17, 33), (64, 128, 128), (192, 96, 96)])
 def test_conv_bn_fused_stats(C, H, W):
     """conv -> BN (training) with the batch statistics accumulated in the conv
     epilogue (HipBackend.conv_bn_act) == oracle conv followed by batch_norm."""

@@ -168,6 +168,13 @@ int main(int argc, char** argv) {
       }
       printf("%-22s %-14s stats worst rel err %.3g%s\n", c.name, "tile+stats", worst, worst > 1e-3 ? "  <-- MISMATCH" : "");
     }
+    if (ssa_conv2d_halo_supported(&d)) {
+      if (ssa_pack_filter(dw, dwp, c.Cout, c.Cin, c.K, c.K, c.Cin, 0, Kflat, 2, st)) { printf("pack2 failed\n"); return 1; }
+      CK(hipMemsetAsync(dy, 0, Pout * c.Cout * 2, st));
+      int rc = 0;
+      float us = timeit([&] { rc |= ssa_conv2d_halo(&d, dx, dwp, nullptr, dy, nullptr, st); });
+      if (rc) printf("%-22s halo failed rc=%d\n", c.name, rc); else check("halo", us);
+    }
     CK(hipFree(dx)); CK(hipFree(dy)); CK(hipFree(dw)); CK(hipFree(dref)); CK(hipFree(derr)); CK(hipFree(dwp)); CK(hipFree(dstats));
   }
   return 0;
