@@ -240,6 +240,17 @@ def main():
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+        if os.environ.get("SSA_DUMP_SHAPES"):
+            per = {}
+            for kind, tile, flops, e0, e1, shape in store:
+                a = per.setdefault((kind, tile) + tuple(shape), [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += 1
+            for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:60]:
+                print("SHAPE %-6s tile %4d k%d s%d cin %4d cout %4d out %4dx%-4d  n/step %3d  avg %7.1f us  %6.1f TF/s  %.3f ms/step"
+                      % (k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], v[2] // 2, v[1] / v[2] * 1e6,
+                         v[0] / v[1] / 1e12, v[1] / 2 * 1e3), file=sys.stderr)
         tot_t = sum(a[1] for a in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])      # most time
         (kind, tile), (fl, tt, n) = dom

@@ -1,6 +1,6 @@
 // Halo-tile convolution for the small-channel HRNet branches (gfx950 / MI355X).
 //
-// The 48/64/96-channel 3x3 convs of the HRNetV2 trunk (network/hrnetv2.py:31-66,
+// The 48/64/96/192/384-channel 3x3 convs of the HRNetV2 trunk (network/hrnetv2.py:31-66,
 // SURVEY.md K1; 24 % of the step's FLOPs, 1,046 launches per training step) are
 // HBM/latency bound: K = 9*Cin is only 432..864, so a K-pipelined implicit GEMM
 // spends its time in 14..27 dependent global->LDS stages.  Here one workgroup
@@ -28,22 +28,25 @@ namespace {
 
 constexpr int kStatReplicas = 8;   // BN partial sums are spread over 8 replicas (atomic contention)
 
-// Filter chunk c (TPC taps) of the NB n-blocks -> LDS buffer, as direct
-// global->LDS DMA: one global_load_lds_dwordx4 per wave moves one 1-KiB
-// (n-block, k-step) fragment block; the LDS image is lane-linear, which is
+// Filter stage (channel chunk cc, taps [tap0, tap0+TPC)) of the NB n-blocks -> LDS
+// buffer, as direct global->LDS DMA: one global_load_lds_dwordx4 per wave moves one
+// 1-KiB (n-block, k-step) fragment block; the LDS image is lane-linear, which is
 // exactly the order ds_read_b128 wants the B fragment in.
-template <int NB, int KSTEPS, int CHUNK_KS>
+template <int NB, int TPC, int CST>
 __device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfrag, int nb0,
-                                                   int nb_total, int chunk, unsigned char* dst,
-                                                   int wave, int lane) {
-  constexpr int NFRAG = NB * CHUNK_KS;
+                                                   int nb_total, int ksteps_total, int csteps_total,
+                                                   int cc, int tap0, unsigned char* dst, int wave,
+                                                   int lane) {
+  constexpr int PER_NB = TPC * CST;
+  constexpr int NFRAG = NB * PER_NB;
 #pragma unroll
   for (int f = 0; f < (NFRAG + 3) / 4; ++f) {
     const int fi = f * 4 + wave;               // wave-uniform
     if (fi < NFRAG) {
-      const int nb = fi / CHUNK_KS, ksl = fi - nb * CHUNK_KS;
+      const int nb = fi / PER_NB, rem = fi - nb * PER_NB;
+      const int tl = rem / CST, j = rem - tl * CST;
       const int nbg = min(nb0 + nb, nb_total - 1);   // n-blocks past the end re-read the last one (never stored)
-      const uint4* src = wfrag + ((long)nbg * KSTEPS + chunk * CHUNK_KS + ksl) * 64 + lane;
+      const uint4* src = wfrag + ((long)nbg * ksteps_total + (tap0 + tl) * csteps_total + cc * CST + j) * 64 + lane;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(dst + (size_t)fi * 1024), 16, 0, 0);
@@ -51,26 +54,27 @@ __device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfr
   }
 }
 
-template <int CIN, int KS, int NB, int MI, int TW, int TPC>
+// CK: input channels staged per halo image (= Cin for 48/64/96; 192 for Cin = 192/384,
+// which run Cin/CK passes over the taps), TPC: taps per filter stage.
+template <int CK, int KS, int NB, int MI, int TW, int TPC>
 __global__ __launch_bounds__(256) void conv_tile_kernel(
-    const bf16_t* __restrict__ x, int ldx, const uint4* __restrict__ wfrag,
+    const bf16_t* __restrict__ x, int ldx, int Cin, const uint4* __restrict__ wfrag,
     const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
     int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats) {
   constexpr int R = KS / 2;
   constexpr int BM = 4 * MI * 32;              // output pixels per workgroup
   constexpr int TH = BM / TW;                  // tile rows
   constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
-  constexpr int PSB = CIN * 2 + 16;            // halo pixel stride in bytes
-  constexpr int CP = CIN / 8;                  // 16-byte pieces per pixel
+  constexpr int PSB = CK * 2 + 16;             // halo pixel stride in bytes
+  constexpr int CP = CK / 8;                   // 16-byte pieces per pixel
   constexpr int NPIECE = HH_ * HW_ * CP;
-  constexpr int CSTEPS = CIN / 16;
+  constexpr int CST = CK / 16;                 // c-steps per halo chunk
   constexpr int TAPS = KS * KS;
-  constexpr int KSTEPS = TAPS * CSTEPS;
-  constexpr int NCHUNK = TAPS / TPC;
-  static_assert(NCHUNK * TPC == TAPS, "taps per chunk must divide the tap count");
-  constexpr int CHUNK_KS = TPC * CSTEPS;       // k-steps per filter chunk
-  constexpr int CHUNK_BYTES = NB * CHUNK_KS * 1024;
-  constexpr int NBUF = NCHUNK > 1 ? 2 : 1;
+  constexpr int NSTAGE = TAPS / TPC;           // filter stages per channel chunk
+  static_assert(NSTAGE * TPC == TAPS, "taps per stage must divide the tap count");
+  constexpr int STAGE_KS = TPC * CST;          // k-steps per filter stage
+  constexpr int STAGE_BYTES = NB * STAGE_KS * 1024;
+  constexpr int NBUF = NSTAGE > 1 ? 2 : 1;
   constexpr int HALO_BYTES = (HH_ * HW_ * PSB + 1023) / 1024 * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Bs = smem + HALO_BYTES;
@@ -83,30 +87,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
   const int b = bid;
   const int nb0 = blockIdx.y * NB;
   const int x0 = tx_i * TW, y0 = ty_i * TH;
-
-  // ---- halo tile -> registers, filter chunk 0 -> LDS (DMA), halo -> LDS: one burst
-  {
-    const bf16_t* xb = x + (long)b * H * W * ldx;
-    constexpr int IT = (NPIECE + 255) / 256;
-    uint4 v[IT];
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int piece = tid + i * 256;
-      const int pix = piece / CP, cp = piece - pix * CP;
-      const int hy = pix / HW_, hx = pix - hy * HW_;
-      const int iy = y0 - R + hy, ix = x0 - R + hx;
-      const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      v[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cp * 8)
-                : make_uint4(0, 0, 0, 0);
-    }
-    stage_filter_chunk<NB, KSTEPS, CHUNK_KS>(wfrag, nb0, nb_total, 0, Bs, wave, lane);
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int piece = tid + i * 256;
-      const int pix = piece / CP, cp = piece - pix * CP;
-      if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
-    }
-  }
+  const int nchunk = Cin / CK;
+  const int csteps_total = Cin / 16;
+  const int ksteps_total = TAPS * csteps_total;
 
   // ---- per-lane A addressing: MFMA row block mi of this wave -> tile pixels
   int a_off[MI];
@@ -125,31 +108,57 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
 
-  __syncthreads();                              // halo + filter chunk 0 landed (vmcnt(0) + barrier)
-
+  const bf16_t* xb = x + (long)b * H * W * ldx;
+  for (int cc = 0; cc < nchunk; ++cc) {
+    if (cc > 0) __syncthreads();                // previous chunk's halo image and filter buffers are free
+    // ---- halo tile -> registers, filter stage 0 -> LDS (DMA), halo -> LDS: one burst
+    {
+      constexpr int IT = (NPIECE + 255) / 256;
+      uint4 v[IT];
 #pragma unroll
-  for (int ch = 0; ch < NCHUNK; ++ch) {
-    if (ch + 1 < NCHUNK)
-      stage_filter_chunk<NB, KSTEPS, CHUNK_KS>(wfrag, nb0, nb_total, ch + 1,
-                                               Bs + ((ch + 1) % NBUF) * CHUNK_BYTES, wave, lane);
-    const unsigned char* Bc = Bs + (ch % NBUF) * CHUNK_BYTES + lane * 16;
+      for (int i = 0; i < IT; ++i) {
+        const int piece = tid + i * 256;
+        const int pix = piece / CP, cp = piece - pix * CP;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int iy = y0 - R + hy, ix = x0 - R + hx;
+        const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        v[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cc * CK + cp * 8)
+                  : make_uint4(0, 0, 0, 0);
+      }
+      stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, 0, Bs, wave, lane);
 #pragma unroll
-    for (int ksl = 0; ksl < CHUNK_KS; ++ksl) {
-      const int tap = ch * TPC + ksl / CSTEPS, cs = ksl % CSTEPS;
-      const int kh = tap / KS, kw = tap - kh * KS;
-      bf16x8_t af[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        af[mi] = *reinterpret_cast<const bf16x8_t*>(smem + a_off[mi] + (kh * HW_ + kw) * PSB + cs * 32);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * CHUNK_KS + ksl) * 1024);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][nb], 0, 0, 0);
+      for (int i = 0; i < IT; ++i) {
+        const int piece = tid + i * 256;
+        const int pix = piece / CP, cp = piece - pix * CP;
+        if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
       }
     }
-    if (ch + 1 < NCHUNK) __syncthreads();       // next chunk landed; this buffer is free for chunk ch+2
+    __syncthreads();                            // halo + filter stage 0 landed (vmcnt(0) + barrier)
+
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+      if (st + 1 < NSTAGE)
+        stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, (st + 1) * TPC,
+                                         Bs + ((st + 1) % NBUF) * STAGE_BYTES, wave, lane);
+      const unsigned char* Bc = Bs + (st % NBUF) * STAGE_BYTES + lane * 16;
+#pragma unroll
+      for (int ksl = 0; ksl < STAGE_KS; ++ksl) {
+        const int tap = st * TPC + ksl / CST, cs = ksl % CST;
+        const int kh = tap / KS, kw = tap - kh * KS;
+        bf16x8_t af[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *reinterpret_cast<const bf16x8_t*>(smem + a_off[mi] + (kh * HW_ + kw) * PSB + cs * 32);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * STAGE_KS + ksl) * 1024);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][nb], 0, 0, 0);
+        }
+      }
+      if (st + 1 < NSTAGE) __syncthreads();     // next stage landed; this buffer is free for stage st+2
+    }
   }
 
   // ---- epilogue: (+bias) -> bf16 -> LDS -> coalesced 16-byte stores; BN statistics
@@ -218,19 +227,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
   }
 }
 
-template <int CIN, int KS, int NB, int MI, int TW, int TPC>
+template <int CK, int KS, int NB, int MI, int TW, int TPC>
 int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
                 double* stats, hipStream_t s) {
   constexpr int R = KS / 2, BM = 4 * MI * 32, TH = BM / TW;
-  constexpr int NCHUNK = KS * KS / TPC;
-  constexpr size_t halo = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (CIN * 2 + 16) + 1023) / 1024 * 1024;
-  constexpr size_t filt = (size_t)(NCHUNK > 1 ? 2 : 1) * NB * TPC * (CIN / 16) * 1024;
+  constexpr int NSTAGE = KS * KS / TPC;
+  constexpr size_t halo = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (CK * 2 + 16) + 1023) / 1024 * 1024;
+  constexpr size_t filt = (size_t)(NSTAGE > 1 ? 2 : 1) * NB * TPC * (CK / 16) * 1024;
   constexpr size_t stage = (size_t)BM * (NB * 32 + 8) * 2 + 4 * 2 * NB * 32 * sizeof(float);
   constexpr size_t lds = halo + filt > stage ? halo + filt : stage;
   static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
   const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
   const int nb_total = (d.Cout + 31) / 32;
-  auto kern = conv_tile_kernel<CIN, KS, NB, MI, TW, TPC>;
+  auto kern = conv_tile_kernel<CK, KS, NB, MI, TW, TPC>;
   if (lds > 64 * 1024) {
     static bool once = false;                  // per template instantiation
     if (!once) {
@@ -240,7 +249,7 @@ int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const 
     }
   }
   hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * d.B, (nb_total + NB - 1) / NB), dim3(256), lds, s,
-                     (const bf16_t*)x, d.ldx, (const uint4*)wfrag, bias, (bf16_t*)y, d.ldy, d.B, d.H,
+                     (const bf16_t*)x, d.ldx, d.Cin, (const uint4*)wfrag, bias, (bf16_t*)y, d.ldy, d.B, d.H,
                      d.W, d.Cout, nb_total, tiles_x, tiles_y, stats);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
@@ -248,17 +257,20 @@ int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const 
 
 // tile shape by image width: TW = 32 where the image is at least 32 wide.
 // big: two MFMA row blocks per wave (256 pixels per workgroup) where LDS allows.
-template <int CIN, int KS, int NB, int TPC, bool BIG_OK>
+template <int CK, int KS, int NB, int TPC, bool BIG_OK, bool NARROW_OK = true>
 int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
                   double* stats, hipStream_t s, bool want_big) {
-  if (d.W >= 32) {
+  if (d.W >= 32 || !NARROW_OK) {
     if constexpr (BIG_OK) {
-      if (want_big) return launch_tile<CIN, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s);
+      if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s);
     }
-    return launch_tile<CIN, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s);
+    return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s);
   }
-  if (d.W >= 16) return launch_tile<CIN, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s);
-  return launch_tile<CIN, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s);
+  if constexpr (NARROW_OK) {
+    if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s);
+    return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s);
+  }
+  return SSA_EUNSUPPORTED;
 }
 
 }  // namespace
@@ -271,7 +283,7 @@ int ssa_conv2d_tile_supported(const ssa_conv_desc* d) {
   if (d->stride != 1 || d->dil != 1 || d->transposed || d->pad != d->KH / 2) return 0;
   if (d->Ho != d->H || d->Wo != d->W || d->out_f32) return 0;
   if (d->Cout % 8 || d->ldy % 8 || d->ldx % 8) return 0;
-  return d->Cin == 48 || d->Cin == 64 || d->Cin == 96;
+  return d->Cin == 48 || d->Cin == 64 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
 }
 
 int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
@@ -283,8 +295,13 @@ int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   const ssa_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   const int nbt = (d.Cout + 31) / 32;
-  // cfg (benchmark knob): bit 0 = force the 128-pixel tile, bit 1 = one n-block per workgroup
-  const int cfg = d.cfg < 0 ? 0 : d.cfg;
+  // Measured on MI355X (tools/convbench, gpurun_out/convbench*.log): these layers are
+  // latency bound, more and smaller workgroups win everywhere -- 128-pixel tiles and one
+  // n-block per workgroup (2-3 workgroups per CU) -- except the 48-channel layers at
+  // >= 512 tiles, where both n-blocks in one workgroup save the second halo read.
+  // cfg >= 0 (benchmark knob): bit 0 = 128-pixel tile, bit 1 = one n-block per workgroup.
+  const long tiles128 = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
+  const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && tiles128 >= 512) ? 0 : 2)) : d.cfg;
   const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
   const bool split_n = (cfg & 2) != 0;
   switch (d.Cin) {
@@ -299,6 +316,10 @@ int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
       if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big);
       if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big);
       return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big);
+    case 192:
+    case 384:      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
+      if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big);
+      return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big);
     default: return SSA_EUNSUPPORTED;
   }
 }

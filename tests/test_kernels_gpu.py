@@ -81,6 +81,9 @@ CONV_CASES = [
     (1, 9, 7, 96, 48, 3, 1, 1, 1, False, False),
     (1, 33, 18, 64, 24, 3, 1, 1, 1, False, False),
     (1, 128, 160, 96, 96, 3, 1, 1, 1, False, False),
+    (1, 33, 30, 192, 96, 3, 1, 1, 1, False, False),
+    (2, 20, 12, 384, 200, 3, 1, 1, 1, True, False),
+    (1, 64, 64, 192, 192, 3, 1, 1, 1, False, False),
     # halo-chunk GEMM (conv_halo_gemm.hip): CK 48 / 64, 3x3 / 1x1, ragged tiles, partial n-blocks
     (1, 130, 131, 192, 200, 3, 1, 1, 1, True, False),
     (1, 128, 129, 240, 128, 3, 1, 1, 1, False, False),
