@@ -23,7 +23,8 @@ __host__ __device__ inline int active_threads(int VC) { return (NT / VC) * VC; }
 // Accumulate per-channel sums for this block into fp64 global sums.
 // v0/v1 hold 8 channels each (this thread's channel group cg).
 __device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v1, int cg, int C,
-                                                 bool active, double* gsums, float* sh) {
+                                                 bool active, double* gsums, float* sh, int nrep = 1) {
+  gsums += (long)(blockIdx.x % nrep) * 2 * C;   // [nrep][2][C]: spread the same-address atomics
   // sh: [2*C] floats
   for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
   __syncthreads();
@@ -160,20 +161,25 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
     long pix_per_block) {
+  extern __shared__ float sh[];                 // [2C]: scale, shift for this launch
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
-  if (blockIdx.x == 0) {
-    for (int c = t; c < C; c += NT) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
-      const double mean = s1 / count;
-      double var = s2 / count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const double invstd = 1.0 / sqrt(var + (double)eps);
-      const double g = gamma ? (double)gamma[c] : 1.0;
-      const double b = beta ? (double)beta[c] : 0.0;
-      coef[c] = (float)(g * invstd);
-      coef[C + c] = (float)(b - mean * g * invstd);
+  // every workgroup derives the per-channel coefficients once (thread c -> channel c)
+  for (int c = t; c < C; c += NT) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    const double b = beta ? (double)beta[c] : 0.0;
+    const float sc = (float)(g * invstd), sf = (float)(b - mean * g * invstd);
+    sh[c] = sc;
+    sh[C + c] = sf;
+    if (blockIdx.x == 0) {
+      coef[c] = sc;
+      coef[C + c] = sf;
       coef[2 * C + c] = (float)mean;
       coef[3 * C + c] = (float)invstd;
       if (running_mean) {
@@ -186,26 +192,17 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
         pass_stats[C + c] = (float)var;
       }
     }
-    if (t == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (t == 0 && pass_stats) pass_stats[2 * C] = (float)count;
   }
+  if (blockIdx.x == 0 && t == 0) {
+    if (num_batches_tracked) *num_batches_tracked += 1;
+    if (pass_stats) pass_stats[2 * C] = (float)count;
+  }
+  __syncthreads();
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
   float a[8], b[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = cg * 8 + j;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma ? (double)gamma[c] : 1.0;
-    const double bb = beta ? (double)beta[c] : 0.0;
-    a[j] = (float)(g * invstd);
-    b[j] = (float)(bb - mean * g * invstd);
-  }
+  for (int j = 0; j < 8; ++j) { a[j] = sh[cg * 8 + j]; b[j] = sh[C + cg * 8 + j]; }
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
 #pragma unroll 4
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
     const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
-    double* __restrict__ sums, long pix_per_block) {
+    double* __restrict__ sums, int nrep, long pix_per_block) {
   extern __shared__ float sh[];
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
       }
     }
   }
-  block_reduce_2x8(sg, sgx, cg, C, active, sums, sh);
+  block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, nrep);
 }
 
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
@@ -284,28 +281,38 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
     bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    const double* __restrict__ sums, double count, int relu, const float* __restrict__ post,
-    long pix_per_img, long pix_per_block, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float param_grad_scale) {
+    const double* __restrict__ sums, int nrep, double count, int relu,
+    const float* __restrict__ post, long pix_per_img, long pix_per_block,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale) {
+  extern __shared__ float sh[];                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
-  if (blockIdx.x == 0 && (dgamma || dbeta)) {
-    for (int c = t; c < C; c += NT) {
-      if (dbeta) dbeta[c] = (float)(sums[c] * param_grad_scale);
-      if (dgamma) dgamma[c] = (float)(sums[C + c] * param_grad_scale);
+  for (int c = t; c < C; c += NT) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+    const float is_ = invstd[c];
+    sh[c] = mean[c];
+    sh[C + c] = is_;
+    sh[2 * C + c] = (gamma ? gamma[c] : 1.f) * is_;
+    sh[3 * C + c] = (float)(s1 / count);
+    sh[4 * C + c] = (float)(s2 / count);
+    if (blockIdx.x == 0) {
+      if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
+      if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
     }
   }
+  __syncthreads();
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
   float mu[8], is[8], a[8], c1[8], c2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    mu[j] = mean[c];
-    is[j] = invstd[c];
-    a[j] = (gamma ? gamma[c] : 1.f) * is[j];
-    c1[j] = (float)(sums[c] / count);
-    c2[j] = (float)(sums[C + c] / count);
+    mu[j] = sh[c];
+    is[j] = sh[C + c];
+    a[j] = sh[2 * C + c];
+    c1[j] = sh[3 * C + c];
+    c2[j] = sh[4 * C + c];
   }
   const long p0 = blockIdx.x * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
@@ -480,7 +487,7 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
-  hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
                      sums, nrep, count, gamma, beta, running_mean, running_var, num_batches_tracked,
                      momentum, eps, coef, pass_stats, relu, post, pix_per_img, g.ppb);
@@ -499,34 +506,35 @@ int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_chann
 
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                       long P, int C, const float* mean, const float* invstd, int relu,
-                      const float* post, long pix_per_img, double* sums, int zero_sums,
+                      const float* post, long pix_per_img, double* sums, int nrep, int zero_sums,
                       void* stream) {
-  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
+  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z) || nrep < 1) return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (zero_sums) {
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * nrep, s);
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
-                     mean, invstd, relu, post, pix_per_img, sums, g.ppb);
+                     mean, invstd, relu, post, pix_per_img, sums, nrep, g.ppb);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }
 
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                      void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
-                     const float* mean, const float* invstd, const double* sums, double count,
-                     int relu, const float* post, long pix_per_img, float* dgamma, float* dbeta,
-                     float param_grad_scale, void* stream) {
-  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z)) return SSA_EINVAL;
+                     const float* mean, const float* invstd, const double* sums, int nrep,
+                     double count, int relu, const float* post, long pix_per_img, float* dgamma,
+                     float* dbeta, float param_grad_scale, void* stream) {
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z) || nrep < 1)
+    return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 5 * C * sizeof(float), (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz,
-                     (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums,
+                     (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums, nrep,
                      count, relu, post, pix_per_img, g.ppb, dgamma, dbeta, param_grad_scale);
   SSA_LAUNCH_CHECK();
   return SSA_OK;

@@ -500,9 +500,10 @@ class BatchNormActFn(torch.autograd.Function):
         dz, lddz = _pixels(dz if dz.dtype == ACT_DTYPE else dz.to(ACT_DTYPE))
         if lddz % 8 or dz.data_ptr() % 16:
             dz, lddz = dz.contiguous(), C
-        sums = _ARENA.take(2 * C, dev)
+        nrep = stat_replicas() if training else 1
+        sums = _ARENA.take(nrep * 2 * C, dev)
         check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
-                                  int(relu), _p(pst), H * W, _p(sums), 0, _s()), "ssa_bn_bwd_reduce")
+                                  int(relu), _p(pst), H * W, _p(sums), nrep, 0, _s()), "ssa_bn_bwd_reduce")
         pg = torch.empty((2, C), dtype=torch.float32, device=dev) if g is not None else None
         pscale = 1.0
         use_sums = sums
@@ -521,7 +522,7 @@ class BatchNormActFn(torch.autograd.Function):
         dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if has_res else None
         fuse_pg = pg is not None and training
         check(L.ssa_bn_bwd_apply(_p(x), ldx, _p(dz), lddz, _p(z), C, _p(dx), C, _p(dres), C, P, C, _p(g),
-                                 _p(coef[2]), _p(coef[3]), _p(use_sums), count, int(relu), _p(pst), H * W,
+                                 _p(coef[2]), _p(coef[3]), _p(use_sums), nrep, count, int(relu), _p(pst), H * W,
                                  _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale, _s()),
               "ssa_bn_bwd_apply")
         dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
