@@ -228,6 +228,15 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
                      int lddy, void* dx, int dx_dtype, int Hi, int Wi, int lddx,
                      void* stream);
 
+/* Label-map resize, mask.resize(size, Image.NEAREST) of
+ * transforms/joint_transforms.py:193,267,290,319,339,364,466:
+ * uint8 [B,Hs,Ws] -> [B,Hd,Wd], dst[y,x] = src[iy_table[y], ix_table[x]].  The
+ * index tables carry Pillow's exact rule (a running double-precision sum, see
+ * semseg_amd/datasets/transforms.py); the result is bit-identical to PIL.      */
+int ssa_resize_nearest_u8(const unsigned char* src, int B, int Hs, int Ws,
+                          unsigned char* dst, int Hd, int Wd, const int* iy_table,
+                          const int* ix_table, void* stream);
+
 /* ------------------------------------------------------------------- OCR ----
  * SpatialGather_Module.forward, network/ocr_utils.py:34-46 (K9) and
  * ObjectAttentionBlock.forward, network/ocr_utils.py:95-119 (K10).

@@ -1,0 +1,54 @@
+"""ORACLE -- test infrastructure only.  Never imported by the product package.
+
+Plain-Python restatement of the two integer pieces of the reference's input
+pipeline that SURVEY.md section 8a lists on the hot path's boundary:
+  S1  datasets/sampler.py:78-100   DistributedSampler.__iter__
+  S2  transforms/joint_transforms.py:193 (and 267, 290, 319, 339, 364, 466)
+      mask.resize(size, Image.NEAREST)  -- Pillow's ImagingScaleAffine
+Pinned by tests/golden/data_golden.json (generated from the real reference /
+from Pillow by tests/golden/make_golden_data.py)."""
+import math
+
+import torch
+
+
+def sampler_indices(n, epoch, rank, world, pad=False, consecutive_sample=False, permutation=False):
+    """datasets/sampler.py:78-100, statement by statement."""
+    num_samples = int(math.ceil(n * 1.0 / world)) if pad else int(math.floor(n * 1.0 / world))
+    total_size = num_samples * world                       # sampler.py:71-75
+    g = torch.Generator()
+    g.manual_seed(epoch)                                   # sampler.py:80-81
+    if permutation:
+        indices = [int(v) for v in torch.randperm(n, generator=g)]   # sampler.py:84
+    else:
+        indices = [x for x in range(n)]                    # sampler.py:86
+    if total_size > len(indices):
+        indices += indices[:(total_size - len(indices))]   # sampler.py:89-90
+    if consecutive_sample:
+        offset = num_samples * rank                        # sampler.py:93-95
+        indices = indices[offset:offset + num_samples]
+    else:
+        indices = indices[rank:total_size:world]           # sampler.py:97
+    assert len(indices) == num_samples
+    return indices
+
+
+def pil_nearest_indices(n_dst, n_src):
+    """Source index per destination index of Pillow's NEAREST resize
+    (libImaging/Geometry.c ImagingScaleAffine: xo = a0*0.5; per pixel
+    xin = (int)xo; xo += a0, all in double)."""
+    a0 = float(n_src) / float(n_dst)
+    xo = a0 * 0.5
+    out = []
+    for _ in range(n_dst):
+        xin = -1 if xo < 0.0 else int(xo)
+        out.append(min(max(xin, 0), n_src - 1))
+        xo += a0
+    return out
+
+
+def resize_nearest(mask, size):
+    """mask: 2-D list/array of ints [Hs][Ws]; size = (Hd, Wd) -> nested lists."""
+    hs, ws = len(mask), len(mask[0])
+    iy, ix = pil_nearest_indices(size[0], hs), pil_nearest_indices(size[1], ws)
+    return [[int(mask[y][x]) for x in ix] for y in iy]

@@ -190,6 +190,24 @@ inline int grid_for(long n) {
   return (int)b;
 }
 
+
+// Nearest-neighbour resize of uint8 label maps with PIL's index rule.  The
+// source row/column of every destination row/column comes from host-computed
+// tables (semseg_amd/datasets/transforms.py reproduces Pillow's running double
+// sum bit for bit), so the gather itself is exact by construction.
+__global__ void resize_nearest_u8_kernel(const unsigned char* __restrict__ src, int Hs, int Ws,
+                                         unsigned char* __restrict__ dst, int Hd, int Wd,
+                                         const int* __restrict__ iy, const int* __restrict__ ix,
+                                         long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wd);
+    long t = i / Wd;
+    const int y = (int)(t % Hd);
+    const long b = t / Hd;
+    dst[i] = src[(b * Hs + iy[y]) * Ws + ix[x]];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -253,6 +271,18 @@ int ssa_image_resize_to_nhwc_bf16(const float* x, int B, int C, int Hi, int Wi, 
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   hipLaunchKernelGGL(image_resize_kernel, dim3(grid_for((long)B * Ho * Wo)), dim3(256), 0,
                      (hipStream_t)stream, x, B, C, Hi, Wi, (bf16_t*)y, Ho, Wo, cpad, sh, sw);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_resize_nearest_u8(const unsigned char* src, int B, int Hs, int Ws, unsigned char* dst, int Hd,
+                          int Wd, const int* iy_table, const int* ix_table, void* stream) {
+  if (!src || !dst || !iy_table || !ix_table || B < 1 || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1)
+    return SSA_EINVAL;
+  const long n = (long)B * Hd * Wd;
+  const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(resize_nearest_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, Hs,
+                     Ws, dst, Hd, Wd, iy_table, ix_table, n);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

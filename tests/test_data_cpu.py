@@ -1,0 +1,73 @@
+"""Integer-exact boundary pieces on CPU: the oracle
+against golden vectors from the real reference sampler / Pillow, and the
+product's host logic against the oracle."""
+import json
+import os
+import random
+
+import numpy as np
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_golden.json")
+
+
+def _gold():
+    with open(G) as f:
+        return json.load(f)
+
+
+def golden_masks():
+    """The source masks of make_golden_data.py, regenerated from its seed."""
+    rng = np.random.default_rng(7)
+    for case in _gold()["nearest"]:
+        hs, ws = case["src"]
+        yield case, rng.integers(0, 256, (hs, ws), dtype=np.uint8)
+
+
+def checksums(r):
+    r = np.asarray(r)
+    w = (np.arange(r.size).reshape(r.shape) % 251 + 1)
+    return int(r.astype(np.int64).sum()), int((r.astype(np.int64) * w).sum())
+
+
+def test_oracle_sampler_matches_reference():
+    from oracle.data import sampler_indices
+    for c in _gold()["sampler"]:
+        got = sampler_indices(c["n"], c["epoch"], c["rank"], c["world"], c["pad"], c["consecutive"], c["permutation"])
+        assert got == c["indices"], c
+
+
+def test_product_sampler_matches_reference_and_oracle():
+    from oracle.data import sampler_indices
+    from semseg_amd.datasets import DistributedSampler, shard_indices
+    for c in _gold()["sampler"]:
+        s = DistributedSampler(list(range(c["n"])), pad=c["pad"], consecutive_sample=c["consecutive"],
+                               permutation=c["permutation"], num_replicas=c["world"], rank=c["rank"])
+        s.set_epoch(c["epoch"])
+        assert list(s) == c["indices"] and len(s) == len(c["indices"])
+    rnd = random.Random(3)
+    for _ in range(200):
+        n, world = rnd.randint(1, 400), rnd.randint(1, 16)
+        args = (n, rnd.randint(0, 50), rnd.randrange(world), world, rnd.random() < 0.5, rnd.random() < 0.5,
+                rnd.random() < 0.5)
+        assert shard_indices(*args) == sampler_indices(*args), args
+    # every sample appears exactly once per epoch when the split is padded and strided
+    seen = sorted(i for r in range(8) for i in shard_indices(64, 4, r, 8, True, False, True))
+    assert seen == list(range(64))
+
+
+def test_oracle_nearest_matches_pillow():
+    from oracle.data import resize_nearest
+    for case, m in golden_masks():
+        r = np.array(resize_nearest(m.tolist(), tuple(case["dst"])), dtype=np.uint8)
+        assert tuple(r.shape) == tuple(case["dst"])
+        assert checksums(r) == (case["sum"], case["weighted"]), case["src"]
+        assert r[0].tolist()[:64] == case["first_row"] and r[:, -1].tolist()[:64] == case["last_col"]
+
+
+def test_index_table_is_the_oracles():
+    from oracle.data import pil_nearest_indices
+    from semseg_amd.datasets import nearest_index_table
+    rnd = random.Random(5)
+    sizes = [(rnd.randint(1, 2100), rnd.randint(1, 2100)) for _ in range(300)] + [(1024, 2048), (2048, 1024), (1, 1)]
+    for n_dst, n_src in sizes:
+        assert nearest_index_table(n_dst, n_src).tolist() == pil_nearest_indices(n_dst, n_src), (n_dst, n_src)

@@ -1,0 +1,39 @@
+"""Label resize on the GPU (ssa_resize_nearest_u8 through the C ABI): bit-exact
+against the golden Pillow checksums, against the oracle on random sizes, and at
+Cityscapes' full 1024x2048 size."""
+import numpy as np
+import pytest
+import torch
+
+from test_data_cpu import golden_masks, checksums
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nearest_resize_matches_pillow_golden():
+    from semseg_amd.datasets import resize_labels_nearest
+    for case, m in golden_masks():
+        r = resize_labels_nearest(torch.from_numpy(m).cuda(), tuple(case["dst"])).cpu().numpy()
+        assert checksums(r) == (case["sum"], case["weighted"]), case["src"]
+        assert r[0].tolist()[:64] == case["first_row"] and r[:, -1].tolist()[:64] == case["last_col"]
+
+
+def test_nearest_resize_batched_and_full_size():
+    from oracle.data import pil_nearest_indices
+    from semseg_amd.datasets import resize_labels_nearest
+    rng = np.random.default_rng(11)
+    for (b, hs, ws), (hd, wd) in [((3, 37, 53), (80, 41)), ((2, 1024, 2048), (717, 1434)), ((1, 64, 64), (64, 64)),
+                                  ((2, 300, 200), (1, 1))]:
+        m = rng.integers(0, 256, (b, hs, ws), dtype=np.uint8)
+        got = resize_labels_nearest(torch.from_numpy(m).cuda(), (hd, wd)).cpu().numpy()
+        iy, ix = pil_nearest_indices(hd, hs), pil_nearest_indices(wd, ws)
+        want = m[:, iy][:, :, ix]
+        assert got.shape == want.shape and np.array_equal(got, want)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    m = rng.integers(0, 20, (1024, 2048), dtype=np.uint8)
+    want = np.array(Image.fromarray(m).resize((1434, 717), Image.NEAREST))
+    got = resize_labels_nearest(torch.from_numpy(m).cuda(), (717, 1434)).cpu().numpy()
+    assert np.array_equal(got, want)
