@@ -380,16 +380,17 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int stride, int 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int WGM, int WGN, int MI, int NI>
+// BKP: pixels (GEMM k) per LDS stage, 32 or 64.
+template <int WGM, int WGN, int MI, int NI, int BKP>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
     ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
     int cout_pad, float* __restrict__ partial, int tiles_n, int chunk) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
   constexpr int SA = tr_row_stride(BM), SB = tr_row_stride(BN);
   constexpr int PA = BM / 8, PB = BN / 8;          // 16-byte pieces per pixel row
-  constexpr int A_PIECES = 32 * PA, B_PIECES = 32 * PB;
+  constexpr int A_PIECES = BKP * PA, B_PIECES = BKP * PB;
   constexpr int A_IT = (A_PIECES + NT - 1) / NT, B_IT = (B_PIECES + NT - 1) / NT;
-  constexpr int STAGE = 32 * (SA + SB);
+  constexpr int STAGE = BKP * (SA + SB);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
 
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   uint4 ra[A_IT], rb[B_IT];
   auto gload = [&](int kt) {
-    const int pbase = p_begin + kt * 32;
+    const int pbase = p_begin + kt * BKP;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int p = pbase + a_pix[i];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
   };
   auto lstore = [&](int buf) {
     bf16_t* As = lds + buf * STAGE;
-    bf16_t* Bs = As + 32 * SA;
+    bf16_t* Bs = As + BKP * SA;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       if (tid + i * NT < A_PIECES) *reinterpret_cast<uint4*>(As + a_pix[i] * SA + a_co[i]) = ra[i];
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const int nk = (p_end - p_begin + 31) / 32;
+  const int nk = (p_end - p_begin + BKP - 1) / BKP;
   if (nk > 0) {
     gload(0);
     lstore(0);
@@ -479,9 +480,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
       const int buf = kt & 1;
       if (kt + 1 < nk) gload(kt + 1);
       const bf16_t* As = lds + buf * STAGE;
-      const bf16_t* Bs = As + 32 * SA;
+      const bf16_t* Bs = As + BKP * SA;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < BKP / 16; ++ks) {
         bf16x8_t af[MI], bfr[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[mi] = tr_frag(As, SA, wm * MI * 32 + mi * 32, ks * 16, lane);
@@ -667,9 +668,28 @@ int launch_wgrad(const ssa_conv_desc& d, const void* x, const void* dy, int lddy
     const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
     const long P = (long)d.B * d.Ho * d.Wo;
     long chunk = (P + nsplit - 1) / nsplit;
+    // 64-pixel stages (16 MFMAs per wave between barriers) were measured SLOWER on MI355X:
+    // 720->512 3x3 wgrad 2.22 ms -> 3.20 ms, the 80 KB of LDS leave one workgroup per CU
+    // instead of three.  Kept selectable (cfg 102) for experiments only.
+    const bool deep = (BM >= 128 && BN >= 128) ? (chunk >= 512 && d.cfg == 102) : false;
+    if (deep) {
+      chunk = (chunk + 63) / 64 * 64;
+      const size_t lds = (size_t)2 * 64 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
+      auto kern = conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 64>;
+      static bool once = false;
+      if (!once && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        once = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, nsplit), dim3(64 * WGM * WGN), lds, s, d,
+                         (const bf16_t*)x, (const bf16_t*)dy, lddy, cout_pad, partial, tiles_n, (int)chunk);
+      SSA_LAUNCH_CHECK();
+      return SSA_OK;
+    }
     chunk = (chunk + 31) / 32 * 32;
     const size_t lds = (size_t)2 * 32 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n, nsplit),
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 32>), dim3(tiles_m * tiles_n, nsplit),
                        dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
                        cout_pad, partial, tiles_n, (int)chunk);
     SSA_LAUNCH_CHECK();
