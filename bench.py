@@ -255,8 +255,21 @@ def main():
         dom = max(agg.items(), key=lambda kv: kv[1][1])      # most time
         (kind, tile), (fl, tt, n) = dom
         name = TILE_NAMES.get(tile, kind)
+        # HBM bytes per launch of that kernel family: PMC counters (FETCH_SIZE, WRITE_SIZE in separate
+        # rocprofv3 passes over this same command, corrected as MI355X_MICROARCH.md prescribes) --
+        # collected offline into profiles/ (rocprofv3 cannot run inside this process)
+        traffic, traffic_src = None, None
+        fam = {"wgrad": "conv_wgrad_tr_kernel", "tile": "conv_tile_kernel", "halo": "conv_halo_gemm_kernel",
+               "igemm": "conv_igemm_kernel"}.get(kind)
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if fam and os.path.exists(pmc):
+            with open(pmc) as f:
+                ent = json.load(f)["kernels"].get(fam)
+            if ent:
+                traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
         roof = {"bound": "mfma", "kernel": name, "achieved": fl / tt / 1e12, "peak": PEAK_BF16_MFMA / 1e12,
-                "unit": "TFLOP/s", "frac": fl / tt / PEAK_BF16_MFMA, "traffic": None,
+                "unit": "TFLOP/s", "frac": fl / tt / PEAK_BF16_MFMA, "traffic": traffic,
+                "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "launches_per_step": n // 2, "avg_launch_us": tt / n * 1e6,
                 "flop_per_launch": fl / n, "gemm_time_share_of_step": tot_t / 2 / (ms * 1e-3),
                 "all_gemm_kernels": {("%s/%s" % (k[0], TILE_NAMES.get(k[1], "-"))): {

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/semseg_hip.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -792,7 +793,8 @@ int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, siz
   const int Kflat = d->KH * d->KW * d->Cin;
   const long tiles = (long)((cout_pad + bm - 1) / bm) * ((Kflat + bn - 1) / bn);
   const long P = (long)d->B * d->Ho * d->Wo;
-  long ns = (640 + tiles - 1) / tiles;
+  static const long target_wgs = getenv("SSA_WGRAD_WGS") ? atol(getenv("SSA_WGRAD_WGS")) : 640;
+  long ns = (target_wgs + tiles - 1) / tiles;
   const long max_by_pixels = (P + 127) / 128;  // at least 4 stages per split
   if (ns > max_by_pixels) ns = max_by_pixels;
   if (ns < 1) ns = 1;
