@@ -228,6 +228,21 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
                      int lddy, void* dx, int dx_dtype, int Hi, int Wi, int lddx,
                      void* stream);
 
+/* ----------------------------------------------------------------- pooling ----
+ * DeepLabV3+/ResNet-50 (BASELINE configs[0]): nn.MaxPool2d(3, 2, 1) of the ResNet
+ * stem (network/Resnet.py:147) and nn.AdaptiveAvgPool2d(1) of the ASPP image
+ * branch (network/utils.py:201).  NHWC bf16, C % 8 == 0.  idx: winning tap per
+ * output element (uint8, PyTorch's first-maximum rule), consumed by the backward. */
+int ssa_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void* y,
+                         unsigned char* idx, int Ho, int Wo, void* stream);
+int ssa_maxpool3x3s2_bwd(const void* dy, const unsigned char* idx, int B, int Ho, int Wo,
+                         int C, void* dx, int H, int W, void* stream);
+/* out[b,c] = mean_p x[b,p,c];  dx[b,p,c] = dout[b,c] / HW                        */
+int ssa_global_avg_pool_fwd(const void* x, int ldx, int B, long HW, int C, void* out,
+                            void* stream);
+int ssa_global_avg_pool_bwd(const void* dout, int B, long HW, int C, void* dx,
+                            void* stream);
+
 /* Label-map resize, mask.resize(size, Image.NEAREST) of
  * transforms/joint_transforms.py:193,267,290,319,339,364,466:
  * uint8 [B,Hs,Ws] -> [B,Hd,Wd], dst[y,x] = src[iy_table[y], ix_table[x]].  The

@@ -123,3 +123,13 @@ def rmi_loss(logits_4D, labels_4D, num_classes, do_rmi=True, weight_lambda=0.5):
     onehot_4D = onehot.permute(0, 3, 1, 2)
     rmi = rmi_lower_bound(onehot_4D, probs_4D, num_classes)
     return weight_lambda * bce_loss + rmi * (1 - weight_lambda)
+
+
+def max_pool_3x3_s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1), network/Resnet.py:147."""
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def global_avg_pool(x):
+    """nn.AdaptiveAvgPool2d(1), network/utils.py:201 (ASPP image pooling)."""
+    return F.adaptive_avg_pool2d(x, 1)

@@ -73,6 +73,10 @@ _SIGS = {
                           c_int, _P], c_int),
     "ssa_bilinear_bwd": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,
                           c_int, _P], c_int),
+    "ssa_maxpool3x3s2_fwd": ([_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P], c_int),
+    "ssa_maxpool3x3s2_bwd": ([_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P], c_int),
+    "ssa_global_avg_pool_fwd": ([_P, c_int, c_int, c_long, c_int, _P, _P], c_int),
+    "ssa_global_avg_pool_bwd": ([_P, c_int, c_long, c_int, _P, _P], c_int),
     "ssa_resize_nearest_u8": ([_P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P], c_int),
     "ssa_softmax_hw_stats": ([_P, c_int, c_long, c_int, _P, _P], c_int),
     "ssa_softmax_hw_probs": ([_P, c_int, c_long, c_int, _P, _P, c_int, _P], c_int),

@@ -589,6 +589,52 @@ class BilinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, stride=2, padding=1) on NHWC bf16 (ResNet stem)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = _pixels(x)
+        B, H, W, C = x.shape
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty((B, Ho, Wo, C), dtype=ACT_DTYPE, device=x.device)
+        idx = torch.empty((B, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+        check(lib().ssa_maxpool3x3s2_fwd(_p(x), ldx, B, H, W, C, _p(y), _p(idx), Ho, Wo, _s()), "ssa_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.meta = (B, H, W, C, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, H, W, C, Ho, Wo = ctx.meta
+        dy = (dy if dy.dtype == ACT_DTYPE else dy.to(ACT_DTYPE)).contiguous()
+        dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dy.device)
+        check(lib().ssa_maxpool3x3s2_bwd(_p(dy), _p(idx), B, Ho, Wo, C, _p(dx), H, W, _s()), "ssa_maxpool3x3s2_bwd")
+        return dx
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) on NHWC bf16: [B,H,W,C] -> [B,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = _pixels(x)
+        B, H, W, C = x.shape
+        out = torch.empty((B, 1, 1, C), dtype=ACT_DTYPE, device=x.device)
+        check(lib().ssa_global_avg_pool_fwd(_p(x), ldx, B, H * W, C, _p(out), _s()), "ssa_global_avg_pool_fwd")
+        ctx.meta = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, W, C = ctx.meta
+        dout = (dout if dout.dtype == ACT_DTYPE else dout.to(ACT_DTYPE)).contiguous()
+        dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dout.device)
+        check(lib().ssa_global_avg_pool_bwd(_p(dout), B, H * W, C, _p(dx), _s()), "ssa_global_avg_pool_bwd")
+        return dx
+
+
 def image_to_nhwc(images, out_hw=None, cpad=16):
     """NCHW fp32 image batch -> NHWC bf16, optionally bilinearly resized."""
     images = images.detach()

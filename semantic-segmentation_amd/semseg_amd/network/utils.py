@@ -10,12 +10,17 @@ from ..nn import Conv2d, Norm2d, BNReLU, conv_bn  # noqa: F401  (BNReLU re-expor
 
 
 def get_trunk(trunk_name, output_stride=8):
-    """network/utils.py:102-141 -- only the HRNetV2 trunk is on the hot path."""
-    if trunk_name != "hrnetv2":
-        raise ValueError("unsupported trunk {} (hot path: hrnetv2)".format(trunk_name))
-    from . import hrnetv2
-    backbone = hrnetv2.get_seg_model()
-    return backbone, None, None, backbone.high_level_ch
+    """network/utils.py:102-141 -- the trunks of BASELINE.json's configs: HRNetV2-W48
+    (hot path) and ResNet-50 (DeepLabV3+ plumbing config)."""
+    assert output_stride == 8, "Only stride8 supported right now"
+    if trunk_name == "hrnetv2":
+        from . import hrnetv2
+        backbone = hrnetv2.get_seg_model()
+        return backbone, -1, -1, backbone.high_level_ch
+    if trunk_name == "resnet-50":
+        from .resnet import get_resnet
+        return get_resnet(trunk_name, output_stride=output_stride), 256, -1, 2048
+    raise ValueError("unsupported trunk {} (supported: hrnetv2, resnet-50)".format(trunk_name))
 
 
 class AttnHead(nn.Sequential):

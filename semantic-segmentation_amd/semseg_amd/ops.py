@@ -113,6 +113,12 @@ class HipBackend:
             return x
         return self.hb.BilinearFn.apply(x, int(size[0]), int(size[1]), bool(out_f32))
 
+    def max_pool3x3s2(self, x):
+        return self.hb.MaxPool3x3s2Fn.apply(x)
+
+    def global_avg_pool(self, x):
+        return self.hb.GlobalAvgPoolFn.apply(x)
+
     def cat(self, tensors):
         return torch.cat(tensors, dim=3)      # pure data movement
 

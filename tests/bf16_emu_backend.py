@@ -52,11 +52,18 @@ class Bf16EmuBackend(OracleBackend):
         # HIP path too (everything here has dtype fp32, so go by channel count)
         return y if (out_f32 or x.shape[3] in (1, 19)) else R(y)
 
+    def max_pool3x3s2(self, x):
+        return R(super().max_pool3x3s2(x))
+
+    def global_avg_pool(self, x):
+        return R(super().global_avg_pool(x))
+
     def ocr_attention(self, q, k, v, scale):
         return R(super().ocr_attention(q, k, v, scale))
 
 
-TRACED = ("image_to_nhwc", "conv2d", "batch_norm_act", "sum_act", "bilinear", "ocr_gather", "ocr_attention")
+TRACED = ("image_to_nhwc", "conv2d", "batch_norm_act", "sum_act", "bilinear", "ocr_gather", "ocr_attention",
+          "max_pool3x3s2", "global_avg_pool")
 
 
 def traced(backend, sink):

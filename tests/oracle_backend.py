@@ -73,6 +73,12 @@ class OracleBackend:
             return x
         return _to_nhwc(O.bilinear(_to_nchw(x), tuple(size)))
 
+    def max_pool3x3s2(self, x):
+        return _to_nhwc(O.max_pool_3x3_s2(_to_nchw(x)))
+
+    def global_avg_pool(self, x):
+        return _to_nhwc(O.global_avg_pool(_to_nchw(x)))
+
     def cat(self, tensors):
         return torch.cat(tensors, dim=3)
 

@@ -74,6 +74,12 @@ CONV_CASES = [
     (1, 16, 16, 384, 384, 3, 1, 1, 1, False, False),
     (1, 37, 29, 96, 96, 3, 1, 1, 1, False, False),
     (1, 19, 1, 512, 256, 1, 1, 0, 1, False, False),
+    # DeepLabV3+/ResNet-50 shapes: 7x7 stride-2 stem, strided 1x1 downsample, ASPP dilations
+    (1, 64, 80, 3, 64, 7, 2, 3, 1, False, False),
+    (1, 24, 32, 256, 512, 1, 2, 0, 1, False, False),
+    (2, 12, 16, 512, 256, 3, 1, 24, 24, False, False),
+    (1, 12, 16, 2048, 256, 1, 1, 0, 1, False, False),
+    (1, 20, 28, 128, 128, 3, 1, 2, 2, False, False),
     # halo-tile kernel (conv_tile.hip): every (Cin, n-block, tile-width) dispatch class
     (1, 70, 75, 64, 64, 3, 1, 1, 1, False, False),
     (1, 130, 129, 48, 48, 3, 1, 1, 1, True, False),
@@ -328,6 +334,42 @@ def test_bn_eval():
                                 rv.to(DEV), None, 0.1, 1e-5, False, True, False)
     torch.cuda.synchronize()
     check_close("bn_eval", nchw(z.float()), y)
+
+
+# ---------------------------------------------------------------- pooling
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 48, 64), (1, 64, 33, 47), (1, 8, 5, 7)])
+def test_maxpool3x3s2(B, C, H, W):
+    """ResNet stem pooling on post-ReLU data (many exact ties at zero): values and
+    the gradient routing must match PyTorch's first-maximum rule."""
+    from oracle import ops as O
+    hb = _hb()
+    x = torch.relu(_rand(B, C, H, W, seed=31))
+    xr = x.clone().requires_grad_(True)
+    yr = O.max_pool_3x3_s2(xr)
+    gy = _rand(*yr.shape, seed=32)
+    yr.backward(gy)
+    xd = _to_dev_nhwc(x).requires_grad_(True)
+    yd = hb.MaxPool3x3s2Fn.apply(xd)
+    yd.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(yd.float()).cpu(), yr.detach())
+    check_close("maxpool dx", nchw(xd.grad.float()), xr.grad, 1e-2, 4e-3)
+
+
+def test_global_avg_pool():
+    from oracle import ops as O
+    hb = _hb()
+    x = _rand(2, 2048, 12, 16, seed=33)
+    xr = x.clone().requires_grad_(True)
+    yr = O.global_avg_pool(xr)
+    gy = _rand(*yr.shape, seed=34)
+    yr.backward(gy)
+    xd = _to_dev_nhwc(x).requires_grad_(True)
+    yd = hb.GlobalAvgPoolFn.apply(xd)
+    yd.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    check_close("gap fwd", nchw(yd.float()), yr)
+    check_close("gap dx", nchw(xd.grad.float()), xr.grad)
 
 
 # --------------------------------------------------------------- bilinear

@@ -99,3 +99,38 @@ def test_mscale_eval_matches_reference(gold):
         o = net.nscale_forward(gold["images"], [0.5, 1.0, 2.0])
     for k, v in gold["eval_nscale"].items():
         check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 1e-4, 1e-4)
+
+
+def test_deepv3_oracle_matches_reference():
+    """DeepLabV3+/ResNet-50 (BASELINE configs[0]): oracle/deepv3.py vs the real
+    reference's train loss, sampled gradients of all 161 parameters, BN running
+    statistics and eval logits (tests/golden/make_golden_deepv3.py)."""
+    import os
+    from oracle.deepv3 import DeepV3PlusNet
+    from oracle.model import seeded_state_dict
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    gold = torch.load(os.path.join(G, "deepv3_golden.pt"), map_location="cpu", weights_only=False)
+    shapes = []
+    with open(os.path.join(G, "keys_deepv3.txt")) as f:
+        for line in f:
+            k, _, s = line.strip().partition(" ")
+            shapes.append((k, tuple(int(v) for v in s.split(",")) if s else ()))
+    sd = seeded_state_dict(shapes, seed=gold["seed"])
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    loss = DeepV3PlusNet(sd, 19, training=True).forward(gold["images"], gold["gts"])
+    loss.backward()
+    assert abs(float(loss) - float(gold["train_loss"])) <= 1e-5 * abs(float(gold["train_loss"]))
+    for name, (idx, vals, norm) in gold["grads"].items():
+        g = sd[name].grad.flatten()
+        assert torch.allclose(g[idx], vals, rtol=2e-3, atol=2e-6 * float(norm) + 1e-9), name
+        assert abs(float(g.norm()) - float(norm)) <= 1e-3 * float(norm) + 1e-9, name
+    for k, v in gold["running_sample"].items():
+        assert torch.allclose(sd[k].detach().flatten()[:4], v, rtol=1e-4, atol=1e-6), k
+    sd2 = seeded_state_dict(shapes, seed=gold["seed"])
+    sd2.update(gold["calib_buffers"])
+    with torch.no_grad():
+        pred = DeepV3PlusNet(sd2, 19, training=False).forward(gold["images"])["pred"]
+    ref = gold["eval_pred"]
+    assert float((pred[:, :, ::8, ::8] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())

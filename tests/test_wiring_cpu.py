@@ -103,3 +103,62 @@ def test_eval_wiring(oracle_ops):
         cfg.MODEL.N_SCALES = None
         for k, v in gold["eval_nscale"].items():
             check_close("nscale " + k, o[k][:, :, ::8, ::8], v, 2e-3, 5e-3)
+
+
+# ------------------------------------------------------------------ DeepLabV3+
+def _deepv3_shapes():
+    out = []
+    with open(os.path.join(G, "keys_deepv3.txt")) as f:
+        for line in f:
+            k, _, s = line.strip().partition(" ")
+            out.append((k, tuple(int(v) for v in s.split(",")) if s else ()))
+    return out
+
+
+def _deepv3(train, seed):
+    from semseg_amd.loss import CrossEntropyLoss2d
+    from semseg_amd.network import get_model
+    from oracle.model import seeded_state_dict
+    net = get_model("deepv3.DeepV3PlusR50", 19, CrossEntropyLoss2d(ignore_index=255))
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == _deepv3_shapes()
+    net.load_state_dict(seeded_state_dict(_deepv3_shapes(), seed=seed))
+    return net.train(train)
+
+
+def test_deepv3_wiring(oracle_ops):
+    """semseg_amd.network.deepv3.DeepV3PlusR50 (BASELINE configs[0]) on the oracle's
+    operators == the REAL reference: state_dict, train loss, every parameter
+    gradient (fp64 vs the pinned oracle), running stats, eval logits."""
+    from oracle.deepv3 import DeepV3PlusNet
+    from oracle.model import seeded_state_dict
+    gold = torch.load(os.path.join(G, "deepv3_golden.pt"), map_location="cpu", weights_only=False)
+    net = _deepv3(True, gold["seed"])
+    loss = net({"images": gold["images"], "gts": gold["gts"]})
+    check_close("deepv3 train loss", loss.detach().view(1), gold["train_loss"].view(1), 1e-5, 1e-5)
+    assert int(net.state_dict()["backbone.layer0.1.num_batches_tracked"]) == 1
+
+    net = _deepv3(True, gold["seed"]).double()
+    img = gold["images"].double()
+    loss = net({"images": img, "gts": gold["gts"]})
+    loss.backward()
+    osd = {k: (v.double() if v.is_floating_point() else v) for k, v in
+           seeded_state_dict(_deepv3_shapes(), gold["seed"]).items()}
+    for k, v in osd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    oloss = DeepV3PlusNet(osd, 19, training=True).forward(img, gold["gts"])
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-10
+    for name, p in net.named_parameters():
+        ref = osd[name].grad
+        assert float((p.grad - ref).norm() / (ref.norm() + 1e-300)) < 1e-8, name
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            assert torch.allclose(v, osd[k], rtol=1e-9, atol=1e-12), k
+
+    net = _deepv3(False, gold["seed"])
+    net.load_state_dict(gold["calib_buffers"], strict=False)
+    with torch.no_grad():
+        o = net({"images": gold["images"]})
+    assert tuple(o["pred"].shape) == (2, 19, 96, 128)
+    check_close("deepv3 eval pred", o["pred"][:, :, ::8, ::8], gold["eval_pred"], 2e-3, 5e-3)
