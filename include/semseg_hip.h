@@ -121,6 +121,19 @@ typedef struct ssa_pack_job {
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job,
                              void* stream);
 
+/* Halo-staged weight gradient for the 3x3 stride-1 trunk convs with
+ * Cin == cout_pad in {48, 64, 96, 192, 384}: persistent workgroups keep their
+ * block of dW in MFMA accumulators while they walk 128-pixel tiles whose x halo
+ * image and dy tile are staged in LDS once (transposing ds_read_b64_tr_b16
+ * fragment reads).  Same partial layout as ssa_conv2d_wgrad
+ * ([nsplit][cout_pad][9*Cin] fp32) -> finish with ssa_conv2d_wgrad_reduce.
+ * _plan returns SSA_EUNSUPPORTED for shapes this kernel does not take.          */
+int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit,
+                               size_t* ws_bytes);
+int ssa_conv2d_wgrad_tile(const ssa_conv_desc* d, const void* x, const void* dy,
+                          int lddy, int cout_pad, int nsplit, float* partial,
+                          void* stream);
+
 /* Column sum over pixels: out[c] = sum_p x[p, c]  (bias gradient). x bf16. */
 int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out,
                     double* scratch2c, void* stream);

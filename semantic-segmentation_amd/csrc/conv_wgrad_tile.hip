@@ -1,0 +1,296 @@
+// Halo-staged weight gradient for the 3x3 stride-1 convs of the HRNet trunk
+// (Cin = Cout = 48 / 64 / 96 / 192 / 384; network/hrnetv2.py:31-66, SURVEY.md K1:
+// 522 of the 641 wgrad launches of a training step).
+//
+//   dW[co][tap][ci] = sum over pixels p of  dy[p][co] * x[p + tap][ci]
+//
+// as a GEMM: M = co, N = (tap, ci), K = pixels.  The K-pipelined wgrad kernel
+// (conv_igemm.hip) gathers x im2col-style (every input pixel read 9 times, 9
+// bounds checks per element) and splits the pixel axis over ~90 workgroups per
+// output tile, each writing an fp32 partial: 30-40 MB of partial traffic for a
+// 6 MB layer (profiles/r01_pmc_traffic.txt).  Here
+//   * a workgroup is PERSISTENT over a strip of 128-pixel tiles (4 rows x 32) and
+//     keeps its whole block of dW in MFMA accumulators, so only G <= 96 partials
+//     exist per layer;
+//   * per tile the x HALO image (6x34 pixels) and the dy tile are staged in LDS
+//     once, pixel-major exactly as they lie in HBM (16-byte copies, no transposing
+//     stores); all 9 taps are the same image at shifted pixel offsets;
+//   * both MFMA operands need 8 consecutive PIXELS per lane for one channel, i.e.
+//     a transposed read of the pixel-major image: ds_read_b64_tr_b16 (lane map
+//     probed on the device, tests/test_kernels_gpu.py::test_probe_tr16).  The
+//     pixel stride is 64*odd bytes, which puts the 4 pixels a 16-lane group reads
+//     in 4 distinct 64-byte windows of the 256-byte bank row: conflict free.
+// blockIdx.y partitions the output (co part, n part) so that a workgroup owns at
+// most 12 accumulator tiles per wave:
+//     C=48: 2 m-blocks x 14 n-blocks (all taps)      C=64: 2 x 18
+//     C=96: 3 x 9 (one kernel row kh per part)       C=192/384: 6 x 6 (one tap,
+//     192 input channels and 192 output channels per part)
+#include "common.h"
+#include "../../include/semseg_hip.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int tr_stride_bytes(int row_bytes) {   // smallest 64*odd >= row_bytes
+  int s = (row_bytes + 63) / 64;
+  if ((s & 1) == 0) ++s;
+  return s * 64;
+}
+
+__device__ __forceinline__ bf16x8_t tr_read8(const unsigned char* p, int stride_bytes) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(p + 4 * stride_bytes));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int CX, int MB, int NBW>
+__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
+    const bf16_t* __restrict__ x, int ldx, int Cin, const bf16_t* __restrict__ dy, int lddy,
+    int cout_pad, int B, int H, int W, int tiles_x, int tiles_y, int tiles_per_wg, int n_parts,
+    float* __restrict__ partial) {
+  constexpr int TW = 32, TH = 4, HW_ = TW + 2, HH_ = TH + 2;
+  constexpr int SX = tr_stride_bytes(CX * 2), SD = tr_stride_bytes(MB * 64);
+  constexpr int HALO_BYTES = HH_ * HW_ * SX;
+  constexpr int NBL = (NBW + 3) / 4;           // n-blocks per wave
+  constexpr int XP = CX / 8, DP = MB * 4;      // 16-byte pieces per pixel
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Xs = smem;
+  unsigned char* Ds = smem + HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_part = blockIdx.y % n_parts, co_part = blockIdx.y / n_parts;
+  const int co0 = co_part * MB * 32;
+  const int n0 = n_part * NBW * 32;
+  const int Kflat = 9 * Cin;
+  const int ci_base = n0 % Cin;
+
+  // per-lane constants of the B (x) fragments of this wave's n-blocks
+  const int li = lane & 15, lj = li >> 2, lq = li & 3, lg = (lane >> 4) & 1, lh = lane >> 5;
+  int b_off[NBL];
+  bool b_ok[NBL];
+#pragma unroll
+  for (int l = 0; l < NBL; ++l) {
+    const int nb = wave + 4 * l;
+    const int n16 = n0 + nb * 32 + 16 * lg;
+    b_ok[l] = nb < NBW && n16 < Kflat;
+    const int tap = b_ok[l] ? n16 / Cin : 0;
+    const int ci = b_ok[l] ? n16 - tap * Cin - ci_base : -4 * lq;   // invalid: offset 0 (in bounds, discarded)
+    const int kh = tap / 3, kw = tap - kh * 3;
+    b_off[l] = (kh * HW_ + kw) * SX + (ci + 4 * lq) * 2;
+  }
+  const int a_col = (16 * lg + 4 * lq) * 2;     // byte offset of this lane's 4 channels inside an m-block
+
+  f32x16_t acc[MB][NBL];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][l][r] = 0.f;
+
+  const int total_tiles = B * tiles_x * tiles_y;
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = min(total_tiles, t_begin + tiles_per_wg);
+  constexpr int XN = HH_ * HW_ * XP, DN = TH * TW * DP;
+  constexpr int XI = (XN + 255) / 256, DI = (DN + 255) / 256;
+  uint4 xv[XI], dv[DI];
+  // tile-invariant part of every piece this thread moves: packed (row, column) inside the
+  // tile, element offset relative to the tile origin, LDS byte offset (-1: no such piece).
+  // Kept in registers when there are few pieces per thread (C <= 96); recomputed per tile
+  // for the 192-channel variant, whose accumulators leave no registers for them.
+  constexpr bool PRE = (XI + DI) <= 16;
+  int x_rc_[PRE ? XI : 1], x_go_[PRE ? XI : 1], x_lo_[PRE ? XI : 1];
+  int d_rc_[PRE ? DI : 1], d_go_[PRE ? DI : 1], d_lo_[PRE ? DI : 1];
+  auto x_piece = [&](int i, int* rc, int* go, int* lo) {
+    const int piece = tid + i * 256;
+    const int pix = piece / XP, cp = piece - pix * XP;
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    *rc = (hy << 8) | hx;
+    *go = (hy * W + hx) * ldx + cp * 8;
+    *lo = piece < XN ? pix * SX + cp * 16 : -1;
+  };
+  auto d_piece = [&](int i, int* rc, int* go, int* lo) {
+    const int piece = tid + i * 256;
+    const int pix = piece / DP, cp = piece - pix * DP;
+    const int ty = pix / TW, tx = pix - ty * TW;
+    *rc = (ty << 8) | tx;
+    *go = (ty * W + tx) * lddy + cp * 8;
+    *lo = (piece < DN && co0 + cp * 8 < cout_pad) ? pix * SD + cp * 16 : -1;
+  };
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) x_piece(i, &x_rc_[i], &x_go_[i], &x_lo_[i]);
+#pragma unroll
+    for (int i = 0; i < DI; ++i) d_piece(i, &d_rc_[i], &d_go_[i], &d_lo_[i]);
+  }
+  // global -> registers for tile t (x halo image, zero outside the image; dy tile, zero
+  // outside the image / past cout_pad); issued one tile ahead of the MFMAs
+  auto fetch = [&](int t) {
+    int r_ = t;
+    const int tx_i = r_ % tiles_x; r_ /= tiles_x;
+    const int ty_i = r_ % tiles_y;
+    const int b = r_ / tiles_y;
+    const int x0 = tx_i * TW, y0 = ty_i * TH;
+    const bf16_t* xb = x + ((long)b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + ci_base;
+    const bf16_t* db = dy + ((long)b * H * W + (long)y0 * W + x0) * lddy + co0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int rc, go, lo;
+      if constexpr (PRE) { rc = x_rc_[i]; go = x_go_[i]; lo = x_lo_[i]; } else { x_piece(i, &rc, &go, &lo); }
+      const int iy = y0 - 1 + (rc >> 8), ix = x0 - 1 + (rc & 255);
+      const bool ok = lo >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      xv[i] = ok ? *reinterpret_cast<const uint4*>(xb + go) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      int rc, go, lo;
+      if constexpr (PRE) { rc = d_rc_[i]; go = d_go_[i]; lo = d_lo_[i]; } else { d_piece(i, &rc, &go, &lo); }
+      const bool ok = lo >= 0 && y0 + (rc >> 8) < H && x0 + (rc & 255) < W;
+      dv[i] = ok ? *reinterpret_cast<const uint4*>(db + go) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int lo;
+      if constexpr (PRE) { lo = x_lo_[i]; } else { int rc, go; x_piece(i, &rc, &go, &lo); }
+      if (lo >= 0) *reinterpret_cast<uint4*>(Xs + lo) = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int piece = tid + i * 256;
+      if (piece < DN) *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = dv[i];
+    }
+  };
+  if (t_begin < t_end) fetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t > t_begin) __syncthreads();          // previous tile's fragments are read
+    stage();
+    __syncthreads();
+    if (t + 1 < t_end) fetch(t + 1);           // next tile's loads fly during this tile's MFMAs
+    // ---- 8 k-steps of 16 pixels (half a tile row each)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int ty = ks >> 1, tx0 = (ks & 1) * 16;
+      const int kp = tx0 + 8 * lh + lj;         // this lane's first pixel column inside the row
+      bf16x8_t af[MB], bfr[NBL];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        af[mb] = tr_read8(Ds + (ty * TW + kp) * SD + mb * 64 + a_col, SD);
+      // columns n >= 9*Cin of the last n-block read whatever lies at offset 0 of the image:
+      // a B column only feeds its own output column, and those columns are never stored
+#pragma unroll
+      for (int l = 0; l < NBL; ++l)
+        if (wave + 4 * l < NBW) bfr[l] = tr_read8(Xs + (ty * HW_ + kp) * SX + b_off[l], SX);
+#pragma unroll
+      for (int l = 0; l < NBL; ++l)
+        if (wave + 4 * l < NBW) {               // wave-uniform: waves without a 4th n-block skip it
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            acc[mb][l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[l], acc[mb][l], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- this workgroup's block of partial[g][co][k] (zeros if it had no tile)
+  float* out = partial + (long)blockIdx.x * cout_pad * Kflat;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) {
+      const int nb = wave + 4 * l;
+      const int kcol = n0 + nb * 32 + (lane & 31);
+      if (nb >= NBW || kcol >= Kflat) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[mb][l][r];
+      }
+    }
+}
+
+struct Plan { int cx, mb, nbw, n_parts, co_parts; };
+
+bool make_plan(int Cin, int cout_pad, Plan* p) {
+  if (Cin != cout_pad) return false;
+  switch (Cin) {
+    case 48: *p = {48, 2, 14, 1, 1}; return true;
+    case 64: *p = {64, 2, 18, 1, 1}; return true;
+    case 96: *p = {96, 3, 9, 3, 1}; return true;
+    case 192: *p = {192, 6, 6, 9, 1}; return true;
+    case 384: *p = {192, 6, 6, 18, 2}; return true;
+    default: return false;
+  }
+}
+
+template <int CX, int MB, int NBW>
+int launch(const ssa_conv_desc& d, const Plan& p, const void* x, const void* dy, int lddy, int cout_pad,
+           int G, int tiles_per_wg, float* partial, hipStream_t s) {
+  constexpr size_t lds = (size_t)6 * 34 * tr_stride_bytes(CX * 2) + (size_t)128 * tr_stride_bytes(MB * 64);
+  static_assert(lds <= 160 * 1024, "does not fit in LDS");
+  auto kern = conv_wgrad_tile_kernel<CX, MB, NBW>;
+  static bool once = false;
+  if (!once && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 3) / 4;
+  hipLaunchKernelGGL(kern, dim3(G, p.n_parts * p.co_parts), dim3(256), lds, s, (const bf16_t*)x, d.ldx, d.Cin,
+                     (const bf16_t*)dy, lddy, cout_pad, d.B, d.H, d.W, tiles_x, tiles_y, tiles_per_wg,
+                     p.n_parts, partial);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+bool shape_ok(const ssa_conv_desc* d) {
+  return d && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 && !d->transposed &&
+         d->Ho == d->H && d->Wo == d->W && d->ldx % 8 == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, size_t* ws_bytes) {
+  Plan p;
+  if (!nsplit || !ws_bytes || !shape_ok(d) || !make_plan(d->Cin, cout_pad, &p)) return SSA_EUNSUPPORTED;
+  const long tiles = (long)d->B * ((d->W + 31) / 32) * ((d->H + 3) / 4);
+  const long per_split = (long)cout_pad * 9 * d->Cin * sizeof(float);
+  static const long budget_mb = getenv("SSA_WGRAD_TILE_MB") ? atol(getenv("SSA_WGRAD_TILE_MB")) : 12;
+  long g = (budget_mb << 20) / per_split;       // bounded partial traffic per layer
+  if (g > 192) g = 192;
+  if (g < 2) g = 2;
+  if (g > tiles) g = tiles;
+  const long tpw = (tiles + g - 1) / g;
+  g = (tiles + tpw - 1) / tpw;
+  *nsplit = (int)g;
+  *ws_bytes = (size_t)g * per_split;
+  return SSA_OK;
+}
+
+int ssa_conv2d_wgrad_tile(const ssa_conv_desc* dp, const void* x, const void* dy, int lddy, int cout_pad,
+                          int nsplit, float* partial, void* stream) {
+  Plan p;
+  if (!dp || !x || !dy || !partial || nsplit < 1) return SSA_EINVAL;
+  if (!shape_ok(dp) || !make_plan(dp->Cin, cout_pad, &p) || lddy % 8) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  const long tiles = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
+  const int tpw = (int)((tiles + nsplit - 1) / nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  switch (d.Cin) {
+    case 48: return launch<48, 2, 14>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+    case 64: return launch<64, 2, 18>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+    case 96: return launch<96, 3, 9>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+    default: return launch<192, 6, 6>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+  }
+}
+
+}  // extern "C"

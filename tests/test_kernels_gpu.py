@@ -199,6 +199,35 @@ def test_conv_bn_fused_stats(C, H, W):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("C,B,H,W", [(48, 1, 37, 45), (64, 2, 20, 33), (96, 1, 64, 64), (192, 1, 21, 40), (384, 1, 9, 33)])
+def test_wgrad_tile_kernel(C, B, H, W):
+    """Halo-staged weight gradient (conv_wgrad_tile.hip, ds_read_b64_tr_b16 fragments):
+    every channel configuration against the oracle.  Not routed by Conv2dFn yet (it only
+    ties the K-pipelined kernel) -- exercised through the C ABI."""
+    import ctypes
+    from oracle import ops as O
+    from semseg_amd._lib import lib, check, ConvDesc
+    x = _rand(B, C, H, W, seed=41)
+    gy = _rand(B, C, H, W, seed=42)
+    w = torch.zeros(C, C, 3, 3, requires_grad=True)
+    O.conv2d(x, w, None, 1, 1, 1).backward(gy)
+    xd = _to_dev_nhwc(x)
+    gd = nhwc(gy).to(DEV).to(torch.bfloat16).contiguous()
+    d = ConvDesc(B, H, W, C, C, H, W, C, C, 3, 3, 1, 1, 1, 0, 0, 0, -1)
+    ns, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+    L = lib()
+    check(L.ssa_conv2d_wgrad_tile_plan(ctypes.byref(d), C, ctypes.byref(ns), ctypes.byref(ws)), "plan")
+    part = torch.empty(ws.value // 4, dtype=torch.float32, device=DEV)
+    dw = torch.empty(C, C, 3, 3, dtype=torch.float32, device=DEV)
+    P = ctypes.c_void_p
+    check(L.ssa_conv2d_wgrad_tile(ctypes.byref(d), P(xd.data_ptr()), P(gd.data_ptr()), C, C, ns.value,
+                                  P(part.data_ptr()), None), "ssa_conv2d_wgrad_tile")
+    check(L.ssa_conv2d_wgrad_reduce(P(part.data_ptr()), ns.value, C, C, C, C, 3, 3, P(dw.data_ptr()), None),
+          "ssa_conv2d_wgrad_reduce")
+    torch.cuda.synchronize()
+    check_close("wgrad tile C=%d" % C, dw, w.grad, 2e-3, 5e-4)
+
+
 def test_batched_filter_repack():
     """refresh_packed_filters (one launch for all stale filters) == per-filter packing."""
     hb = _hb()

@@ -51,6 +51,34 @@ __global__ void cmp_bf16(const bf16_t* y, int ldy, const float* ref, long P, int
   atomicMax((int*)&out[1], __float_as_int(fabsf(r)));
 }
 
+__global__ void ref_wgrad(const bf16_t* x, const bf16_t* dy, float* dw, int B, int H, int W, int Cin, int Cout) {
+  // dw[co][ci][kh][kw], 3x3 stride 1 pad 1; one thread per element
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  long n = (long)Cout * Cin * 9;
+  if (i >= n) return;
+  int kw = i % 3, kh = (i / 3) % 3, ci = (i / 9) % Cin, co = i / (9L * Cin);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int oy = 0; oy < H; ++oy) {
+      int iy = oy + kh - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int ox = 0; ox < W; ++ox) {
+        int ix = ox + kw - 1;
+        if (ix < 0 || ix >= W) continue;
+        acc += __uint_as_float(((uint32_t)dy[((long)(b * H + oy) * W + ox) * Cout + co]) << 16) *
+               __uint_as_float(((uint32_t)x[((long)(b * H + iy) * W + ix) * Cin + ci]) << 16);
+      }
+    }
+  dw[i] = acc;
+}
+
+__global__ void cmp_f32(const float* a, const float* r, long n, float* out) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  atomicMax((int*)&out[0], __float_as_int(fabsf(a[i] - r[i])));
+  atomicMax((int*)&out[1], __float_as_int(fabsf(r[i])));
+}
+
 struct Case { int B, H, W, Cin, Cout, K, stride; const char* name; };
 
 int main(int argc, char** argv) {
@@ -67,7 +95,8 @@ int main(int argc, char** argv) {
     {1, 256, 256, 720, 720, 1, 1, "aux_head.0"}, {1, 256, 256, 512, 256, 1, 1, "f_pixel.0"},
     {1, 256, 256, 64, 256, 1, 1, "layer1 conv3"}, {1, 256, 256, 48, 96, 3, 2, "fuse down 48-96"},
     {1, 37, 45, 48, 48, 3, 1, "ragged 48"}, {2, 40, 24, 96, 96, 3, 1, "ragged 96 B2"},
-    {1, 20, 12, 64, 64, 3, 1, "ragged 64"},
+    {1, 20, 12, 64, 64, 3, 1, "ragged 64"}, {2, 21, 45, 192, 192, 3, 1, "ragged 192 B2"},
+    {1, 9, 33, 384, 384, 3, 1, "ragged 384"},
   };
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -174,6 +203,41 @@ int main(int argc, char** argv) {
       int rc = 0;
       float us = timeit([&] { rc |= ssa_conv2d_halo(&d, dx, dwp, nullptr, dy, nullptr, st); });
       if (rc) printf("%-22s halo failed rc=%d\n", c.name, rc); else check("halo", us);
+    }
+    // ---- weight gradient: K-pipelined kernel vs halo-staged tile kernel, both checked against a naive sum
+    {
+      int ns_t = 0; size_t ws_t = 0;
+      if (c.K == 3 && c.stride == 1 && c.Cin == c.Cout && ssa_conv2d_wgrad_tile_plan(&d, c.Cout, &ns_t, &ws_t) == 0) {
+        std::vector<bf16_t> hdy(Pout * c.Cout);
+        for (auto& v : hdy) v = f2bf_h((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        bf16_t* ddy; float *dwr, *dwo, *part; float* derr2;
+        const long nw = (long)c.Cout * c.Cin * 9;
+        int ns_o = 0; size_t ws_o = 0;
+        ssa_conv2d_wgrad_plan(&d, c.Cout, &ns_o, &ws_o);
+        CK(hipMalloc(&ddy, hdy.size() * 2)); CK(hipMalloc(&dwr, nw * 4)); CK(hipMalloc(&dwo, nw * 4));
+        CK(hipMalloc(&part, ws_o > ws_t ? ws_o : ws_t)); CK(hipMalloc(&derr2, 8));
+        CK(hipMemcpy(ddy, hdy.data(), hdy.size() * 2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ref_wgrad, dim3((nw + 255) / 256), dim3(256), 0, st, dx, ddy, dwr, c.B, c.H, c.W, c.Cin, c.Cout);
+        auto checkw = [&](const char* nm, float us) {
+          CK(hipMemsetAsync(derr2, 0, 8, st));
+          hipLaunchKernelGGL(cmp_f32, dim3((nw + 255) / 256), dim3(256), 0, st, dwo, dwr, nw, derr2);
+          float he[2]; CK(hipMemcpyAsync(he, derr2, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+          printf("%-22s %-14s %9.2f %9.1f %9s %10.5f%s\n", c.name, nm, us, flops / us * 1e-6, "-", he[0] / (he[1] + 1e-30f),
+                 he[0] / (he[1] + 1e-30f) > 5e-3f ? "  <-- MISMATCH" : "");
+        };
+        int rc = 0;
+        float us = timeit([&] { rc |= ssa_conv2d_wgrad(&d, dx, ddy, c.Cout, c.Cout, ns_o, part, st);
+                                rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, st); });
+        char nm[40]; snprintf(nm, sizeof nm, "wgrad old s%d", ns_o);
+        if (rc) printf("%-22s wgrad old failed rc=%d\n", c.name, rc); else checkw(nm, us);
+        CK(hipMemsetAsync(dwo, 0, nw * 4, st));
+        rc = 0;
+        us = timeit([&] { rc |= ssa_conv2d_wgrad_tile(&d, dx, ddy, c.Cout, c.Cout, ns_t, part, st);
+                          rc |= ssa_conv2d_wgrad_reduce(part, ns_t, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, st); });
+        snprintf(nm, sizeof nm, "wgrad tile s%d", ns_t);
+        if (rc) printf("%-22s wgrad tile failed rc=%d\n", c.name, rc); else checkw(nm, us);
+        CK(hipFree(ddy)); CK(hipFree(dwr)); CK(hipFree(dwo)); CK(hipFree(part)); CK(hipFree(derr2));
+      }
     }
     CK(hipFree(dx)); CK(hipFree(dy)); CK(hipFree(dw)); CK(hipFree(dref)); CK(hipFree(derr)); CK(hipFree(dwp)); CK(hipFree(dstats));
   }
