@@ -590,13 +590,56 @@ __device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int* r, i
   }
 }
 
+// All filters of the network in one launch: blockIdx.y = job, blockIdx.x strides over the
+// operand's rows.  A row's source elements are first copied into LDS in SOURCE order
+// (mode 0/2: the Cin*KH*KW contiguous floats of output channel r; mode 1/3: the KH*KW
+// runs of input channel r, one per output channel) so that the OIHW tensor is read with
+// unit stride instead of a stride of KH*KW floats per consecutive k; the permuted,
+// bf16-rounded row is then written from LDS.  Rows that do not fit (48 KiB) fall back to
+// the element-wise gather.
 __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob* __restrict__ jobs) {
+  extern __shared__ float rowbuf[];
   const PackJob j = jobs[blockIdx.y];
-  const long n = (long)j.rows * j.Kpad;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    int r, k;
-    pack_index(i, j.Kpad, j.mode, &r, &k);
-    j.out[i] = pack_one(j.w, j.Cout, j.Cin, j.KH, j.KW, j.cin_pad, j.cout_pad, j.mode & 1, r, k);
+  const int taps = j.KH * j.KW;
+  const int transposed = j.mode & 1;
+  const int rows_real = transposed ? j.Cin : j.Cout;      // rows that carry data
+  const int csrc = transposed ? j.Cout : j.Cin;            // channels along k in the source
+  const int cpad = transposed ? j.cout_pad : j.cin_pad;
+  const bool fits = (long)csrc * taps * sizeof(float) <= 48 * 1024;
+  const int ksteps = j.Kpad >> 4;
+  for (int r = blockIdx.x; r < j.rows; r += gridDim.x) {
+    if (fits && r < rows_real) {
+      __syncthreads();
+      if (!transposed) {
+        const float* src = j.w + (long)r * csrc * taps;
+        for (int i = threadIdx.x; i < csrc * taps; i += 256) rowbuf[i] = src[i];
+      } else {
+        for (int i = threadIdx.x; i < csrc * taps; i += 256) {
+          const int co = i / taps, t = i - co * taps;
+          rowbuf[i] = j.w[((long)co * j.Cin + r) * taps + t];
+        }
+      }
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < j.Kpad; k += 256) {
+      float v = 0.f;
+      if (r < rows_real) {
+        const int tap = k / cpad, c = k - tap * cpad;
+        if (tap < taps && c < csrc) {
+          const int tsrc = transposed ? (taps - 1 - tap) : tap;     // flipped taps for the data gradient
+          v = fits ? rowbuf[c * taps + tsrc]
+                   : (transposed ? j.w[((long)c * j.Cin + r) * taps + tsrc] : j.w[((long)r * j.Cin + c) * taps + tsrc]);
+        }
+      }
+      long o;
+      if (j.mode < 2) {
+        o = (long)r * j.Kpad + k;
+      } else {
+        const int kk = k & 15;
+        o = ((((long)(r >> 5) * ksteps + (k >> 4)) * 64) + (r & 31) + 32 * (kk >> 3)) * 8 + (kk & 7);
+      }
+      j.out[o] = f2bf(v);
+    }
   }
 }
 
@@ -835,7 +878,7 @@ int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int 
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job, void* stream) {
   if (!jobs_dev || njobs < 1 || blocks_per_job < 1) return SSA_EINVAL;
   static_assert(sizeof(PackJob) == 64, "ssa_pack_job layout");
-  hipLaunchKernelGGL(pack_filters_batched_kernel, dim3(blocks_per_job, njobs), dim3(256), 0,
+  hipLaunchKernelGGL(pack_filters_batched_kernel, dim3(blocks_per_job, njobs), dim3(256), 48 * 1024,
                      (hipStream_t)stream, (const PackJob*)jobs_dev);
   SSA_LAUNCH_CHECK();
   return SSA_OK;

@@ -106,7 +106,7 @@ def refresh_packed_filters():
         arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         _JOB_TABLE.update(key=tkey, dev=host.to(stale[0][2].device), n=len(stale))
-    check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 8, _s()),
+    check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 32, _s()),
           "ssa_pack_filters_batched")
     for _, e, w in stale:
         e.version = w._version

@@ -234,8 +234,9 @@ def test_batched_filter_repack():
     hb.clear_pack_cache()
     ws = [torch.randn(48, 48, 3, 3, device=DEV), torch.randn(19, 512, 1, 1, device=DEV),
           torch.randn(96, 48, 3, 3, device=DEV), torch.randn(64, 3, 3, 3, device=DEV)]
-    specs = [(0, 48, 0), (1, 0, 48), (0, 512, 0), (1, 0, 24), (0, 48, 0), (1, 0, 96), (0, 16, 0)]
-    owners = [0, 0, 1, 1, 2, 2, 3]
+    specs = [(0, 48, 0), (1, 0, 48), (0, 512, 0), (1, 0, 24), (0, 48, 0), (1, 0, 96), (0, 16, 0),
+             (2, 48, 0), (3, 0, 48), (2, 512, 0), (2, 48, 0), (3, 0, 96), (2, 16, 0)]     # fragment-major forms
+    owners = [0, 0, 1, 1, 2, 2, 3, 0, 0, 1, 2, 2, 3]
     first = [hb._packed_filter(ws[o], *sp)[0] for o, sp in zip(owners, specs)]
     for w in ws:
         w.mul_(-0.5).add_(0.25)                # in-place update, like an optimizer step
