@@ -33,7 +33,8 @@ TILE_NAMES = {0: "conv_igemm_kernel<2,2,2,2> (128x128)", 1: "conv_igemm_kernel<4
               2: "conv_igemm_kernel<4,1,1,3> (128x96)", 3: "conv_igemm_kernel<4,1,2,1> (256x32)",
               4: "conv_igemm_kernel<2,2,1,1> (64x64)", 5: "conv_igemm_kernel<2,2,2,1> (128x64)",
               100: "conv_tile_kernel (halo tile, 128/256 px x Cout)",
-              101: "conv_halo_gemm_kernel (256 px x 128 ch, halo chunks)", -1: "conv_wgrad_tr_kernel"}
+              101: "conv_halo_gemm_kernel (256 px x 128 ch, halo chunks)", -1: "conv_wgrad_tr_kernel",
+              102: "conv_wgrad_head_kernel (128 co x 128 ci x 3 kw, persistent)"}
 
 
 def synth_batch(B, H, W, rank, device):
@@ -162,6 +163,10 @@ def main():
     model = net
     if world > 1:
         from semseg_amd.parallel import DistributedDataParallel
+        from semseg_amd import ops as sops
+        # N > 1 runs eager (no hipGraph around RCCL calls): the step is host-launch bound, where
+        # the second stream buys nothing -- keep every collective on one stream
+        sops.backend().concurrency = 0
         model = DistributedDataParallel(net)
     optim = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     images, gts = synth_batch(args.batch, args.crop, args.crop, rank, "cuda")
@@ -260,7 +265,7 @@ def main():
         # collected offline into profiles/ (rocprofv3 cannot run inside this process)
         traffic, traffic_src = None, None
         fam = {"wgrad": "conv_wgrad_tr_kernel", "tile": "conv_tile_kernel", "halo": "conv_halo_gemm_kernel",
-               "igemm": "conv_igemm_kernel"}.get(kind)
+               "igemm": "conv_igemm_kernel", "wgrad_head": "conv_wgrad_head_kernel"}.get(kind)
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if fam and os.path.exists(pmc):
             with open(pmc) as f:

@@ -134,6 +134,17 @@ int ssa_conv2d_wgrad_tile(const ssa_conv_desc* d, const void* x, const void* dy,
                           int lddy, int cout_pad, int nsplit, float* partial,
                           void* stream);
 
+/* Weight gradient of the large-channel 3x3 / 1x1 stride-1 head convs (Cin >= 128,
+ * >= 16 K pixels): 8-wave workgroups persistent over 128-pixel tiles hold a
+ * 128(co) x 128(ci) x 3(kw) [3x3] or 128 x 256 [1x1] block of dW in MFMA
+ * accumulators; LDS images pixel-major, transposing fragment reads.  Partial
+ * layout as ssa_conv2d_wgrad -> finish with ssa_conv2d_wgrad_reduce.            */
+int ssa_conv2d_wgrad_head_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit,
+                               size_t* ws_bytes);
+int ssa_conv2d_wgrad_head(const ssa_conv_desc* d, const void* x, const void* dy,
+                          int lddy, int cout_pad, int nsplit, float* partial,
+                          void* stream);
+
 /* Column sum over pixels: out[c] = sum_p x[p, c]  (bias gradient). x bf16. */
 int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out,
                     double* scratch2c, void* stream);

@@ -11,6 +11,7 @@
 // per-channel accumulators live in registers and every wave-level access is a
 // contiguous run of 16-byte pieces.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -415,7 +416,13 @@ __global__ __launch_bounds__(128) void bn_update_running_kernel(const BnUpdateJo
 struct Grid { int blocks; long ppb; };
 // rows_per_thread pixel rows per thread; at most max_blocks workgroups (the
 // reducing kernels end in 2C fp64 atomics per workgroup, so they get a lower cap).
-Grid plan_grid(long P, int C, int rows_per_thread = 4, long max_blocks = 16384) {
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+Grid plan_grid(long P, int C, int rows_per_thread = -1, long max_blocks = 16384) {
+  static const int apply_rows = env_int("SSA_BN_ROWS_APPLY", 2);
+  if (rows_per_thread < 0) rows_per_thread = apply_rows;
   const int VC = C >> 3;
   const int RP = active_threads(VC) / VC;
   long ppb = (long)RP * rows_per_thread;
@@ -429,7 +436,10 @@ Grid plan_grid(long P, int C, int rows_per_thread = 4, long max_blocks = 16384) 
   if (blocks < 1) blocks = 1;
   return {(int)blocks, ppb};
 }
-Grid plan_reduce_grid(long P, int C) { return plan_grid(P, C, 8, 1024); }
+Grid plan_reduce_grid(long P, int C) {
+  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 4), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
+  return plan_grid(P, C, rows, cap);
+}
 
 bool ok_c(int C) { return C > 0 && C % 8 == 0 && C <= 2048; }
 

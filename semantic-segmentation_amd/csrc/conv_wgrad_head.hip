@@ -1,0 +1,247 @@
+// Weight gradient of the large-channel head convolutions (conv3x3_ocr 720->512,
+// attn 512->256 / 256->256, the 1x1 convs 1024->512, 720->720, 512->256, ...;
+// network/ocrnet.py:54-58, network/utils.py:348-357, network/ocr_utils.py:68-93):
+//
+//   dW[co][tap][ci] = sum over pixels p of  dy[p][co] * x[p + tap][ci]
+//
+// GEMM with M = co, N = (tap, ci), K = pixels (65,536 per image at 1024x1024).
+// One workgroup (8 wave64s) owns a 128(co) x 128(ci) x 3(kw)  [3x3, one kernel row
+// kh]  or a 128(co) x 256(ci)  [1x1]  block of dW in MFMA accumulators and is
+// PERSISTENT over a strip of 128-pixel tiles (4 rows x 32 columns):
+//   * per tile the dy tile and the x rows it needs (4 x 34 pixels for the three kw
+//     shifts of one kh) are staged in LDS pixel-major, exactly as they lie in HBM;
+//     the three taps reuse the same x image at shifted pixel offsets;
+//   * both MFMA operands want 8 consecutive PIXELS per lane for one channel:
+//     ds_read_b64_tr_b16 transposing reads, pixel stride 64*odd bytes (conflict free);
+//   * the next tile's global loads are issued into registers before the current
+//     tile's MFMAs and stored to LDS after them (one barrier pair per tile);
+//   * blockIdx.x = pixel split: only G = 256 / (#output blocks) partials per layer
+//     ([G][cout_pad][taps*Cin] fp32, summed by wgrad_reduce_kernel).
+// Replaces the K-pipelined conv_wgrad_tr_kernel (195 TFLOP/s on 720->512) for these shapes.
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__host__ __device__ constexpr int trs(int row_bytes) {   // smallest 64*odd >= row_bytes
+  int s = (row_bytes + 63) / 64;
+  if ((s & 1) == 0) ++s;
+  return s * 64;
+}
+
+__device__ __forceinline__ bf16x8_t tr8(const unsigned char* p, int stride_bytes) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(p + 4 * stride_bytes));
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// KS = 3: NT = 3 (the kw taps of kernel row kh), 128 input channels per workgroup.
+// KS = 1: NT = 2 (two 32-channel blocks per wave), 256 input channels per workgroup.
+template <int KS>
+__global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
+    const bf16_t* __restrict__ x, int ldx, int Cin, const bf16_t* __restrict__ dy, int lddy,
+    int cout_pad, int B, int H, int W, int tiles_x, int tiles_y, int tiles_per_wg, int ci_tiles,
+    float* __restrict__ partial) {
+  constexpr int TW = 32, TH = 4, NT = KS == 3 ? 3 : 2;
+  constexpr int CX = KS == 3 ? 128 : 256;                // input channels per workgroup
+  constexpr int XW = KS == 3 ? TW + 2 : TW;              // x image width in pixels
+  constexpr int SX = trs(CX * 2), SD = trs(256);
+  constexpr int X_BYTES = TH * XW * SX;
+  constexpr int XP = CX / 8, DP = 16;                    // 16-byte pieces per pixel
+  constexpr int XN = TH * XW * XP, DN = TH * TW * DP;
+  constexpr int XI = (XN + 511) / 512, DI = (DN + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Xs = smem;
+  unsigned char* Ds = smem + X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // blockIdx.y -> (co tile, ci tile, kh)
+  int by = blockIdx.y;
+  const int kh = KS == 3 ? by % 3 : 0;
+  if (KS == 3) by /= 3;
+  const int ci_t = by % ci_tiles, co_t = by / ci_tiles;
+  const int co0 = co_t * 128, ci0 = ci_t * CX;
+  const int taps = KS * KS, Kflat = taps * Cin;
+
+  const int li = lane & 15, lj = li >> 2, lq = li & 3, lg = (lane >> 4) & 1, lh = lane >> 5;
+  // B fragment j of this wave: KS=3 -> tap (kh, kw=j), channel block wn; KS=1 -> channel block 2*wn+j
+  int b_off[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cblk = KS == 3 ? wn : 2 * wn + j;
+    const int shift = KS == 3 ? j : 0;
+    b_off[j] = shift * SX + (cblk * 32 + 16 * lg + 4 * lq) * 2;
+  }
+  const int a_col = (16 * lg + 4 * lq) * 2;
+
+  f32x16_t acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+  const int total_tiles = B * tiles_x * tiles_y;
+  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_end = min(total_tiles, t_begin + tiles_per_wg);
+  uint4 xv[XI], dv[DI];
+  auto fetch = [&](int t) {
+    int r_ = t;
+    const int tx_i = r_ % tiles_x; r_ /= tiles_x;
+    const int ty_i = r_ % tiles_y;
+    const int b = r_ / tiles_y;
+    const int x0 = tx_i * TW, y0 = ty_i * TH;
+    const int yoff = KS == 3 ? kh - 1 : 0, xoff = KS == 3 ? -1 : 0;
+    const bf16_t* xb = x + (long)b * H * W * ldx + ci0;
+    const bf16_t* db = dy + (long)b * H * W * lddy + co0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int piece = tid + i * 512;
+      const int pix = piece / XP, cp = piece - pix * XP;
+      const int hy = pix / XW, hx = pix - hy * XW;
+      const int iy = y0 + hy + yoff, ix = x0 + hx + xoff;
+      const bool ok = piece < XN && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci0 + cp * 8 < Cin;
+      xv[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cp * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int piece = tid + i * 512;
+      const int pix = piece / DP, cp = piece - pix * DP;
+      const int oy = y0 + pix / TW, ox = x0 + pix % TW;
+      const bool ok = piece < DN && oy < H && ox < W && co0 + cp * 8 < cout_pad;
+      dv[i] = ok ? *reinterpret_cast<const uint4*>(db + ((long)oy * W + ox) * lddy + cp * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int piece = tid + i * 512;
+      if (piece < XN) *reinterpret_cast<uint4*>(Xs + (piece / XP) * SX + (piece % XP) * 16) = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int piece = tid + i * 512;
+      if (piece < DN) *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = dv[i];
+    }
+  };
+
+  if (t_begin < t_end) fetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t > t_begin) __syncthreads();          // previous tile's fragments are read
+    stage();
+    __syncthreads();
+    if (t + 1 < t_end) fetch(t + 1);           // next tile's loads fly during this tile's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {           // 16 pixels (half a tile row) per k-step
+      const int ty = ks >> 1, kp = (ks & 1) * 16 + 8 * lh + lj;
+      bf16x8_t af[2], bfr[NT];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        af[m] = tr8(Ds + (ty * TW + kp) * SD + (wm * 2 + m) * 64 + a_col, SD);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bfr[j] = tr8(Xs + (ty * XW + kp) * SX + b_off[j], SX);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[j], acc[m][j], 0, 0, 0);
+    }
+  }
+
+  float* out = partial + (long)blockIdx.x * cout_pad * Kflat;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int cblk = KS == 3 ? wn : 2 * wn + j;
+      const int ci = ci0 + cblk * 32 + (lane & 31);
+      const int tap = KS == 3 ? kh * 3 + j : 0;
+      if (ci >= Cin) continue;
+      const long kcol = (long)tap * Cin + ci;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[m][j][r];
+      }
+    }
+}
+
+bool head_shape_ok(const ssa_conv_desc* d, int cout_pad) {
+  if (!d || d->KH != d->KW || (d->KH != 3 && d->KH != 1)) return false;
+  if (d->stride != 1 || d->dil != 1 || d->pad != d->KH / 2 || d->transposed) return false;
+  if (d->Ho != d->H || d->Wo != d->W || d->ldx % 8 || d->Cin % 8 || cout_pad % 8) return false;
+  // large-channel layers on large images only: small ones are latency bound either way
+  return d->Cin >= 128 && cout_pad >= 64 && d->W >= 32 && (long)d->B * d->H * d->W >= 16384;
+}
+
+struct HeadPlan { int co_tiles, ci_tiles, wgs_y, G, tpw; long per_split; };
+
+HeadPlan head_plan(const ssa_conv_desc& d, int cout_pad) {
+  HeadPlan p;
+  const int cx = d.KH == 3 ? 128 : 256;
+  p.co_tiles = (cout_pad + 127) / 128;
+  p.ci_tiles = (d.Cin + cx - 1) / cx;
+  p.wgs_y = p.co_tiles * p.ci_tiles * (d.KH == 3 ? 3 : 1);
+  const long tiles = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
+  long g = 256 / p.wgs_y;                         // one workgroup per CU
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles;
+  p.tpw = (int)((tiles + g - 1) / g);
+  p.G = (int)((tiles + p.tpw - 1) / p.tpw);
+  p.per_split = (long)cout_pad * d.KH * d.KW * d.Cin * sizeof(float);
+  return p;
+}
+
+template <int KS>
+int launch_head(const ssa_conv_desc& d, const HeadPlan& p, const void* x, const void* dy, int lddy,
+                int cout_pad, float* partial, hipStream_t s) {
+  constexpr int XW = KS == 3 ? 34 : 32, CX = KS == 3 ? 128 : 256;
+  constexpr size_t lds = (size_t)4 * XW * trs(CX * 2) + (size_t)128 * trs(256);
+  static_assert(lds <= 160 * 1024, "does not fit in LDS");
+  auto kern = conv_wgrad_head_kernel<KS>;
+  static bool once = false;
+  if (!once) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    once = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.G, p.wgs_y), dim3(512), lds, s, (const bf16_t*)x, d.ldx, d.Cin,
+                     (const bf16_t*)dy, lddy, cout_pad, d.B, d.H, d.W, (d.W + 31) / 32, (d.H + 3) / 4, p.tpw,
+                     p.ci_tiles, partial);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_conv2d_wgrad_head_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, size_t* ws_bytes) {
+  if (!nsplit || !ws_bytes || !head_shape_ok(d, cout_pad)) return SSA_EUNSUPPORTED;
+  const HeadPlan p = head_plan(*d, cout_pad);
+  *nsplit = p.G;
+  *ws_bytes = (size_t)p.G * p.per_split;
+  return SSA_OK;
+}
+
+int ssa_conv2d_wgrad_head(const ssa_conv_desc* dp, const void* x, const void* dy, int lddy, int cout_pad,
+                          int nsplit, float* partial, void* stream) {
+  if (!dp || !x || !dy || !partial) return SSA_EINVAL;
+  if (!head_shape_ok(dp, cout_pad) || lddy % 8) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) return SSA_EINVAL;
+  const HeadPlan p = head_plan(*dp, cout_pad);
+  if (nsplit != p.G) return SSA_EINVAL;
+  if (dp->KH == 3) return launch_head<3>(*dp, p, x, dy, lddy, cout_pad, partial, (hipStream_t)stream);
+  return launch_head<1>(*dp, p, x, dy, lddy, cout_pad, partial, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -331,17 +331,24 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
     nsplit = ctypes.c_int(0)
     ws = ctypes.c_size_t(0)
     L = lib()
-    check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
-          "ssa_conv2d_wgrad_plan")
+    # large-channel head convs: persistent 8-wave kernel (conv_wgrad_head.hip); everything else:
+    # the K-pipelined kernel
+    head = (x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and
+            L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0)
+    if not head:
+        check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
+              "ssa_conv2d_wgrad_plan")
     partial = torch.empty((ws.value // 4,), dtype=torch.float32, device=x.device)
     if _PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.ssa_conv2d_wgrad(ctypes.byref(d), _p(x), _p(dy), lddy, cout_pad, nsplit.value, _p(partial), _s()),
-          "ssa_conv2d_wgrad")
+    fn = L.ssa_conv2d_wgrad_head if head else L.ssa_conv2d_wgrad
+    check(fn(ctypes.byref(d), _p(x), _p(dy), lddy, cout_pad, nsplit.value, _p(partial), _s()),
+          "ssa_conv2d_wgrad_head" if head else "ssa_conv2d_wgrad")
     if _PROFILE is not None:
         e1.record()
-        _PROFILE.append(("wgrad", -1, 2.0 * B * Ho * Wo * Cout * Cin_real * k[0] * k[1], e0, e1,
+        _PROFILE.append(("wgrad_head" if head else "wgrad", 102 if head else -1,
+                         2.0 * B * Ho * Wo * Cout * Cin_real * k[0] * k[1], e0, e1,
                          (k[0], stride, Cin, Cout, Ho, Wo)))
     dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
     check(L.ssa_conv2d_wgrad_reduce(_p(partial), nsplit.value, cout_pad, Cout, Cin, Cin_real, k[0], k[1],

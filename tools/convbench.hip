@@ -96,7 +96,8 @@ int main(int argc, char** argv) {
     {1, 256, 256, 64, 256, 1, 1, "layer1 conv3"}, {1, 256, 256, 48, 96, 3, 2, "fuse down 48-96"},
     {1, 37, 45, 48, 48, 3, 1, "ragged 48"}, {2, 40, 24, 96, 96, 3, 1, "ragged 96 B2"},
     {1, 20, 12, 64, 64, 3, 1, "ragged 64"}, {2, 21, 45, 192, 192, 3, 1, "ragged 192 B2"},
-    {1, 9, 33, 384, 384, 3, 1, "ragged 384"},
+    {1, 9, 33, 384, 384, 3, 1, "ragged 384"}, {1, 130, 131, 200, 136, 3, 1, "ragged head 3x3"},
+    {2, 100, 97, 264, 72, 1, 1, "ragged head 1x1"},
   };
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -237,6 +238,36 @@ int main(int argc, char** argv) {
         snprintf(nm, sizeof nm, "wgrad tile s%d", ns_t);
         if (rc) printf("%-22s wgrad tile failed rc=%d\n", c.name, rc); else checkw(nm, us);
         CK(hipFree(ddy)); CK(hipFree(dwr)); CK(hipFree(dwo)); CK(hipFree(part)); CK(hipFree(derr2));
+      }
+    }
+    // ---- head weight gradient (large channels): new persistent kernel vs the K-pipelined one
+    {
+      int ns_h = 0; size_t ws_h = 0;
+      if (c.stride == 1 && ssa_conv2d_wgrad_head_plan(&d, c.Cout, &ns_h, &ws_h) == 0) {
+        std::vector<bf16_t> hdy(Pout * c.Cout);
+        for (auto& v : hdy) v = f2bf_h((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        bf16_t* ddy; float *dw_old, *dw_new, *part, *derr2;
+        const long nw = (long)c.Cout * c.Cin * c.K * c.K;
+        int ns_o = 0; size_t ws_o = 0;
+        ssa_conv2d_wgrad_plan(&d, c.Cout, &ns_o, &ws_o);
+        CK(hipMalloc(&ddy, hdy.size() * 2)); CK(hipMalloc(&dw_old, nw * 4)); CK(hipMalloc(&dw_new, nw * 4));
+        CK(hipMalloc(&part, ws_o > ws_h ? ws_o : ws_h)); CK(hipMalloc(&derr2, 8));
+        CK(hipMemcpy(ddy, hdy.data(), hdy.size() * 2, hipMemcpyHostToDevice));
+        int rc = 0;
+        float us_old = timeit([&] { rc |= ssa_conv2d_wgrad(&d, dx, ddy, c.Cout, c.Cout, ns_o, part, st);
+                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_old, st); });
+        if (rc) printf("%-22s wgrad old failed rc=%d\n", c.name, rc);
+        rc = 0;
+        float us_new = timeit([&] { rc |= ssa_conv2d_wgrad_head(&d, dx, ddy, c.Cout, c.Cout, ns_h, part, st);
+                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_h, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_new, st); });
+        CK(hipMemsetAsync(derr2, 0, 8, st));
+        hipLaunchKernelGGL(cmp_f32, dim3((nw + 255) / 256), dim3(256), 0, st, dw_new, dw_old, nw, derr2);
+        float he[2]; CK(hipMemcpyAsync(he, derr2, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+        printf("%-22s wgrad old s%-4d  %9.2f %9.1f\n", c.name, ns_o, us_old, flops / us_old * 1e-6);
+        if (rc) printf("%-22s wgrad head failed rc=%d\n", c.name, rc);
+        else printf("%-22s wgrad head s%-3d  %9.2f %9.1f   max|new-old|/max|old| %.6f%s\n", c.name, ns_h, us_new,
+                    flops / us_new * 1e-6, he[0] / (he[1] + 1e-30f), he[0] / (he[1] + 1e-30f) > 2e-3f ? "  <-- MISMATCH" : "");
+        CK(hipFree(ddy)); CK(hipFree(dw_old)); CK(hipFree(dw_new)); CK(hipFree(part)); CK(hipFree(derr2));
       }
     }
     CK(hipFree(dx)); CK(hipFree(dy)); CK(hipFree(dw)); CK(hipFree(dref)); CK(hipFree(derr)); CK(hipFree(dwp)); CK(hipFree(dstats));
