@@ -241,10 +241,15 @@ def main():
         agg = {}
         for kind, tile, flops, e0, e1, shape in store:
             key = (kind, tile)
-            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            # algorithmic HBM bytes of the launch: bf16 input + output once,
+            # the filter once (fp32 dW for a weight gradient); batch = args.batch
+            kk, st, ci, co, ho, wo = shape
+            pix = args.batch * ho * wo
+            a[3] += 2.0 * (pix * st * st * ci + pix * co) + (4.0 if kind.startswith("wgrad") else 2.0) * co * ci * kk * kk
         if os.environ.get("SSA_DUMP_SHAPES"):
             per = {}
             for kind, tile, flops, e0, e1, shape in store:
@@ -258,7 +263,7 @@ def main():
                          v[0] / v[1] / 1e12, v[1] / 2 * 1e3), file=sys.stderr)
         tot_t = sum(a[1] for a in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])      # most time
-        (kind, tile), (fl, tt, n) = dom
+        (kind, tile), (fl, tt, n, by) = dom
         name = TILE_NAMES.get(tile, kind)
         # HBM bytes per launch of that kernel family: PMC counters (FETCH_SIZE, WRITE_SIZE in separate
         # rocprofv3 passes over this same command, corrected as MI355X_MICROARCH.md prescribes) --
@@ -276,9 +281,15 @@ def main():
                 "unit": "TFLOP/s", "frac": fl / tt / PEAK_BF16_MFMA, "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "launches_per_step": n // 2, "avg_launch_us": tt / n * 1e6,
-                "flop_per_launch": fl / n, "gemm_time_share_of_step": tot_t / 2 / (ms * 1e-3),
+                "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
+                "hbm_achieved_GBps": by / tt / 1e9, "hbm_frac_of_8TBps": by / tt / 8e12,
+                "note": "dominant = the conv-class kernel family with the most time in an eager, single-stream "
+                        "pass (per-launch HIP events on the launch stream); its layers are a mix of HBM-bound "
+                        "(48 ch: 216 FLOP/B) and MFMA-bound shapes, both fractions are given",
+                "gemm_time_share_of_step": tot_t / 2 / (ms * 1e-3),
                 "all_gemm_kernels": {("%s/%s" % (k[0], TILE_NAMES.get(k[1], "-"))): {
-                    "tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / 2 * 1e3, "launches_per_step": v[2] // 2}
+                    "tflops": v[0] / v[1] / 1e12, "hbm_GBps": v[3] / v[1] / 1e9, "ms_per_step": v[1] / 2 * 1e3,
+                    "launches_per_step": v[2] // 2}
                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
 
     cpu = None

@@ -72,7 +72,7 @@ from ._lib import PackJob
 
 
 class _Packed:
-    __slots__ = ("wref", "out", "Kpad", "version", "job")
+    __slots__ = ("wref", "out", "Kpad", "version", "job", "shape")
 
 
 _PACKED = {}
@@ -115,7 +115,9 @@ def refresh_packed_filters():
 def _packed_filter(weight, mode, cin_pad, cout_pad):
     key = (weight.data_ptr(), mode, cin_pad, cout_pad)
     e = _PACKED.get(key)
-    if e is not None and e.wref() is weight and e.version == weight._version:
+    # same storage + same version counter = same values: also true for the detached "shadow"
+    # leaves the 0.5x pass runs on (MscaleOCR._shadow_parameters), which alias the parameter
+    if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
     if mode & 1 == 0:
@@ -130,8 +132,9 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     direct = w.dtype == torch.float32 and w.is_contiguous()
     if not direct:
         w = w.float().contiguous()
-    if e is None or e.wref() is not weight:
+    if e is None or e.wref() is None or e.shape != tuple(weight.shape):
         e = _Packed()
+        e.shape = tuple(weight.shape)
         e.out = torch.empty((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)
         e.Kpad = Kpad
         e.wref = weakref.ref(weight)

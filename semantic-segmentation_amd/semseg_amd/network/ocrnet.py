@@ -6,7 +6,9 @@ Drop-in for the reference's network/ocrnet.py: same factories
 predictions in eval), same state_dict.  Internally everything is NHWC bf16 on
 the HIP kernels; the NCHW tensors handed back are zero-copy permuted views.
 """
+import torch
 from torch import nn
+from torch.nn.utils import stateless
 
 from .. import ops
 from ..config import cfg
@@ -147,9 +149,16 @@ class MscaleOCR(_Base):
         (network/ocrnet.py:264-327)."""
         B = ops.backend()
 
+        shadow = None
+        if self.training and torch.is_grad_enabled() and getattr(B, "use_shadow_pass", lambda: False)():
+            shadow = self._shadow_parameters()
+
         def lo_pass():
             x_lo, lo_size = self._images(inputs, cfg.MODEL.MSCALE_LO_SCALE)
-            return self._fwd(x_lo, lo_size)
+            if shadow is None:
+                return self._fwd(x_lo, lo_size)
+            with stateless._reparametrize_module(self, shadow):
+                return self._fwd(x_lo, lo_size)
 
         def hi_pass():
             x_1x, size = self._images(inputs)
@@ -176,9 +185,49 @@ class MscaleOCR(_Base):
                 loss_lo = self.criterion(_nchw(B.bilinear(pred_05x, size)), gts, do_rmi=False)
                 loss_hi = self.criterion(_nchw(pred_10x), gts, do_rmi=False)
                 loss = loss + wt * loss_lo + wt * loss_hi
+            if shadow is not None and loss.requires_grad:
+                loss.register_hook(self._arm_shadow_merge)
             return loss
         return {"pred": _nchw(joint_pred), "pred_05x": _nchw(pred_05x), "pred_10x": _nchw(pred_10x),
                 "attn_05x": _nchw(attn_05x)}
+
+    # -- gradients of the 0.5x pass ------------------------------------------------------
+    # Both passes use every parameter, so autograd would add the two contributions with one
+    # `add` kernel per parameter (955 launches per step).  Instead the 0.5x pass runs on detached
+    # aliases (same storage, separate autograd leaves) and ONE multi-tensor add merges their
+    # gradients into the parameters' at the end of backward.
+    def _shadow_parameters(self):
+        cur = getattr(self, "_shadow", None)
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if cur is None or len(cur[0]) != len(named) or any(
+                s.data_ptr() != p.data_ptr() or s.shape != p.shape for (_, p), s in zip(named, cur[0].values())):
+            cur = ({n: p.detach().requires_grad_(True) for n, p in named}, [p for _, p in named])
+            object.__setattr__(self, "_shadow", cur)
+        return cur[0]
+
+    def _arm_shadow_merge(self, grad):
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(self._merge_shadow_grads)
+        return None
+
+    def _merge_shadow_grads(self):
+        shadows, params = self._shadow
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        if main is not None:
+            for st in getattr(ops.backend(), "side_streams", lambda: [])():
+                main.wait_stream(st)             # the 0.5x pass's gradients were produced there
+        dst, src = [], []
+        for p, s in zip(params, shadows.values()):
+            if s.grad is None:
+                continue
+            if p.grad is None:
+                p.grad = s.grad
+            else:
+                dst.append(p.grad)
+                src.append(s.grad)
+            s.grad = None
+        if dst:
+            torch._foreach_add_(dst, src)
 
     def forward(self, inputs):
         ops.backend().begin_step(inputs["images"].device)

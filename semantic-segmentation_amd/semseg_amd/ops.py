@@ -40,6 +40,18 @@ class HipBackend:
     # fork/join events cost more than the overlap buys at this size; at 256x256 the
     # branches alone give 70.3 -> 60.1) -- hence the default of 1.
     concurrency = int(os.environ.get("SSA_CONCURRENCY", "1"))
+    # The 0.5x pass runs on detached aliases of the parameters and its gradients are added to the
+    # 1.0x pass's by ONE multi-tensor add at the end of backward, instead of autograd's 955
+    # per-parameter `add` launches (MscaleOCR._shadow_parameters).  Off under torch.distributed:
+    # DDP's per-parameter hooks must see the complete gradient.
+    shadow_lo_pass = os.environ.get("SSA_SHADOW", "1") != "0"
+
+    def use_shadow_pass(self):
+        import torch.distributed as dist
+        return self.shadow_lo_pass and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def side_streams(self):
+        return list(self._streams.values())
     _streams = {}
     _side_handles = set()
 

@@ -25,6 +25,14 @@ class OracleBackend:
     def end_forward(self):
         pass
 
+    shadow = False              # tests flip this to exercise MscaleOCR's shadow-parameter gradient merge
+
+    def use_shadow_pass(self):
+        return self.shadow
+
+    def side_streams(self):
+        return []
+
     def parallel(self, thunks, level=1):
         # issue order of HipBackend.parallel: thunks[1:] first, thunks[0] last
         outs = [None] * len(thunks)
