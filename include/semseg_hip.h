@@ -60,6 +60,12 @@ typedef struct ssa_conv_desc {
 int ssa_conv2d_igemm(const ssa_conv_desc* d, const void* x, const void* w_packed,
                      const float* bias, void* y, void* stream);
 
+/* Same, with the BatchNorm batch statistics of the bf16-rounded outputs accumulated in
+ * the epilogue (stats: [ssa_bn_stat_replicas()][2][Cout] fp64, caller clears; bf16
+ * output, forward form only) -- replaces the ssa_bn_stats pass after the conv.        */
+int ssa_conv2d_igemm_stats(const ssa_conv_desc* d, const void* x, const void* w_packed,
+                           const float* bias, void* y, double* stats, void* stream);
+
 /* Halo-tile convolution for the small-channel 3x3 stride-1 "same" convs of the
  * HRNet branches (Cin in {48, 64, 96}): the input halo tile is staged in LDS
  * once, all taps are computed from it, the filter streams from L2 in fragment

@@ -57,7 +57,8 @@ __device__ __forceinline__ void mma_stage(const bf16_t* __restrict__ As,
 template <int WGM, int WGN, int MI, int NI>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
     ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-    const float* __restrict__ bias, void* __restrict__ yv, int tiles_n, int tr_shift) {
+    const float* __restrict__ bias, void* __restrict__ yv, int tiles_n, int tr_shift,
+    double* __restrict__ stats) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
   constexpr int PPR = BK / 8;
   constexpr int RPP = NT / PPR;
@@ -188,20 +189,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
   }
   constexpr int LDC = BN + 8;
   bf16_t* Cs = lds;  // safe: the K loop ended on a barrier
+  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [WGM][2][BN] BN-statistics partials
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = wn * NI * 32 + ni * 32 + (lane & 31);
+    const int n = n0 + col;
+    const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+    float ssum = 0.f, sq = 0.f;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = wn * NI * 32 + ni * 32 + (lane & 31);
-      const int n = n0 + col;
-      const float bv = (bias != nullptr && n < d.Cout) ? bias[n] : 0.f;
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        Cs[row * LDC + col] = f2bf(acc[mi][ni][r] + bv);
+        const bf16_t o = f2bf(acc[mi][ni][r] + bv);
+        Cs[row * LDC + col] = o;
+        if (stats != nullptr) {          // batch statistics of the bf16-rounded outputs (fused bn_stats)
+          const float f = (m0 + row < M) ? bf2f(o) : 0.f;
+          ssum += f;
+          sq += f * f;
+        }
       }
     }
+    if (stats != nullptr) {
+      ssum += __shfl_xor(ssum, 32, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * BN + col] = ssum;
+        red[(wm * 2 + 1) * BN + col] = sq;
+      }
+    }
+  }
   __syncthreads();
+  if (stats != nullptr) {
+    double* st = stats + (long)(blockIdx.x % 8) * 2 * d.Cout;     // replica, as conv_tile.hip
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int which = i / BN, col = i - which * BN;
+      const int n = n0 + col;
+      if (n < d.Cout) {
+        float v = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < WGM; ++w_) v += red[(w_ * 2 + which) * BN + col];
+        atomicAdd(&st[which * d.Cout + n], (double)v);
+      }
+    }
+  }
   bf16_t* y = reinterpret_cast<bf16_t*>(yv);
   constexpr int CPR = BN / 8;
   for (int idx = tid; idx < BM * CPR; idx += NT) {
@@ -689,16 +720,16 @@ int choose_fwd_tile(long M, int N) {
 
 template <int WGM, int WGN, int MI, int NI>
 int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
-               hipStream_t s, int tr_shift) {
+               hipStream_t s, int tr_shift, double* stats = nullptr) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
   const long M = (long)d.B * d.Ho * d.Wo;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (d.Cout + BN - 1) / BN;
   size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
-  const size_t cs = (size_t)BM * (BN + 8) * 2;
+  const size_t cs = (size_t)BM * (BN + 8) * 2 + (size_t)WGM * 2 * BN * sizeof(float);
   if (cs > lds) lds = cs;
   hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n),
                      dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)w, bias, y,
-                     tiles_n, tr_shift);
+                     tiles_n, tr_shift, stats);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }
@@ -776,9 +807,10 @@ extern "C" {
 
 int ssa_version(void) { return 1; }
 
-int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packed,
-                     const float* bias, void* y, void* stream) {
+int ssa_conv2d_igemm_stats(const ssa_conv_desc* dp, const void* x, const void* w_packed,
+                           const float* bias, void* y, double* stats, void* stream) {
   if (!dp || !x || !w_packed || !y) return SSA_EINVAL;
+  if (stats && (dp->out_f32 || dp->transposed)) return SSA_EINVAL;
   const ssa_conv_desc& d = *dp;
   if (d.Cin % 8 || d.ldx % 8 || d.Kpad % BK || d.Kpad < d.KH * d.KW * d.Cin) return SSA_EINVAL;
   if (!aligned16(x) || !aligned16(w_packed)) return SSA_EINVAL;
@@ -794,14 +826,19 @@ int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packe
   const long M = (long)d.B * d.Ho * d.Wo;
   const int cfg = d.cfg >= 0 ? d.cfg : choose_fwd_tile(M, d.Cout);
   switch (cfg) {
-    case 0: return launch_fwd<2, 2, 2, 2>(d, x, w_packed, bias, y, s, tr_shift);
-    case 1: return launch_fwd<4, 1, 2, 2>(d, x, w_packed, bias, y, s, tr_shift);
-    case 2: return launch_fwd<4, 1, 1, 3>(d, x, w_packed, bias, y, s, tr_shift);
-    case 3: return launch_fwd<4, 1, 2, 1>(d, x, w_packed, bias, y, s, tr_shift);
-    case 4: return launch_fwd<2, 2, 1, 1>(d, x, w_packed, bias, y, s, tr_shift);
-    case 5: return launch_fwd<2, 2, 2, 1>(d, x, w_packed, bias, y, s, tr_shift);
+    case 0: return launch_fwd<2, 2, 2, 2>(d, x, w_packed, bias, y, s, tr_shift, stats);
+    case 1: return launch_fwd<4, 1, 2, 2>(d, x, w_packed, bias, y, s, tr_shift, stats);
+    case 2: return launch_fwd<4, 1, 1, 3>(d, x, w_packed, bias, y, s, tr_shift, stats);
+    case 3: return launch_fwd<4, 1, 2, 1>(d, x, w_packed, bias, y, s, tr_shift, stats);
+    case 4: return launch_fwd<2, 2, 1, 1>(d, x, w_packed, bias, y, s, tr_shift, stats);
+    case 5: return launch_fwd<2, 2, 2, 1>(d, x, w_packed, bias, y, s, tr_shift, stats);
     default: return SSA_EINVAL;
   }
+}
+
+int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packed,
+                     const float* bias, void* y, void* stream) {
+  return ssa_conv2d_igemm_stats(dp, x, w_packed, bias, y, nullptr, stream);
 }
 
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* dp) {

@@ -39,6 +39,7 @@ _P = c_void_p
 _SIGS = {
     "ssa_version": ([], c_int),
     "ssa_conv2d_igemm": ([POINTER(ConvDesc), _P, _P, _P, _P, _P], c_int),
+    "ssa_conv2d_igemm_stats": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_conv2d_igemm_tile": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_tile_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_tile": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),

@@ -260,7 +260,7 @@ def set_profile(store):
 
 
 def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
-           cfg=-1):
+           cfg=-1, stats=None):
     """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
     B, H, W, Cin = geom_in
     Ho, Wo = geom_out
@@ -271,7 +271,8 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tile = lib().ssa_conv2d_igemm_tile(ctypes.byref(d))
         e0.record()
-    check(lib().ssa_conv2d_igemm(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _s()), "ssa_conv2d_igemm")
+    check(lib().ssa_conv2d_igemm_stats(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _p(stats), _s()),
+          "ssa_conv2d_igemm")
     if _PROFILE is not None:
         e1.record()
         # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
@@ -407,8 +408,13 @@ class Conv2dFn(torch.autograd.Function):
                 _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
         else:
             wp, Kpad = _packed_filter(weight, 0, Cin, 0)
+            stats = None
+            if want_stats and not out_f32:
+                stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
             y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
-                       out_f32)
+                       out_f32, stats=stats)
+            if stats is not None:
+                _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
         ctx.save_for_backward(x, weight)
         ctx.meta = (ldx, stride, pad, dil, bias is not None, (Ho, Wo))
         return y

@@ -228,6 +228,37 @@ def test_wgrad_tile_kernel(C, B, H, W):
     check_close("wgrad tile C=%d" % C, dw, w.grad, 2e-3, 5e-4)
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,W", [(48, 96, 3, 2, 50, 70), (64, 256, 1, 1, 33, 47), (96, 48, 1, 1, 20, 24)])
+def test_conv_bn_fused_stats_igemm(Cin, Cout, k, stride, H, W):
+    """Same as test_conv_bn_fused_stats for the shapes that run on the K-pipelined igemm kernel
+    (strided 3x3 and small 1x1 convs of the fuse layers / layer1): statistics from its epilogue."""
+    from oracle import ops as O
+    from semseg_amd import ops, nn as snn
+    hb = _hb()
+    B = 2
+    x = _rand(B, Cin, H, W, seed=51)
+    conv = snn.Conv2d(Cin, Cout, k, stride, k // 2, bias=False)
+    bn = snn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(Cout, Cin, k, k, seed=52, scale=0.05))
+        bn.weight.copy_(torch.rand(Cout) + 0.5)
+        bn.bias.copy_(torch.randn(Cout) * 0.1)
+    rm, rv = torch.zeros(Cout), torch.ones(Cout)
+    yr = O.conv2d(x, conv.weight.detach(), None, stride, k // 2, 1)
+    zr = O.batch_norm(bf16_round(yr), bn.weight.detach(), bn.bias.detach(), rm, rv, True, 0.1, 1e-5)
+    conv, bn = conv.to(DEV), bn.to(DEV).train()
+    hb.clear_pack_cache()
+    be = ops.HipBackend()
+    hb.begin_step(torch.device(DEV))
+    z = be.conv_bn_act(conv, bn, _to_dev_nhwc(x), relu=False)
+    be.end_forward()
+    torch.cuda.synchronize()
+    assert hb._PENDING_STATS[0] is None
+    check_close("fused igemm conv-bn", nchw(z.float()), zr, 2e-2, 6e-3)
+    check_close("fused igemm running_mean", bn.running_mean, rm, 2e-3, 2e-3)
+    check_close("fused igemm running_var", bn.running_var, rv, 2e-3, 2e-3)
+
+
 def test_batched_filter_repack():
     """refresh_packed_filters (one launch for all stale filters) == per-filter packing."""
     hb = _hb()
