@@ -325,6 +325,7 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False):
 # (data_ptr of a conv output, its BN partial sums [nrep][2][C], nrep): handed from the conv
 # epilogue to the BatchNorm that consumes that output next (HipBackend.conv_bn_act)
 _PENDING_STATS = [None]
+_NO_IGEMM_STATS = bool(__import__("os").environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
 
 
 def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real):
@@ -409,7 +410,7 @@ class Conv2dFn(torch.autograd.Function):
         else:
             wp, Kpad = _packed_filter(weight, 0, Cin, 0)
             stats = None
-            if want_stats and not out_f32:
+            if want_stats and not out_f32 and not _NO_IGEMM_STATS:
                 stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
             y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
                        out_f32, stats=stats)
