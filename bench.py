@@ -154,10 +154,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    # SSA_BENCH_ONE_DEVICE / SSA_DIST_BACKEND: self-test of the N > 1 code path on a one-GPU box
+    # (all ranks on cuda:0, gloo collectives); the driver's multi-GPU runs use neither.
+    torch.cuda.set_device(0 if os.environ.get("SSA_BENCH_ONE_DEVICE") else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend=os.environ.get("SSA_DIST_BACKEND", "nccl"), init_method="env://")
 
     net = build_model(world)
     model = net
@@ -227,17 +229,21 @@ def main():
     flop_scale = (args.crop / 1024.0) ** 2
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    store = []
+    if not args.no_roofline:
+        # every rank runs the two profiled steps (they contain collectives when N > 1); only rank 0
+        # attaches per-launch HIP events
         from semseg_amd import hip_backend as hb, ops as sops
-        store = []
         be = sops.backend()
         saved_conc, be.concurrency = be.concurrency, 0   # one stream: a launch's events bracket only that launch
-        hb.set_profile(store)
+        if rank == 0:
+            hb.set_profile(store)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         hb.set_profile(None)
         be.concurrency = saved_conc
+    if rank == 0 and store:
         agg = {}
         for kind, tile, flops, e0, e1, shape in store:
             key = (kind, tile)
