@@ -295,7 +295,7 @@ int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   const ssa_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
   const int nbt = (d.Cout + 31) / 32;
-  // Measured on MI355X (tools/convbench, gpurun_out/convbench*.log): these layers are
+  // Measured on MI355X (tools/convbench, profiles/r01_convbench.txt): these layers are
   // latency bound, more and smaller workgroups win everywhere -- 128-pixel tiles and one
   // n-block per workgroup (2-3 workgroups per CU) -- except the 48-channel layers at
   // >= 512 tiles, where both n-blocks in one workgroup save the second halo read.
