@@ -6,9 +6,11 @@
 //        A is never materialised: each 16-byte piece (8 channels of one tap of
 //        one pixel) is gathered straight from the NHWC tensor into LDS.
 //   weight-gradient:          dW[co, k] = sum_p dY[p, co] * A[p, k]
-//        the reduction runs over pixels, so both operands are transposed on
-//        their way into LDS; the pixel axis is split over blockIdx.y and the
-//        fp32 partials are summed by conv_wgrad_reduce (deterministic).
+//        the reduction runs over pixels: both operands are staged pixel-major
+//        (as loaded) and read with transposing ds_read_b64_tr_b16 fragments; the
+//        pixel axis is split over blockIdx.y and the fp32 partials are summed by
+//        wgrad_reduce_kernel (deterministic).  The head convs use
+//        conv_wgrad_head.hip instead.
 //
 // Replaces cuDNN behind nn.Conv2d on the reference's hot path (SURVEY.md K1-K6;
 // network/hrnetv2.py:31-34, network/ocrnet.py:54-58, network/utils.py:192-198).
@@ -250,133 +252,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
 }
 
 // ----------------------------------------------------------------------------
-// weight-gradient kernel (v0: transposing LDS stores)
-// ----------------------------------------------------------------------------
-template <int WGM, int WGN, int MI, int NI>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(
-    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
-    int cout_pad, float* __restrict__ partial, int tiles_n, int chunk) {
-  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
-  constexpr int A_PIECES = 32 * BM / 8, B_PIECES = 32 * BN / 8;
-  constexpr int A_IT = (A_PIECES + NT - 1) / NT, B_IT = (B_PIECES + NT - 1) / NT;
-  constexpr int STAGE = (BM + BN) * LDT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int P = d.B * d.Ho * d.Wo, HoWo = d.Ho * d.Wo;
-  const int Kflat = d.KH * d.KW * d.Cin;
-  const int p_begin = blockIdx.y * chunk;
-  const int p_end = min(P, p_begin + chunk);
-  const int pixel = tid & 31;
-
-  // per-piece constants
-  int a_co[A_IT];
-  bool a_ok[A_IT];
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int idx = tid + i * NT, piece = idx >> 5;
-    a_co[i] = m0 + piece * 8;
-    a_ok[i] = (idx < A_PIECES) && (a_co[i] < cout_pad);
-  }
-  int b_ci[B_IT], b_dy[B_IT], b_dx[B_IT];
-  bool b_ok[B_IT];
-#pragma unroll
-  for (int j = 0; j < B_IT; ++j) {
-    const int idx = tid + j * NT, piece = idx >> 5;
-    const int kcol = n0 + piece * 8;
-    b_ok[j] = (idx < B_PIECES) && (kcol < Kflat);
-    const int tap = kcol / d.Cin;
-    b_ci[j] = kcol - tap * d.Cin;
-    const int kh = tap / d.KW, kw = tap - kh * d.KW;
-    b_dy[j] = kh * d.dil - d.pad;
-    b_dx[j] = kw * d.dil - d.pad;
-  }
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  uint4 ra[A_IT], rb[B_IT];
-  auto gload = [&](int kt) {
-    const int p = p_begin + kt * 32 + pixel;
-    const bool pok = p < p_end;
-    const int pp = pok ? p : 0;
-    const int b = pp / HoWo, rem = pp - b * HoWo;
-    const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const bf16_t* ptr = dy + (long)pp * lddy + a_co[i];
-      ra[i] = (pok && a_ok[i]) ? *reinterpret_cast<const uint4*>(ptr) : zero4;
-    }
-#pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-      const int iy = oy * d.stride + b_dy[j], ix = ox * d.stride + b_dx[j];
-      const bool ok = pok && b_ok[j] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-      const long pix = ok ? (long)((b * d.H + iy) * d.W + ix) : 0;
-      const bf16_t* ptr = x + pix * d.ldx + b_ci[j];
-      rb[j] = ok ? *reinterpret_cast<const uint4*>(ptr) : zero4;
-    }
-  };
-  auto tstore = [&](bf16_t* dst, const uint4& v, int piece) {
-    bf16_t* q = dst + (piece * 8) * LDT + pixel;
-    q[0 * LDT] = (bf16_t)(v.x & 0xffff); q[1 * LDT] = (bf16_t)(v.x >> 16);
-    q[2 * LDT] = (bf16_t)(v.y & 0xffff); q[3 * LDT] = (bf16_t)(v.y >> 16);
-    q[4 * LDT] = (bf16_t)(v.z & 0xffff); q[5 * LDT] = (bf16_t)(v.z >> 16);
-    q[6 * LDT] = (bf16_t)(v.w & 0xffff); q[7 * LDT] = (bf16_t)(v.w >> 16);
-  };
-  auto lstore = [&](int buf) {
-    bf16_t* As = lds + buf * STAGE;
-    bf16_t* Bs = As + BM * LDT;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < A_PIECES) tstore(As, ra[i], idx >> 5);
-    }
-#pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-      const int idx = tid + j * NT;
-      if (idx < B_PIECES) tstore(Bs, rb[j], idx >> 5);
-    }
-  };
-
-  f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int nk = (p_end - p_begin + 31) / 32;
-  if (nk > 0) {
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < nk) gload(kt + 1);
-      const bf16_t* As = lds + buf * STAGE;
-      mma_stage<MI, NI>(As, As + BM * LDT, wm * MI * 32, wn * NI * 32, lane, acc);
-      if (kt + 1 < nk) lstore(buf ^ 1);
-      __syncthreads();
-    }
-  }
-  float* out = partial + (long)blockIdx.y * cout_pad * Kflat;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int kcol = n0 + wn * NI * 32 + ni * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < cout_pad && kcol < Kflat) out[(long)co * Kflat + kcol] = acc[mi][ni][r];
-      }
-    }
-}
-
-// ----------------------------------------------------------------------------
-// weight-gradient kernel v1: [pixel][channel] LDS images (16-byte stores, exactly
+// weight-gradient kernel: [pixel][channel] LDS images (16-byte stores, exactly
 // as loaded) + ds_read_b64_tr_b16 transposing fragment reads.
 //
 // ds_read_b64_tr_b16 lane map (probed on gfx950, tests/test_kernels_gpu.py::
@@ -738,45 +614,16 @@ template <int WGM, int WGN, int MI, int NI>
 int launch_wgrad(const ssa_conv_desc& d, const void* x, const void* dy, int lddy, int cout_pad,
                  int nsplit, float* partial, hipStream_t s) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
-  if (d.cfg != 100) {   // default: transposing-read kernel; cfg 100 selects the v0 kernel
-    const int Kflat = d.KH * d.KW * d.Cin;
-    const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
-    const long P = (long)d.B * d.Ho * d.Wo;
-    long chunk = (P + nsplit - 1) / nsplit;
-    // 64-pixel stages (16 MFMAs per wave between barriers) were measured SLOWER on MI355X:
-    // 720->512 3x3 wgrad 2.22 ms -> 3.20 ms, the 80 KB of LDS leave one workgroup per CU
-    // instead of three.  Kept selectable (cfg 102) for experiments only.
-    const bool deep = (BM >= 128 && BN >= 128) ? (chunk >= 512 && d.cfg == 102) : false;
-    if (deep) {
-      chunk = (chunk + 63) / 64 * 64;
-      const size_t lds = (size_t)2 * 64 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
-      auto kern = conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 64>;
-      static bool once = false;
-      if (!once && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        once = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n, nsplit), dim3(64 * WGM * WGN), lds, s, d,
-                         (const bf16_t*)x, (const bf16_t*)dy, lddy, cout_pad, partial, tiles_n, (int)chunk);
-      SSA_LAUNCH_CHECK();
-      return SSA_OK;
-    }
-    chunk = (chunk + 31) / 32 * 32;
-    const size_t lds = (size_t)2 * 32 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 32>), dim3(tiles_m * tiles_n, nsplit),
-                       dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
-                       cout_pad, partial, tiles_n, (int)chunk);
-    SSA_LAUNCH_CHECK();
-    return SSA_OK;
-  }
   const int Kflat = d.KH * d.KW * d.Cin;
   const int tiles_m = (cout_pad + BM - 1) / BM, tiles_n = (Kflat + BN - 1) / BN;
   const long P = (long)d.B * d.Ho * d.Wo;
   long chunk = (P + nsplit - 1) / nsplit;
+  // 32 pixels per LDS stage.  Measured and rejected on MI355X: 64-pixel
+  // stages (80 KB of LDS -> one workgroup per CU: 720->512 wgrad 2.22 -> 3.20 ms) and a second
+  // register set for two-stage-ahead prefetch (96@128^2: 36 -> 52 us).
   chunk = (chunk + 31) / 32 * 32;
-  const size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
-  hipLaunchKernelGGL((conv_wgrad_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n, nsplit),
+  const size_t lds = (size_t)2 * 32 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
+  hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 32>), dim3(tiles_m * tiles_n, nsplit),
                      dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
                      cout_pad, partial, tiles_n, (int)chunk);
   SSA_LAUNCH_CHECK();

@@ -118,9 +118,16 @@ class MscaleOCR(_Base):
         assert 1.0 in scales, "expected 1.0 to be the target scale"
         pred = aux = None
         out = {}
-        for s in sorted(scales, reverse=True):
+        order = sorted(scales, reverse=True)
+
+        def one_scale(s):
             x, size = self._images(inputs, s)
-            o = self._fwd(x, size)
+            return self._fwd(x, size)
+
+        # the per-scale passes are independent (only the fusion below is sequential): issue them
+        # on concurrent streams, the target scale on the calling stream
+        passes = B.parallel([(lambda s=s: one_scale(s)) for s in order])
+        for s, o in zip(order, passes):
             cls_out, attn_out, aux_out = o["cls_out"], o["logit_attn"], o["aux_out"]
             out[fmt_scale("pred", s)] = _nchw(cls_out)
             if s != 2.0:

@@ -183,6 +183,43 @@ def test_train_step(setup):
     assert worst < 3e-2
 
 
+def test_eval_nscale(setup):
+    """Hierarchical multi-scale inference {0.5, 1.0, 2.0} (network/ocrnet.py:185-262, BASELINE
+    configs[2]); the three scale passes run on concurrent streams on the HIP path."""
+    from semseg_amd import ops
+    from semseg_amd.config import cfg
+    from oracle_backend import OracleBackend
+    from bf16_emu_backend import Bf16EmuBackend
+    sd, images, gts = setup
+    images = images[:1, :, :128, :192].contiguous()
+    gts = gts[:1, :128, :192].contiguous()
+
+    def run(backend, device):
+        from semseg_amd.loss import RMILoss
+        from semseg_amd.network import ocrnet
+        prev = ops._BACKEND
+        ops._set_backend_for_tests(backend)
+        try:
+            cfg.MODEL.N_SCALES = [0.5, 1.0, 2.0]
+            net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255))
+            net.load_state_dict(sd)
+            net = net.to(device).eval()
+            with torch.no_grad():
+                o = net({"images": images.to(device), "gts": gts.to(device)})
+            return {k: v.float().cpu() for k, v in o.items()}
+        finally:
+            cfg.MODEL.N_SCALES = None
+            ops._set_backend_for_tests(prev)
+
+    ref, emu, hip = run(OracleBackend(), "cpu"), run(Bf16EmuBackend(), "cpu"), run(ops.HipBackend(), "cuda")
+    assert set(hip) == set(ref) and "pred_2.0x" in hip and "attn_0.5x" in hip
+    for k in sorted(ref):
+        eh, ee = _rel(hip[k], ref[k]), _rel(emu[k], ref[k])
+        print("nscale %-10s rel err hip %.4f emu %.4f" % (k, eh, ee))
+        assert torch.isfinite(hip[k]).all() and hip[k].shape == ref[k].shape
+        assert eh <= 1.5 * ee + 5e-3, k
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Secondary measurement (not the headline metric): inference throughput of the two eval
+configurations of BASELINE.json on one MI355X, synthetic Cityscapes-sized input, random
+weights, hipGraph replay:
+  configs[1]  HRNet-OCR single scale, 1024x2048                     (ocrnet.HRNet)
+  configs[2]  HRNet-OCR-MScale hierarchical attention {0.5,1.0,2.0}  (ocrnet.HRNet_Mscale, N_SCALES)
+usage: python tools/eval_bench.py [iters]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "semantic-segmentation_amd")]
+import torch  # noqa: E402
+
+
+def run(name, arch, n_scales, H, W, iters):
+    from semseg_amd.config import cfg
+    from semseg_amd.loss import CrossEntropyLoss2d
+    from semseg_amd.network import get_model
+    cfg.MODEL.N_SCALES = n_scales
+    cfg.MODEL.BNFUNC = None
+    torch.manual_seed(0)
+    net = get_model(arch, 19, CrossEntropyLoss2d(ignore_index=255)).cuda().eval()
+    images = torch.randn(1, 3, H, W, device="cuda")
+    inputs = {"images": images}
+    out_buf = {}
+
+    def step():
+        with torch.no_grad():
+            o = net(inputs)
+        out_buf["pred"] = o["pred"]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = None
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        torch.cuda.synchronize()
+    except Exception as e:
+        print("graph capture failed, eager:", repr(e)[:120], file=sys.stderr)
+        graph = None
+    f = graph.replay if graph is not None else step
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    pred = out_buf["pred"]
+    res = {"config": name, "arch": arch, "scales": n_scales or [1.0], "input": [H, W], "ms_per_image": dt * 1e3,
+           "images_per_s": 1.0 / dt, "hipgraph": graph is not None, "pred_shape": list(pred.shape),
+           "finite": bool(torch.isfinite(pred).all()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    print(json.dumps(res))
+    del net, graph
+    torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    run("configs[1] HRNet-OCR single-scale eval", "ocrnet.HRNet", None, 1024, 2048, iters)
+    run("configs[2] HRNet-OCR-MScale {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1024, 2048, iters)
