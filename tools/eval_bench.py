@@ -15,14 +15,15 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "semantic-segmentation_amd")]
 import torch  # noqa: E402
 
 
-def run(name, arch, n_scales, H, W, iters):
+def run(name, arch, n_scales, H, W, iters, classes=19, use_graph=True):
     from semseg_amd.config import cfg
     from semseg_amd.loss import CrossEntropyLoss2d
     from semseg_amd.network import get_model
     cfg.MODEL.N_SCALES = n_scales
     cfg.MODEL.BNFUNC = None
     torch.manual_seed(0)
-    net = get_model(arch, 19, CrossEntropyLoss2d(ignore_index=255)).cuda().eval()
+    cfg.DATASET.NUM_CLASSES = classes
+    net = get_model(arch, classes, CrossEntropyLoss2d(ignore_index=255)).cuda().eval()
     images = torch.randn(1, 3, H, W, device="cuda")
     inputs = {"images": images}
     out_buf = {}
@@ -41,6 +42,8 @@ def run(name, arch, n_scales, H, W, iters):
     torch.cuda.synchronize()
     graph = None
     try:
+        if not use_graph:
+            raise RuntimeError("eager requested")
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             step()
@@ -68,5 +71,12 @@ def run(name, arch, n_scales, H, W, iters):
 
 if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    if len(sys.argv) > 2 and sys.argv[2] == "mapillary":
+        # BASELINE configs[4]: Mapillary-sized full-resolution {0.5,1.0,2.0} inference, 65 classes,
+        # on ONE GPU (the reference needs amp O3 to fit); H W from argv
+        H, W = int(sys.argv[3]), int(sys.argv[4])
+        run("configs[4] Mapillary-sized {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], H, W, iters,
+            classes=65, use_graph=False)
+        sys.exit(0)
     run("configs[1] HRNet-OCR single-scale eval", "ocrnet.HRNet", None, 1024, 2048, iters)
     run("configs[2] HRNet-OCR-MScale {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1024, 2048, iters)
