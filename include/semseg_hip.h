@@ -378,6 +378,13 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
                        const float* upstream, double coef, float* dlogits,
                        int accumulate, void* stream);
 
+/* Evaluation tail on the device (utils/trnval_utils.py:173-196 + utils/misc.py:50-67
+ * fast_hist): pred[p] = first argmax_c logits[p,c] (uint8, optional) and
+ * hist[gt*C + pred] += 1 for 0 <= gt < C (int64 [C*C], ACCUMULATED: clear it once per
+ * evaluation).  logits fp32 NHWC [P,C] (pixel stride ld), labels int64 [P].          */
+int ssa_confusion_matrix(const float* logits, int ld, const int64_t* labels, long P, int C,
+                         unsigned char* pred_out, int64_t* hist, void* stream);
+
 /* axpy on fp32: y = alpha*x + (accumulate? y : 0) */
 int ssa_axpy_f32(const float* x, float alpha, float* y, long n, int accumulate,
                  void* stream);

@@ -52,3 +52,18 @@ def resize_nearest(mask, size):
     hs, ws = len(mask), len(mask[0])
     iy, ix = pil_nearest_indices(size[0], hs), pil_nearest_indices(size[1], ws)
     return [[int(mask[y][x]) for x in ix] for y in iy]
+
+
+def fast_hist(pred, gtruth, num_classes):
+    """utils/misc.py:50-67, statement by statement (numpy)."""
+    import numpy as np
+    mask = (gtruth >= 0) & (gtruth < num_classes)
+    hist = np.bincount(num_classes * gtruth[mask].astype(int) + pred[mask], minlength=num_classes ** 2)
+    return hist.reshape(num_classes, num_classes)
+
+
+def eval_predictions(output):
+    """utils/trnval_utils.py:173-174: softmax over classes, then max(1) -> class ids."""
+    import torch
+    probs = torch.nn.functional.softmax(output, dim=1)
+    return probs.max(1)[1]

@@ -510,3 +510,49 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Device-side evaluation tail: per-pixel argmax over
+// the class logits + confusion matrix, replacing the host path of
+// utils/trnval_utils.py:173-196 (softmax -> .cpu() -> max(1)) and utils/misc.py:50-67
+// (fast_hist: np.bincount(C*gt[mask] + pred[mask])).  Integer output, bit-exact given
+// the predictions; argmax takes the FIRST maximum (torch.max's rule; softmax is
+// monotonic, so argmax of the logits is argmax of the probabilities except where two
+// probabilities round to the same float).  One LDS histogram per workgroup, then int64
+// atomics: the 159 MB [B,19,H,W] fp32 copy to the host disappears.
+namespace {
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ logits, int ld,
+                                                        const long* __restrict__ labels, long P, int C,
+                                                        unsigned char* __restrict__ pred_out,
+                                                        unsigned long long* __restrict__ hist) {
+  extern __shared__ unsigned int lh[];          // [C*C]
+  for (int i = threadIdx.x; i < C * C; i += 256) lh[i] = 0u;
+  __syncthreads();
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+    const float* row = logits + p * ld;
+    float best = row[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = row[c];
+      if (v > best || (v != v && best == best)) { best = v; arg = c; }   // first maximum; NaN wins once
+    }
+    if (pred_out) pred_out[p] = (unsigned char)arg;
+    const long g = labels[p];
+    if (g >= 0 && g < C) atomicAdd(&lh[(int)g * C + arg], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += 256)
+    if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+}  // namespace
+
+extern "C" int ssa_confusion_matrix(const float* logits, int ld, const int64_t* labels, long P, int C,
+                                    unsigned char* pred_out, int64_t* hist, void* stream) {
+  if (!logits || !labels || !hist || P < 1 || C < 1 || C > 255 || ld < C) return SSA_EINVAL;
+  const int blocks = (int)((P + 255) / 256 > 2048 ? 2048 : (P + 255) / 256);
+  hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), (size_t)C * C * sizeof(unsigned int),
+                     (hipStream_t)stream, logits, ld, (const long*)labels, P, C, pred_out,
+                     (unsigned long long*)hist);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}

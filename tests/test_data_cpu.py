@@ -71,3 +71,15 @@ def test_index_table_is_the_oracles():
     sizes = [(rnd.randint(1, 2100), rnd.randint(1, 2100)) for _ in range(300)] + [(1024, 2048), (2048, 1024), (1, 1)]
     for n_dst, n_src in sizes:
         assert nearest_index_table(n_dst, n_src).tolist() == pil_nearest_indices(n_dst, n_src), (n_dst, n_src)
+
+
+def test_oracle_fast_hist_matches_reference():
+    """oracle.data.fast_hist vs the confusion matrix of the real utils/misc.py:fast_hist."""
+    from oracle.data import fast_hist
+    with open(os.path.join(os.path.dirname(G), "fast_hist_golden.json")) as f:
+        gold = json.load(f)
+    rng = np.random.default_rng(gold["seed"])
+    pred = rng.integers(0, 19, gold["n"])
+    gt = rng.integers(0, 19, gold["n"])
+    gt[rng.random(gold["n"]) < 0.1] = 255
+    assert fast_hist(pred, gt, 19).tolist() == gold["hist"]

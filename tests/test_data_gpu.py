@@ -37,3 +37,29 @@ def test_nearest_resize_batched_and_full_size():
     want = np.array(Image.fromarray(m).resize((1434, 717), Image.NEAREST))
     got = resize_labels_nearest(torch.from_numpy(m).cuda(), (717, 1434)).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_confusion_matrix_on_device():
+    """ssa_confusion_matrix (argmax + fast_hist on the GPU) bit-exact against the oracle's
+    softmax -> max(1) -> np.bincount chain, with exact ties, ignore labels and negative labels."""
+    from oracle.data import fast_hist, eval_predictions
+    from semseg_amd.utils import confusion_matrix
+    from semseg_amd.utils import fast_hist as fast_hist_dev
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 2, 19, 67, 93
+    logits = torch.randn(B, C, H, W, generator=g) * 3
+    logits[:, 5] = logits[:, 3]                       # exact ties: the first maximum must win
+    logits[0, :, :8] = 0.0                            # all-equal rows -> class 0
+    gts = torch.randint(0, C, (B, H, W), generator=g)
+    gts[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    gts[0, 0, :5] = -1
+    pred_ref = eval_predictions(logits)
+    assert torch.equal(pred_ref, logits.max(1)[1])    # on this data softmax does not merge distinct logits
+    want = fast_hist(pred_ref.numpy().flatten(), gts.numpy().flatten(), C)
+    nhwc_view = logits.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2)   # what the network hands back
+    hist, pred = confusion_matrix(nhwc_view, gts.cuda(), C, return_predictions=True)
+    assert torch.equal(pred.cpu().long(), pred_ref)
+    assert np.array_equal(hist.cpu().numpy(), want)
+    hist2 = confusion_matrix(logits.cuda(), gts.cuda(), C, hist=hist.clone())         # accumulates; NCHW input
+    assert np.array_equal(hist2.cpu().numpy(), 2 * want)
+    assert np.array_equal(fast_hist_dev(pred, gts.cuda(), C).cpu().numpy(), want)
