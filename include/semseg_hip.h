@@ -206,14 +206,17 @@ int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma,
 int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
                  int ldz, long P, int C, const float* scale, const float* shift,
                  int relu, const float* post, long pix_per_img, void* stream);
-/* backward pass 1: sum g and sum g*xhat, g = dz*post*(z>0), accumulated into
+/* mask_scale/mask_shift (both backward passes, optional): the ReLU mask is recomputed
+ * as scale[c]*x + shift[c] > 0 (the forward's own coefficients) instead of read from
+ * z -- z may then be NULL: one tensor less to read, and to keep, per BN+ReLU layer.
+ * backward pass 1: sum g and sum g*xhat, g = dz*post*(z>0), accumulated into
  * sums[nrep][2][C] (workgroup b adds into replica b % nrep: fewer same-address
  * fp64 atomics); ssa_bn_bwd_apply sums the replicas.                           */
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz,
                       const void* z, int ldz, long P, int C, const float* mean,
                       const float* invstd, int relu, const float* post,
                       long pix_per_img, double* sums, int nrep, int zero_sums,
-                      void* stream);
+                      const float* mask_scale, const float* mask_shift, void* stream);
 /* backward pass 2: dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N);
  * dres (optional) = g.  sums may have been all-reduced; count is global.
  * dgamma/dbeta (optional): = param_grad_scale * sums[C:2C] / sums[0:C]
@@ -224,7 +227,8 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      const float* mean, const float* invstd, const double* sums,
                      int nrep, double count, int relu, const float* post,
                      long pix_per_img, float* dgamma, float* dbeta,
-                     float param_grad_scale, void* stream);
+                     float param_grad_scale, const float* mask_scale,
+                     const float* mask_shift, void* stream);
 /* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);

@@ -237,18 +237,23 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
     const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
-    double* __restrict__ sums, int nrep, long pix_per_block) {
+    double* __restrict__ sums, int nrep, long pix_per_block, const float* __restrict__ mscale,
+    const float* __restrict__ mshift) {
   extern __shared__ float sh[];
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
   const int cg = t % VC, pr = t / VC;
-  float sg[8], sgx[8], mu[8], is[8];
+  float sg[8], sgx[8], mu[8], is[8], ma[8], mb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; ma[j] = 0.f; mb[j] = 0.f; }
   if (active) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
+    if (mscale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
+    }
     const long p0 = blockIdx.x * pix_per_block;
     const long p1 = min(P, p0 + pix_per_block);
   #pragma unroll 4
@@ -261,7 +266,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] *= pp[j];
       }
-      if (relu) {
+      if (relu && mscale) {          // ReLU mask recomputed from x: z = relu(scale*x + shift), z not read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
+      } else if (relu) {
         float zv[8];
         unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
 #pragma unroll
@@ -284,7 +292,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const double* __restrict__ sums, int nrep, double count, int relu,
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
+    const float* __restrict__ mscale, const float* __restrict__ mshift) {
   extern __shared__ float sh[];                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -305,10 +314,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
   __syncthreads();
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
-  float mu[8], is[8], a[8], c1[8], c2[8];
+  float mu[8], is[8], a[8], c1[8], c2[8], ma[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
+    ma[j] = mscale ? mscale[c] : 0.f;
+    mb[j] = mscale ? mshift[c] : 0.f;
     mu[j] = sh[c];
     is[j] = sh[C + c];
     a[j] = sh[2 * C + c];
@@ -327,7 +338,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) g[j] *= pp[j];
     }
-    if (relu) {
+    if (relu && mscale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
+    } else if (relu) {
       float zv[8];
       unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
 #pragma unroll
@@ -517,8 +531,10 @@ int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_chann
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                       long P, int C, const float* mean, const float* invstd, int relu,
                       const float* post, long pix_per_img, double* sums, int nrep, int zero_sums,
-                      void* stream) {
-  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z) || nrep < 1) return SSA_EINVAL;
+                      const float* mask_scale, const float* mask_shift, void* stream) {
+  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z && !mask_scale) || nrep < 1 ||
+      (mask_scale && !mask_shift))
+    return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (zero_sums) {
@@ -528,7 +544,7 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
   const Grid g = plan_reduce_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
-                     mean, invstd, relu, post, pix_per_img, sums, nrep, g.ppb);
+                     mean, invstd, relu, post, pix_per_img, sums, nrep, g.ppb, mask_scale, mask_shift);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }
@@ -537,15 +553,18 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
                      void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
                      const float* mean, const float* invstd, const double* sums, int nrep,
                      double count, int relu, const float* post, long pix_per_img, float* dgamma,
-                     float* dbeta, float param_grad_scale, void* stream) {
-  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z) || nrep < 1)
+                     float* dbeta, float param_grad_scale, const float* mask_scale,
+                     const float* mask_shift, void* stream) {
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z && !mask_scale) || nrep < 1 ||
+      (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 5 * C * sizeof(float), (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz,
                      (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums, nrep,
-                     count, relu, post, pix_per_img, g.ppb, dgamma, dbeta, param_grad_scale);
+                     count, relu, post, pix_per_img, g.ppb, dgamma, dbeta, param_grad_scale, mask_scale,
+                     mask_shift);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

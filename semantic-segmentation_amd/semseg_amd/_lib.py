@@ -66,9 +66,9 @@ _SIGS = {
     "ssa_bn_apply": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
                       c_long, _P], c_int),
     "ssa_bn_bwd_reduce": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
-                           c_long, _P, c_int, c_int, _P], c_int),
+                           c_long, _P, c_int, c_int, _P, _P, _P], c_int),
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
-                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P], c_int),
+                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
     "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
     "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),

@@ -502,15 +502,19 @@ class BatchNormActFn(torch.autograd.Function):
                                     _p(coef[3]), _s()), "ssa_bn_finalize")
             check(L.ssa_bn_apply(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(coef[0]), _p(coef[1]),
                                  int(relu), _p(pst), H * W, _s()), "ssa_bn_apply")
-        ctx.save_for_backward(x, z if relu else None, g, coef, pst)
-        ctx.meta = (ldx, relu, training, world, residual is not None, count)
+        # BN + ReLU without residual / mask: the backward recomputes the ReLU mask from x with the
+        # forward's own scale/shift, so z is neither kept for nor read by the backward
+        mask_from_x = relu and residual is None and pst is None
+        ctx.save_for_backward(x, z if (relu and not mask_from_x) else None, g, coef, pst)
+        ctx.meta = (ldx, relu, training, world, residual is not None, count, mask_from_x)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         L = lib()
         x, z, g, coef, pst = ctx.saved_tensors
-        ldx, relu, training, world, has_res, count = ctx.meta
+        ldx, relu, training, world, has_res, count, mask_from_x = ctx.meta
+        msc, msh = (coef[0], coef[1]) if mask_from_x else (None, None)
         B, H, W, C = x.shape
         P = B * H * W
         dev = x.device
@@ -520,7 +524,8 @@ class BatchNormActFn(torch.autograd.Function):
         nrep = stat_replicas() if training else 1
         sums = _ARENA.take(nrep * 2 * C, dev)
         check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
-                                  int(relu), _p(pst), H * W, _p(sums), nrep, 0, _s()), "ssa_bn_bwd_reduce")
+                                  int(relu), _p(pst), H * W, _p(sums), nrep, 0, _p(msc), _p(msh), _s()),
+              "ssa_bn_bwd_reduce")
         pg = torch.empty((2, C), dtype=torch.float32, device=dev) if g is not None else None
         pscale = 1.0
         use_sums = sums
@@ -540,7 +545,8 @@ class BatchNormActFn(torch.autograd.Function):
         fuse_pg = pg is not None and training
         check(L.ssa_bn_bwd_apply(_p(x), ldx, _p(dz), lddz, _p(z), C, _p(dx), C, _p(dres), C, P, C, _p(g),
                                  _p(coef[2]), _p(coef[3]), _p(use_sums), nrep, count, int(relu), _p(pst), H * W,
-                                 _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale, _s()),
+                                 _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale,
+                                 _p(msc), _p(msh), _s()),
               "ssa_bn_bwd_apply")
         dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
