@@ -25,7 +25,8 @@ def _defaults():
         ALIGN_CORNERS=False,         # config.py:125
         MSCALE_LO_SCALE=0.5,         # config.py:126
         N_SCALES=None,               # config.py:124
-        SEGATTN_BOT_CH=256,          # config.py:128
+        SEGATTN_BOT_CH=256,          # config.py:130
+        ASPP_BOT_CH=256,             # config.py:131
         MSCALE_INNER_3x3=True,       # config.py:131
         HRNET_CHECKPOINT="",         # config.py:147 (empty: random init, no file needed)
         OCR=AttrDict(MID_CHANNELS=512, KEY_CHANNELS=256),   # config.py:157-158
@@ -49,7 +50,7 @@ cfg = _defaults()
 def sync_from_reference(ref_cfg):
     """Copy the fields the hot path reads from the reference's global cfg."""
     m = ref_cfg.MODEL
-    for k in ("ALIGN_CORNERS", "MSCALE_LO_SCALE", "N_SCALES", "SEGATTN_BOT_CH", "MSCALE_INNER_3x3",
+    for k in ("ALIGN_CORNERS", "MSCALE_LO_SCALE", "N_SCALES", "SEGATTN_BOT_CH", "ASPP_BOT_CH", "MSCALE_INNER_3x3",
               "HRNET_CHECKPOINT"):
         if hasattr(m, k):
             cfg.MODEL[k] = getattr(m, k)
@@ -61,3 +62,5 @@ def sync_from_reference(ref_cfg):
     cfg.DATASET.IGNORE_LABEL = ref_cfg.DATASET.IGNORE_LABEL
     cfg.OPTIONS.INIT_DECODER = ref_cfg.OPTIONS.INIT_DECODER
     assert not cfg.MODEL.ALIGN_CORNERS, "only align_corners=False is implemented"
+    for k in ("MSCALE_OLDARCH", "MSCALE_DROPOUT", "MSCALE_CAT_SCALE_FLT"):      # config.py:132-135
+        assert not getattr(m, k, False), "cfg.MODEL.%s is not on the accelerated path" % k

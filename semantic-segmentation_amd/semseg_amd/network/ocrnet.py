@@ -93,6 +93,31 @@ class OCRNet(_Base):
         return {"pred": _nchw(cls_out)}
 
 
+class OCRNetASPP(_Base):
+    """OCR head on ASPP features (network/ocrnet.py:125-155)."""
+
+    def __init__(self, num_classes, trunk="hrnetv2", criterion=None):
+        super().__init__()
+        from .deepv3 import get_aspp
+        self.criterion = criterion
+        self.backbone, _, _, high_level_ch = get_trunk(trunk)
+        self.aspp, aspp_out_ch = get_aspp(high_level_ch, bottleneck_ch=256, output_stride=8)
+        self.ocr = OCR_block(aspp_out_ch)
+
+    def forward(self, inputs):
+        ops.backend().begin_step(inputs["images"].device)
+        x, size = self._images(inputs)
+        _, _, feats = self.backbone(x)
+        cls_out, aux_out, _ = self.ocr(self.aspp(feats))
+        aux_out = Upsample(aux_out, size)
+        cls_out = Upsample(cls_out, size)
+        ops.backend().end_forward()
+        if self.training:
+            gts = inputs["gts"]
+            return cfg.LOSS.OCR_ALPHA * self.criterion(_nchw(aux_out), gts) + self.criterion(_nchw(cls_out), gts)
+        return {"pred": _nchw(cls_out)}
+
+
 class MscaleOCR(_Base):
     """network/ocrnet.py:158-334"""
 

@@ -47,3 +47,21 @@ def make_attn_head(in_ch, out_ch):
     od["conv2"] = Conv2d(bot_ch, out_ch, kernel_size=1, bias=False)
     od["sig"] = nn.Sigmoid()
     return AttnHead(od)
+
+
+class SegHead(nn.Sequential):
+    """3x3 -> BN -> ReLU -> 3x3 -> BN -> ReLU -> 1x1 (children 0..6 as in
+    network/utils.py:320-329); returns fp32 logits [B,H,W,classes]."""
+
+    def forward(self, x):
+        x = conv_bn(self[0], self[1], x, relu=True)
+        x = conv_bn(self[3], self[4], x, relu=True)
+        return self[6](x, out_f32=True)
+
+
+def make_seg_head(in_ch, out_ch):
+    """network/utils.py:320-329"""
+    bot_ch = cfg.MODEL.SEGATTN_BOT_CH
+    return SegHead(Conv2d(in_ch, bot_ch, kernel_size=3, padding=1, bias=False), Norm2d(bot_ch), nn.ReLU(inplace=True),
+                   Conv2d(bot_ch, bot_ch, kernel_size=3, padding=1, bias=False), Norm2d(bot_ch), nn.ReLU(inplace=True),
+                   Conv2d(bot_ch, out_ch, kernel_size=1, bias=False))

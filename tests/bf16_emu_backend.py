@@ -61,6 +61,9 @@ class Bf16EmuBackend(OracleBackend):
     def ocr_attention(self, q, k, v, scale):
         return R(super().ocr_attention(q, k, v, scale))
 
+    def to_act(self, x):
+        return R(x)
+
 
 TRACED = ("image_to_nhwc", "conv2d", "batch_norm_act", "sum_act", "bilinear", "ocr_gather", "ocr_attention",
           "max_pool3x3s2", "global_avg_pool")

@@ -1,0 +1,122 @@
+"""Sibling architectures (mscale.HRNet, mscale.HRNet_ASP,
+mscale.DeepV3R50 (+ fuse_aspp/attn_2b), mscale2.DeepV3R50, ocrnet.OCRNetASPP) on
+the HIP kernels against the same modules on the oracle's operators (whose wiring
+tests/test_siblings_cpu.py pins to the real reference in fp64).  Tolerance scheme
+of tests/test_e2e_gpu.py: the measured bf16 storage noise floor bounds the HIP
+path, op by op in eval and statistically for the training gradients."""
+import pytest
+import torch
+
+from test_e2e_gpu import _rel, _synth
+from test_siblings_cpu import NAMES, calibrate, sibling_shapes
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_dict(name, seed):
+    from oracle.model import seeded_state_dict
+    sd = seeded_state_dict(sibling_shapes()[name], seed=seed)
+    for k in sd:          # near-identity residual blocks + the B=2 image-pooling BN (see test_deepv3_gpu.setup)
+        if (k.endswith("bn2.weight") and "branches" in k) or k.endswith("bn3.weight"):
+            sd[k] = sd[k] * 0.2
+        if k.endswith("aspp.img_conv.1.weight"):
+            sd[k] = sd[k] * 0.05
+    return sd
+
+
+def _build(name, sd, crit="ce", wt=0.0):
+    from test_siblings_cpu import build
+    gold = {"wt": wt, "crit": crit, "seed": 0, "dtype": torch.float32}
+    net = build(name, gold, True).float()
+    net.load_state_dict(sd)
+    return net
+
+
+def _with_backend(backend, fn):
+    from semseg_amd import ops
+    from semseg_amd.config import cfg
+    prev = ops._BACKEND
+    ops._set_backend_for_tests(backend)
+    try:
+        return fn()
+    finally:
+        ops._set_backend_for_tests(prev)
+        cfg.LOSS.SUPERVISED_MSCALE_WT = 0
+        cfg.MODEL.N_SCALES = None
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_sibling_eval_op_by_op(name):
+    from semseg_amd import ops
+    from oracle_backend import OracleBackend
+    from bf16_emu_backend import Bf16EmuBackend, traced
+    images, gts = _synth(2, 128, 192, seed=91)
+    sd = _state_dict(name, seed=5)
+    # BN running statistics calibrated on this batch by the oracle-operator run
+    sd = _with_backend(OracleBackend(), lambda: {k: v.clone() for k, v in calibrate(
+        _build(name, sd), {"images": images, "gts": gts}).state_dict().items()})
+
+    def run(backend, device):
+        def go():
+            net = _build(name, sd).to(device).eval()
+            with torch.no_grad():
+                return {k: v.float().cpu() for k, v in net({"images": images.to(device)}).items()}
+        return _with_backend(backend, go)
+
+    ref_log, emu_err, hip_err, names = [], [], [], []
+    ref = run(traced(OracleBackend(), lambda i, n, y: (ref_log.append(y.detach()), names.append(n))), "cpu")
+    emu = run(traced(Bf16EmuBackend(), lambda i, n, y: emu_err.append(_rel(y.detach(), ref_log[i]))), "cpu")
+    hip = run(traced(ops.HipBackend(), lambda i, n, y: hip_err.append(_rel(y.detach().float().cpu(), ref_log[i]))),
+              "cuda")
+    assert len(ref_log) == len(emu_err) == len(hip_err) > 100
+    worst = max(range(len(hip_err)), key=lambda i: hip_err[i] - 1.5 * emu_err[i])
+    print("%s: ops traced %d; largest excess at op %d (%s %s): hip %.4f emu %.4f" % (
+        name, len(hip_err), worst, names[worst], tuple(ref_log[worst].shape), hip_err[worst], emu_err[worst]))
+    bad = [(i, names[i], tuple(ref_log[i].shape), hip_err[i], emu_err[i]) for i in range(len(hip_err))
+           if not hip_err[i] <= 1.5 * emu_err[i] + 5e-3]
+    assert not bad, bad[:5]
+    assert sorted(hip) == sorted(ref)
+    for k in ref:
+        eh, ee = _rel(hip[k], ref[k]), _rel(emu[k], ref[k])
+        print("  eval %-9s rel err hip %.4f emu %.4f" % (k, eh, ee))
+        assert torch.isfinite(hip[k]).all() and tuple(hip[k].shape) == tuple(ref[k].shape)
+        assert eh <= 1.5 * ee + 5e-3, k
+    ah = (hip["pred"].argmax(1) == ref["pred"].argmax(1)).float().mean().item()
+    ae = (emu["pred"].argmax(1) == ref["pred"].argmax(1)).float().mean().item()
+    assert ah >= ae - 0.02, (ah, ae)
+
+
+@pytest.mark.parametrize("name,crit,wt", [("mscale.HRNet", "rmi", 0.05), ("mscale2.DeepV3R50", "ce", 0.0)])
+def test_sibling_train_step(name, crit, wt):
+    from semseg_amd import ops
+    from oracle_backend import OracleBackend
+    from bf16_emu_backend import Bf16EmuBackend
+    images, gts = _synth(2, 128, 192, seed=92)
+    sd = _state_dict(name, seed=6)
+
+    def run(backend, device):
+        def go():
+            net = _build(name, sd, crit, wt).to(device).train()
+            loss = net({"images": images.to(device), "gts": gts.to(device)})
+            loss.backward()
+            if device != "cpu":
+                torch.cuda.synchronize()
+            return float(loss.detach()), {n: p.grad.detach().float().cpu() for n, p in net.named_parameters()
+                                          if p.grad is not None}
+        return _with_backend(backend, go)
+
+    lr, gr = run(OracleBackend(), "cpu")
+    le, ge = run(Bf16EmuBackend(), "cpu")
+    lh, gh = run(ops.HipBackend(), "cuda")
+    print("%s train loss hip %.6f emu %.6f oracle %.6f" % (name, lh, le, lr))
+    assert abs(lh - lr) <= 2e-3 * abs(lr) + 2 * abs(le - lr)
+    assert sorted(gh) == sorted(gr)
+
+    def cosines(g):
+        return sorted(float((g[n] * r).sum() / (g[n].norm() * r.norm() + 1e-30)) for n, r in gr.items()
+                      if float(r.norm()) > 1e-10)
+    vh, ve = cosines(gh), cosines(ge)
+    print("grad cosine vs oracle: hip min %.4f p10 %.4f median %.4f | emu min %.4f p10 %.4f median %.4f (n=%d)" % (
+        vh[0], vh[len(vh) // 10], vh[len(vh) // 2], ve[0], ve[len(ve) // 10], ve[len(ve) // 2], len(vh)))
+    assert all(torch.isfinite(g).all() for g in gh.values())
+    assert vh[len(vh) // 2] >= ve[len(ve) // 2] - 0.10 and vh[len(vh) // 10] >= ve[len(ve) // 10] - 0.15
