@@ -170,7 +170,14 @@ def main():
         # the second stream buys nothing -- keep every collective on one stream
         sops.backend().concurrency = 0
         model = DistributedDataParallel(net)
-    optim = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    # SGD + momentum + weight decay as in loss/optimizer.py:47-53.  SSA_FUSED_SGD=1: the one-pass
+    # HIP step (ssa_sgd_momentum_step); default: torch's multi-tensor SGD
+    fused_sgd = os.environ.get("SSA_FUSED_SGD", "0") == "1"
+    if fused_sgd:
+        from semseg_amd.loss.optimizer import FusedSGD
+        optim = FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    else:
+        optim = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     images, gts = synth_batch(args.batch, args.crop, args.crop, rank, "cuda")
     inputs = {"images": images, "gts": gts}
     static_loss = torch.zeros((), device="cuda")
@@ -330,7 +337,8 @@ def main():
                                    "crop %dx%d, batch %d/GPU, SGD, synthetic Cityscapes-shaped batch, random init"
                                    % (args.crop, args.crop, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "hipgraph": graph is not None, "loss": loss_val},
+                       "hipgraph": graph is not None, "loss": loss_val,
+                       "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)"},
             "model_flops_util": ips / world * FLOP_FWD_BWD_PER_IMAGE * flop_scale / PEAK_BF16_MFMA,
             "roofline": roof, "cpu_baseline": cpu,
         }

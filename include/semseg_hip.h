@@ -389,6 +389,20 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
 int ssa_confusion_matrix(const float* logits, int ld, const int64_t* labels, long P, int C,
                          unsigned char* pred_out, int64_t* hist, void* stream);
 
+/* Optimizer step (train.py:509 on the torch.optim.SGD of loss/optimizer.py:47-53;
+ * SURVEY.md 8f rank 3): for every tensor i, elementwise in fp32
+ *     d = g + weight_decay*p;  buf = momentum*buf + d;  p -= lr * (nesterov ? d + momentum*buf : buf)
+ * (torch's SGD with dampening 0; a momentum buffer starting at zero reproduces its
+ * first step).  params/grads/bufs/numel are HOST arrays of n_tensors entries holding
+ * device pointers to dense fp32 tensors; bufs may be NULL (momentum 0) and so may
+ * single entries of it.  Up to 96 tensors go into one launch (pointers travel as
+ * kernel arguments, so a captured graph owns them).  lr_dev, when not NULL, is a
+ * device float read at run time instead of `lr` -- a captured step then follows the
+ * LR schedule without re-capture.                                                    */
+int ssa_sgd_momentum_step(void* const* params, const void* const* grads, void* const* bufs,
+                          const int64_t* numel, int n_tensors, float lr, const float* lr_dev,
+                          float momentum, float weight_decay, int nesterov, void* stream);
+
 /* axpy on fp32: y = alpha*x + (accumulate? y : 0) */
 int ssa_axpy_f32(const float* x, float alpha, float* y, long n, int accumulate,
                  void* stream);

@@ -41,6 +41,7 @@ def _defaults():
     c.LOSS = AttrDict(OCR_ALPHA=0.4, OCR_AUX_RMI=False, SUPERVISED_MSCALE_WT=0)   # config.py:150-155
     c.DATASET = AttrDict(NUM_CLASSES=19, IGNORE_LABEL=255)
     c.OPTIONS = AttrDict(INIT_DECODER=False)
+    c.REDUCE_BORDER_EPOCH = -1       # config.py:60 (the 'scl-poly' LR schedule switches there)
     return c
 
 
@@ -61,6 +62,7 @@ def sync_from_reference(ref_cfg):
     cfg.DATASET.NUM_CLASSES = ref_cfg.DATASET.NUM_CLASSES
     cfg.DATASET.IGNORE_LABEL = ref_cfg.DATASET.IGNORE_LABEL
     cfg.OPTIONS.INIT_DECODER = ref_cfg.OPTIONS.INIT_DECODER
+    cfg.REDUCE_BORDER_EPOCH = getattr(ref_cfg, "REDUCE_BORDER_EPOCH", -1)
     assert not cfg.MODEL.ALIGN_CORNERS, "only align_corners=False is implemented"
     for k in ("MSCALE_OLDARCH", "MSCALE_DROPOUT", "MSCALE_CAT_SCALE_FLT"):      # config.py:132-135
         assert not getattr(m, k, False), "cfg.MODEL.%s is not on the accelerated path" % k
