@@ -98,7 +98,15 @@ class FusedSGD(optim.Optimizer):
                                                       momentum, float(group["weight_decay"]),
                                                       int(bool(group["nesterov"])), stream.cuda_stream),
                           "ssa_sgd_momentum_step")
+                # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and the
+                # packed-filter cache (hip_backend.refresh_packed_filters keys on ._version) that
+                # the parameters and buffers changed
+                _mark_updated([p for p, _, _ in items] + [b for _, _, b in items if b is not None])
         return loss
+
+
+def _mark_updated(tensors):
+    torch.autograd.graph.increment_version(tensors)
 
 
 def poly_schedules(args):
