@@ -5,10 +5,12 @@
 registers this package's modules under the names the reference resolves at run
 time, so `train.py`, `config.py` and `scripts/*.yml` run unchanged:
 
-  network.ocrnet / network.hrnetv2 / network.ocr_utils / network.utils / network.mynn
+  network.ocrnet / network.deepv3 / network.mscale / network.mscale2 / network.hrnetv2 /
+  network.ocr_utils / network.utils / network.mynn
         -> semseg_amd.network.*      (importlib target of --arch, network/__init__.py:45-54)
-  loss.utils.get_loss, loss.rmi.RMILoss
-        -> semseg_amd.loss.*         (train.py:341)
+  loss.utils (get_loss, CrossEntropyLoss2d), loss.rmi (RMILoss), loss.optimizer (get_optimizer,
+  restore_opt, restore_net, ...)
+        -> semseg_amd.loss.*         (train.py:45-46,341,378)
   apex.parallel.SyncBatchNorm / DistributedDataParallel, apex.amp
         -> semseg_amd.nn.SyncBatchNorm / semseg_amd.parallel.DistributedDataParallel /
            a bf16 no-op amp shim     (config.py:218-220, network/__init__.py:37-39, train.py:381,504)
@@ -37,7 +39,8 @@ def _amp_shim():
 
 def install(replace_apex=True):
     from . import nn as snn, parallel, network, loss
-    from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn
+    from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn, deepv3, mscale, mscale2
+    from .loss import criteria, optimizer
     if replace_apex:
         apex = types.ModuleType("apex")
         par = types.ModuleType("apex.parallel")
@@ -50,7 +53,9 @@ def install(replace_apex=True):
         sys.modules["apex.amp"] = apex.amp
     for name, mod in (("network.ocrnet", ocrnet), ("network.hrnetv2", hrnetv2),
                       ("network.ocr_utils", ocr_utils), ("network.utils", nutils),
-                      ("network.mynn", mynn)):
+                      ("network.mynn", mynn), ("network.deepv3", deepv3), ("network.mscale", mscale),
+                      ("network.mscale2", mscale2),
+                      ("loss.utils", criteria), ("loss.rmi", criteria), ("loss.optimizer", optimizer)):
         sys.modules[name] = mod
     return network, loss
 
