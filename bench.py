@@ -57,13 +57,18 @@ def build_model(world):
     cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05        # scripts/train_cityscapes_sota.yml
     cfg.LOSS.OCR_AUX_RMI = False
     cfg.MODEL.N_SCALES = None
-    cfg.MODEL.BNFUNC = snn.SyncBatchNorm if world > 1 else None
+    cfg.MODEL.BNFUNC = snn.SyncBatchNorm if (world > 1 or FORCE_DIST) else None
     torch.manual_seed(0)
     net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255))
     for m in net.modules():                     # random init at a realistic scale
         if isinstance(m, torch.nn.Conv2d):
             torch.nn.init.kaiming_normal_(m.weight)
     return net.cuda().train()
+
+
+# SSA_FORCE_DIST=1: run the N > 1 code path (SyncBN exchanges, DDP hooks, RCCL) in a world of one
+# rank, so that a one-GPU box can exercise it -- in particular inside hipGraph capture.
+FORCE_DIST = os.environ.get("SSA_FORCE_DIST", "0") == "1"
 
 
 def cpu_baseline(timeout_s=150):
@@ -157,13 +162,21 @@ def main():
     # SSA_BENCH_ONE_DEVICE / SSA_DIST_BACKEND: self-test of the N > 1 code path on a one-GPU box
     # (all ranks on cuda:0, gloo collectives); the driver's multi-GPU runs use neither.
     torch.cuda.set_device(0 if os.environ.get("SSA_BENCH_ONE_DEVICE") else local_rank)
-    if world > 1:
+    dist_on = world > 1 or FORCE_DIST
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend=os.environ.get("SSA_DIST_BACKEND", "nccl"), init_method="env://")
 
     net = build_model(world)
     model = net
-    if world > 1:
+    if dist_on:
         from semseg_amd.parallel import DistributedDataParallel
         from semseg_amd import ops as sops
         # N > 1 runs eager (no hipGraph around RCCL calls): the step is host-launch bound, where
@@ -190,7 +203,9 @@ def main():
         static_loss.copy_(loss.detach())
 
     graph = None
-    use_graph = (not args.no_graph) and world == 1
+    # N > 1: the captured graph would contain ~1,270 RCCL collectives (SyncBN exchanges, gradient
+    # buckets); opt-in (SSA_DDP_GRAPH=1) until that has run on a multi-GPU node
+    use_graph = (not args.no_graph) and (not dist_on or os.environ.get("SSA_DDP_GRAPH", "0") == "1")
     graph_error = None
     if use_graph:
         try:
@@ -216,7 +231,7 @@ def main():
         run()
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -345,7 +360,7 @@ def main():
         if graph_error:
             out["config"]["hipgraph_error"] = graph_error
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

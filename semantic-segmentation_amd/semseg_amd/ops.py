@@ -47,8 +47,8 @@ class HipBackend:
     shadow_lo_pass = os.environ.get("SSA_SHADOW", "1") != "0"
 
     def use_shadow_pass(self):
-        import torch.distributed as dist
-        return self.shadow_lo_pass and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        from .parallel import sync_world
+        return self.shadow_lo_pass and not sync_world()
 
     def side_streams(self):
         return list(self._streams.values())

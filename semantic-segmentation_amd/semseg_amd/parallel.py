@@ -7,16 +7,23 @@ is still running (reverse-registration order, >= `message_size` elements per
 bucket, as apex's default of 1e7).  `backend='nccl'` is RCCL on ROCm.
 SyncBN lives in semseg_amd.nn.SyncBatchNorm.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
+
+# SSA_FORCE_DIST=1: treat a world of ONE rank like a distributed job (SyncBN exchanges and the
+# DDP hooks run, over a 1-rank RCCL communicator).  Lets a one-GPU box exercise the c10d code
+# path -- in particular inside hipGraph capture -- that the multi-GPU runs take.
+_FORCE = os.environ.get("SSA_FORCE_DIST", "0") == "1"
 
 
 def sync_world(enabled=True, group=None):
     """World size to synchronise BN statistics over (0 = no synchronisation)."""
     if enabled and dist.is_available() and dist.is_initialized():
         ws = dist.get_world_size(group)
-        return ws if ws > 1 else 0
+        return ws if (ws > 1 or _FORCE) else 0
     return 0
 
 
@@ -40,8 +47,9 @@ class DistributedDataParallel(nn.Module):
         self.group = process_group
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         self.delay_allreduce = delay_allreduce
+        self.active = self.world > 1 or (_FORCE and dist.is_initialized())
         params = [p for p in module.parameters() if p.requires_grad]
-        if self.world > 1:
+        if self.active:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=self.group)
         # buckets in reverse parameter order: the order backward produces grads
@@ -61,7 +69,7 @@ class DistributedDataParallel(nn.Module):
         self._pending = [0] * len(self.buckets)
         self._inflight = []
         self._callback_queued = False
-        if self.world > 1:
+        if self.active:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -96,8 +104,8 @@ class DistributedDataParallel(nn.Module):
             work.wait()
             flat.div_(self.world)
             off = 0
-            for p in self.buckets[bi]:
+            for p in self.buckets[bi]:      # the averaged gradients stay where they are: views of the bucket
                 n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                p.grad = flat[off:off + n].view_as(p)
                 off += n
         self._inflight = []
