@@ -1,0 +1,24 @@
+#!/bin/bash
+# First GPU call of the next round: everything that was written after round 1's GPU budget ran
+# out, in order of value, each leg under its own timeout and with its own log under gpurun_out/.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/next_gpu_call.sh'
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+mkdir -p gpurun_out
+log=gpurun_out/next_gpu_call.log
+: > "$log"
+run() {  # name, timeout, command...
+  local name=$1 t=$2; shift 2
+  echo "== $name" >> "$log"
+  timeout "$t" "$@" > "gpurun_out/$name.log" 2>&1
+  echo "$name rc=$?" >> "$log"
+}
+# 1. tests that have not run on hardware yet (fused SGD variants, filter-cache refresh, OCRNetASPP,
+#    sibling training steps, RCCL inside a captured graph with a one-rank communicator)
+SSA_TEST_UNVERIFIED=1 run unverified_tests 420 python -m pytest tests/test_optim_gpu.py tests/test_siblings_gpu.py \
+    tests/test_ddp_graph_gpu.py -q -s -m gpu
+# 2. fused SGD in the bench (valid now that the version counters are bumped): compare with the default
+SSA_FUSED_SGD=1 run bench_fused_sgd 120 python bench.py --no-cpu-baseline
+run bench_torch_sgd 120 python bench.py --no-cpu-baseline
+# 3. who launches the ~350 aten adds and ~300 D2D copies per step
+run attribute_launches 180 python tools/attribute_launches.py 512
+cat "$log"
