@@ -8,6 +8,7 @@ The optimizer is SGD with momentum and weight decay as ONE streaming pass over
 all parameter tensors in a handful of launches (ssa_sgd_momentum_step); its
 state_dict has torch.optim.SGD's layout ('momentum_buffer'), so the reference's
 checkpoints restore into it (`restore_opt`) and vice versa."""
+import contextlib
 import ctypes
 import math
 
@@ -16,6 +17,17 @@ from torch import optim
 
 from .._lib import lib, check
 from ..config import cfg
+
+
+def _on_gpu(p):
+    return p.is_cuda
+
+
+@contextlib.contextmanager
+def _launch_scope(device):
+    """Make `device` current and yield (stream handle, is that stream being captured)."""
+    with torch.cuda.device(device):
+        yield torch.cuda.current_stream().cuda_stream, torch.cuda.is_current_stream_capturing()
 
 
 class FusedSGD(optim.Optimizer):
@@ -68,7 +80,7 @@ class FusedSGD(optim.Optimizer):
                 if p.grad is None:
                     continue
                 g = p.grad
-                if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse):
+                if not (_on_gpu(p) and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse):
                     raise RuntimeError("FusedSGD updates dense fp32 parameters on the GPU")
                 if not p.is_contiguous():
                     raise RuntimeError("FusedSGD needs contiguous parameters")
@@ -79,16 +91,14 @@ class FusedSGD(optim.Optimizer):
                     st = self.state[p]
                     buf = st.get("momentum_buffer")
                     if buf is None:          # zeros: m*0 + d == d, torch's first step
-                        if torch.cuda.is_current_stream_capturing():
+                        if p.is_cuda and torch.cuda.is_current_stream_capturing():
                             raise RuntimeError("FusedSGD: run one eager step before capturing the step in a "
                                                "graph (the momentum buffers are created on the first step)")
                         buf = st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 by_device.setdefault(p.device, []).append((p, g, buf))
             for device, items in by_device.items():
                 n = len(items)
-                with torch.cuda.device(device):
-                    stream = torch.cuda.current_stream()
-                    capturing = torch.cuda.is_current_stream_capturing()
+                with _launch_scope(device) as (stream, capturing):
                     lr_dev = self._lr_scalar(gi, group, device, capturing)
                     P = (ctypes.c_void_p * n)(*[p.data_ptr() for p, _, _ in items])
                     G = (ctypes.c_void_p * n)(*[g.data_ptr() for _, g, _ in items])
@@ -96,7 +106,7 @@ class FusedSGD(optim.Optimizer):
                     N = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
                     check(lib().ssa_sgd_momentum_step(P, G, Bf, N, n, float(group["lr"]), lr_dev.data_ptr(),
                                                       momentum, float(group["weight_decay"]),
-                                                      int(bool(group["nesterov"])), stream.cuda_stream),
+                                                      int(bool(group["nesterov"])), stream),
                           "ssa_sgd_momentum_step")
                 # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and the
                 # packed-filter cache (hip_backend.refresh_packed_filters keys on ._version) that

@@ -51,6 +51,10 @@ def dry(monkeypatch):
     d = DryLib(real)
     monkeypatch.setattr(_lib, "_LIB", d)
     monkeypatch.setattr(hip_backend, "_s", lambda: None)
+    from semseg_amd.loss import optimizer as sopt
+    import contextlib
+    monkeypatch.setattr(sopt, "_on_gpu", lambda p: True)
+    monkeypatch.setattr(sopt, "_launch_scope", lambda device: contextlib.nullcontext((None, False)))
     hip_backend.clear_pack_cache()
     prev = ops._BACKEND
     ops._set_backend_for_tests(ops.HipBackend())
@@ -116,3 +120,22 @@ def test_train_step_and_eval_glue(name, crit, dry):
             out = net({"images": inputs["images"]})
         cfg.MODEL.N_SCALES = None
         assert tuple(out["pred"].shape) == (2, 19, 64, 96)
+
+
+def test_fused_sgd_step_glue_and_filter_cache_refresh(dry):
+    """The optimizer's launch arguments match the C signature, and its version-counter bump makes
+    the next step re-pack the filters in ONE batched launch (the cache keys on ._version)."""
+    from semseg_amd.loss.optimizer import FusedSGD
+    net = _build("deepv3.DeepV3PlusR50", "ce").train()
+    opt = FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    inputs = _batch()
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        net(inputs).backward()
+        versions = [p._version for p in net.parameters()]
+        opt.step()
+        assert all(p._version > v for p, v in zip(net.parameters(), versions))
+        assert dry.calls["ssa_sgd_momentum_step"] == step + 1
+    # steps 2 and 3 start from updated parameters: exactly one batched re-pack each, no single packs
+    assert dry.calls["ssa_pack_filters_batched"] == 2
+    assert all("momentum_buffer" in opt.state[p] for p in net.parameters())
