@@ -115,6 +115,18 @@ int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad,
                             int Cout, int Cin_pad, int Cin, int KH, int KW,
                             float* dw_oihw, void* stream);
 
+/* The same reduce for MANY layers at once: the host glue defers the per-layer reduces of a
+ * backward pass and hands the whole list over at its end (641 layers per training step ->
+ * 9 launches).  `jobs` is a HOST array; up to 72 jobs travel per launch as kernel
+ * arguments.  Arithmetic and summation order are those of ssa_conv2d_wgrad_reduce
+ * (bit-identical results).                                                            */
+typedef struct ssa_wgrad_reduce_job {
+  const float* partial;  /* [nsplit][cout_pad][KH*KW*Cin_pad] fp32                     */
+  float* dw;             /* [Cout][Cin][KH][KW] fp32                                    */
+  int nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, pad_;
+} ssa_wgrad_reduce_job;
+int ssa_conv2d_wgrad_reduce_batched(const ssa_wgrad_reduce_job* jobs, int njobs, void* stream);
+
 /* All filters of a network repacked in ONE launch (the parameters change every
  * optimizer step; 1,276 separate pack launches cost more than the packing).
  * jobs_dev: device array of ssa_pack_job; same semantics as ssa_pack_filter.  */

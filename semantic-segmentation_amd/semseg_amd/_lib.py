@@ -28,6 +28,12 @@ class BnUpdateJob(ctypes.Structure):
                 ("pad_", c_int)]
 
 
+class WgradReduceJob(ctypes.Structure):
+    """Mirror of ssa_wgrad_reduce_job (48 bytes)."""
+    _fields_ = [("partial", c_void_p), ("dw", c_void_p)] + [(n, c_int) for n in (
+        "nsplit", "cout_pad", "Cout", "Cin_pad", "Cin", "KH", "KW", "pad_")]
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of ssa_conv_desc."""
     _fields_ = [(n, c_int) for n in (
@@ -54,6 +60,7 @@ _SIGS = {
     "ssa_conv2d_wgrad_head_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_head": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, _P], c_int),
+    "ssa_conv2d_wgrad_reduce_batched": ([_P, c_int, _P], c_int),
     "ssa_colsum_bf16": ([_P, c_long, c_int, c_int, _P, _P, _P], c_int),
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),

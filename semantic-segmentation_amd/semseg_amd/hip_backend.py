@@ -11,11 +11,12 @@ from torch's caching allocator, kernels are enqueued on the current stream.
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.distributed as dist
 
-from ._lib import lib, check, ConvDesc
+from ._lib import lib, check, ConvDesc, WgradReduceJob
 
 ACT_DTYPE = torch.bfloat16
 
@@ -236,6 +237,8 @@ def end_forward():
 
 def begin_step(device=None):
     _BN_UPDATES.step = {}
+    del _PENDING_REDUCES[:]                  # (left over only if a backward pass was aborted)
+    _REDUCE_CALLBACK_QUEUED[0] = False
     refresh_packed_filters()
     if device is not None:
         _ARENA.reset(device)
@@ -328,8 +331,10 @@ _PENDING_STATS = [None]
 _NO_IGEMM_STATS = bool(__import__("os").environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
 
 
-def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real):
-    """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)]."""
+def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, deferrable=False):
+    """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)].
+    deferrable: the result is a parameter gradient that nobody reads before the end of backward
+    (Conv2dFn.backward) -- its reduce may be batched with the others (SSA_DEFER_WGRAD_REDUCE)."""
     B, H, W, Cin = geom_in
     Ho, Wo = geom_out
     d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, 0, 0, 0, -1)
@@ -356,9 +361,66 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
                          2.0 * B * Ho * Wo * Cout * Cin_real * k[0] * k[1], e0, e1,
                          (k[0], stride, Cin, Cout, Ho, Wo)))
     dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
+    if deferrable and _DEFER_WGRAD_REDUCE and _defer_allowed():
+        _defer_reduce(partial, dw, WgradReduceJob(partial.data_ptr(), dw.data_ptr(), nsplit.value, cout_pad, Cout,
+                                                  Cin, Cin_real, k[0], k[1], 0))
+        return dw
     check(L.ssa_conv2d_wgrad_reduce(_p(partial), nsplit.value, cout_pad, Cout, Cin, Cin_real, k[0], k[1],
                                     _p(dw), _s()), "ssa_conv2d_wgrad_reduce")
     return dw
+
+
+# --------------------------------------------------------------------------
+# Deferred weight-gradient reduces (SSA_DEFER_WGRAD_REDUCE=1, off by default until it has run on
+# hardware): every conv's backward ends in a ~6 us reduce of its split-K partials, 641 per
+# training step.  Nobody reads a weight gradient before backward has finished (autograd only
+# stores the tensor), so the reduces are collected and issued at the end of backward in ~9
+# launches (ssa_conv2d_wgrad_reduce_batched).  Not under torch.distributed: DDP's hooks read
+# the gradients while backward is still running.
+# --------------------------------------------------------------------------
+_DEFER_WGRAD_REDUCE = os.environ.get("SSA_DEFER_WGRAD_REDUCE", "0") == "1"
+_PENDING_REDUCES = []
+_REDUCE_CALLBACK_QUEUED = [False]
+
+
+def _defer_allowed():
+    from .parallel import sync_world
+    return not sync_world()
+
+
+def _defer_reduce(partial, dw, job):
+    _PENDING_REDUCES.append((partial, dw, job))
+    if not _REDUCE_CALLBACK_QUEUED[0]:
+        from torch.autograd import Variable
+        Variable._execution_engine.queue_callback(flush_wgrad_reduces)
+        _REDUCE_CALLBACK_QUEUED[0] = True
+
+
+def flush_wgrad_reduces(side_streams=()):
+    """Issue the deferred reduces on the current stream.  Runs as an end-of-backward callback;
+    anything that reads weight gradients from another end-of-backward callback (the shadow
+    gradient merge of MscaleOCR) calls it first -- a second call finds nothing to do."""
+    _REDUCE_CALLBACK_QUEUED[0] = False
+    if not _PENDING_REDUCES:
+        return
+    jobs = list(_PENDING_REDUCES)
+    del _PENDING_REDUCES[:]
+    on_gpu = jobs[0][0].is_cuda
+    if on_gpu:
+        main = torch.cuda.current_stream()
+        for st in side_streams or _all_side_streams():
+            main.wait_stream(st)             # partials of the other scale pass were produced there
+    arr = (WgradReduceJob * len(jobs))(*[j for _, _, j in jobs])
+    check(lib().ssa_conv2d_wgrad_reduce_batched(arr, len(jobs), _s()), "ssa_conv2d_wgrad_reduce_batched")
+    if on_gpu:
+        for partial, dw, _ in jobs:          # allocated on the producing stream, used on this one
+            partial.record_stream(main)
+            dw.record_stream(main)
+
+
+def _all_side_streams():
+    from . import ops
+    return ops.backend().side_streams() if hasattr(ops.backend(), "side_streams") else []
 
 
 def _grad_as_bf16(dy, Cout):
@@ -443,7 +505,7 @@ class Conv2dFn(torch.autograd.Function):
                             dil * (KH - 1) - pad, dil, stride > 1, False)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(x, ldx, (B, H, W, Cin), dyb, lddy, cout_pad, (Ho, Wo), (KH, KW), stride, pad, dil,
-                        Cout, Cin_real)
+                        Cout, Cin_real, deferrable=weight.dtype == torch.float32)
             if dw.dtype != weight.dtype:
                 dw = dw.to(weight.dtype)
         if has_bias and ctx.needs_input_grad[2]:

@@ -244,6 +244,7 @@ class MscaleOCR(_Base):
 
     def _merge_shadow_grads(self):
         shadows, params = self._shadow
+        getattr(ops.backend(), "flush_backward", lambda: None)()    # deferred weight-gradient reduces first
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
         if main is not None:
             for st in getattr(ops.backend(), "side_streams", lambda: [])():

@@ -117,6 +117,10 @@ class HipBackend:
     def end_forward(self):
         self.hb.end_forward()
 
+    def flush_backward(self):
+        """Deferred backward work whose results another end-of-backward callback is about to read."""
+        self.hb.flush_wgrad_reduces()
+
     def sum_act(self, tensors, relu=True):
         return self.hb.SumActFn.apply(relu, *tensors)
 

@@ -139,3 +139,37 @@ def test_fused_sgd_step_glue_and_filter_cache_refresh(dry):
     # steps 2 and 3 start from updated parameters: exactly one batched re-pack each, no single packs
     assert dry.calls["ssa_pack_filters_batched"] == 2
     assert all("momentum_buffer" in opt.state[p] for p in net.parameters())
+
+
+def test_deferred_wgrad_reduce_glue(dry, monkeypatch):
+    """SSA_DEFER_WGRAD_REDUCE: no per-layer reduce, one batched call per backward, issued before the
+    shadow-gradient merge reads the weight gradients; every parameter still gets its gradient."""
+    from semseg_amd import hip_backend
+    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
+    inputs = _batch()
+    net(inputs).backward()                   # baseline: one reduce per conv weight gradient + the OCR products
+    baseline = dry.calls["ssa_conv2d_wgrad_reduce"]
+    dry.calls.clear()
+    monkeypatch.setattr(hip_backend, "_DEFER_WGRAD_REDUCE", True)
+    order = []
+    real_flush = hip_backend.flush_wgrad_reduces
+    monkeypatch.setattr(hip_backend, "flush_wgrad_reduces",
+                        lambda *a, **k: (order.append(("flush", len(hip_backend._PENDING_REDUCES))), real_flush(*a, **k))[1])
+    import torch as _t
+    real_add = _t._foreach_add_
+    monkeypatch.setattr(_t, "_foreach_add_", lambda *a, **k: (order.append(("merge", 0)), real_add(*a, **k))[1])
+    for step in range(2):
+        net.zero_grad(set_to_none=True)
+        net(inputs).backward()
+        flushed = [n for k, n in order if k == "flush" and n > 0]
+        assert len(flushed) == step + 1
+        # what is still reduced layer by layer (the OCR matrix products) + the batch == the baseline
+        assert dry.calls["ssa_conv2d_wgrad_reduce"] // (step + 1) + flushed[-1] == baseline
+        assert flushed[-1] > 600
+        assert dry.calls["ssa_conv2d_wgrad_reduce_batched"] == step + 1
+        assert not hip_backend._PENDING_REDUCES
+        assert all(p.grad is not None for p in net.parameters())
+    # the flush that found work came before the merge of the 0.5x pass's gradients
+    first_work = next(i for i, (k, n) in enumerate(order) if k == "flush" and n > 0)
+    first_merge = next(i for i, (k, n) in enumerate(order) if k == "merge")
+    assert first_work < first_merge, order[:6]
