@@ -77,6 +77,23 @@ int ssa_conv2d_tile_supported(const ssa_conv_desc* d);
 int ssa_conv2d_tile(const ssa_conv_desc* d, const void* x, const void* w_frag,
                     const float* bias, void* y, double* stats, void* stream);
 int ssa_bn_stat_replicas(void);
+/* The same convolution as the DATA GRADIENT of a residual block's conv (flipped, transposed
+ * filter: ssa_pack_filter mode 3), with a second tile `aux` ([B,H,W,>=Cout] bf16, pixel stride
+ * ldaux), congruent with the output, folded into the epilogue:
+ *   aux_mode 1: y = bf16(bf16(conv) + aux) -- the gradient of the identity branch
+ *               (network/hrnetv2.py:58-64 `out += residual`) added where autograd would launch
+ *               a separate add; stats must be NULL.
+ *   aux_mode 2: aux is the input x of the BatchNorm+ReLU layer whose output this conv consumed
+ *               (conv1 -> bn1 -> relu -> conv2, network/hrnetv2.py:44-56); besides y = dz the
+ *               epilogue ACCUMULATES that layer's backward sums into stats
+ *               [ssa_bn_stat_replicas()][2][Cout] fp64:  sum(m*dz), sum(m*dz*xhat),
+ *               m = [coef[0][c]*x + coef[1][c] > 0], xhat = (x - coef[2][c]) * coef[3][c]
+ *               (coef = the [4][Cout] table ssa_bn_apply_train wrote) -- replaces the
+ *               ssa_bn_bwd_reduce pass over (x, dz) of that layer.
+ * Same shape support as ssa_conv2d_tile.                                                  */
+int ssa_conv2d_tile_aux(const ssa_conv_desc* d, const void* x, const void* w_frag,
+                        const float* bias, void* y, double* stats, const void* aux, int ldaux,
+                        const float* coef, int aux_mode, void* stream);
 
 /* Halo-chunk implicit GEMM for the large-channel 3x3 / 1x1 stride-1 "same" convs
  * of the OCR and attention heads (Cin >= 192, Cin % 48 == 0 or % 64 == 0):

@@ -1,0 +1,378 @@
+// Halo-tile convolution with a fused epilogue tile -- the DATA-GRADIENT variant of
+// conv_tile.hip (same staging, same MFMA loop, same tiling and dispatch), kept in a file of
+// its own so that the measured forward/dgrad kernel stays byte-for-byte what was validated
+// and profiled; the two are to be merged once this variant has been validated on hardware
+// (it is reached only through ssa_conv2d_tile_aux, which the host glue uses under
+// SSA_FUSE_BWD=1).
+//
+// A second tile `aux`, congruent with the output tile, is staged through LDS in the epilogue:
+//   aux_mode 1: added to the output -- the residual branch's gradient, dX = dgrad + dres,
+//               rounded as the unfused bf16 add rounds (bf16(bf16(dgrad) + dres));
+//   aux_mode 2: taken as the INPUT x of the BatchNorm+ReLU layer whose output this conv
+//               consumed (network/hrnetv2.py:44-64: conv1 -> bn1 -> relu -> conv2): the epilogue
+//               accumulates that layer's backward sums  sum(m*dz)  and  sum(m*dz*xhat),
+//               m = [scale*x+shift > 0], xhat = (x-mean)*invstd, over the bf16-rounded dz it
+//               stores (coef = [4][Cout]: scale, shift, mean, invstd) into `stats`
+//               ([replica][2][Cout] fp64) -- what bn_bwd_reduce_kernel (bn.hip) computes in a
+//               pass of its own over (x, dz).
+#include "common.h"
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+constexpr int kStatReplicas = 8;   // BN partial sums are spread over 8 replicas (atomic contention)
+
+// Filter stage (channel chunk cc, taps [tap0, tap0+TPC)) of the NB n-blocks -> LDS
+// buffer, as direct global->LDS DMA: one global_load_lds_dwordx4 per wave moves one
+// 1-KiB (n-block, k-step) fragment block; the LDS image is lane-linear, which is
+// exactly the order ds_read_b128 wants the B fragment in.
+template <int NB, int TPC, int CST>
+__device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfrag, int nb0,
+                                                   int nb_total, int ksteps_total, int csteps_total,
+                                                   int cc, int tap0, unsigned char* dst, int wave,
+                                                   int lane) {
+  constexpr int PER_NB = TPC * CST;
+  constexpr int NFRAG = NB * PER_NB;
+#pragma unroll
+  for (int f = 0; f < (NFRAG + 3) / 4; ++f) {
+    const int fi = f * 4 + wave;               // wave-uniform
+    if (fi < NFRAG) {
+      const int nb = fi / PER_NB, rem = fi - nb * PER_NB;
+      const int tl = rem / CST, j = rem - tl * CST;
+      const int nbg = min(nb0 + nb, nb_total - 1);   // n-blocks past the end re-read the last one (never stored)
+      const uint4* src = wfrag + ((long)nbg * ksteps_total + (tap0 + tl) * csteps_total + cc * CST + j) * 64 + lane;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(dst + (size_t)fi * 1024), 16, 0, 0);
+    }
+  }
+}
+
+// CK: input channels staged per halo image (= Cin for 48/64/96; 192 for Cin = 192/384,
+// which run Cin/CK passes over the taps), TPC: taps per filter stage.
+template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
+__device__ __forceinline__ void conv_tile_body(
+    const bf16_t* __restrict__ x, int ldx, int Cin, const uint4* __restrict__ wfrag,
+    const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
+    int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats,
+    const bf16_t* __restrict__ aux, int ldaux, const float* __restrict__ coef, int aux_mode) {
+  constexpr int R = KS / 2;
+  constexpr int BM = 4 * MI * 32;              // output pixels per workgroup
+  constexpr int TH = BM / TW;                  // tile rows
+  constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
+  constexpr int PSB = CK * 2 + 16;             // halo pixel stride in bytes
+  constexpr int CP = CK / 8;                   // 16-byte pieces per pixel
+  constexpr int NPIECE = HH_ * HW_ * CP;
+  constexpr int CST = CK / 16;                 // c-steps per halo chunk
+  constexpr int TAPS = KS * KS;
+  constexpr int NSTAGE = TAPS / TPC;           // filter stages per channel chunk
+  static_assert(NSTAGE * TPC == TAPS, "taps per stage must divide the tap count");
+  constexpr int STAGE_KS = TPC * CST;          // k-steps per filter stage
+  constexpr int STAGE_BYTES = NB * STAGE_KS * 1024;
+  constexpr int NBUF = NSTAGE > 1 ? 2 : 1;
+  constexpr int HALO_BYTES = (HH_ * HW_ * PSB + 1023) / 1024 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Bs = smem + HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x; bid /= tiles_x;
+  const int ty_i = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int nb0 = blockIdx.y * NB;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int nchunk = Cin / CK;
+  const int csteps_total = Cin / 16;
+  const int ksteps_total = TAPS * csteps_total;
+
+  // ---- per-lane A addressing: MFMA row block mi of this wave -> tile pixels
+  int a_off[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = (wave * MI + mi) * 32 + (lane & 31);
+    const int ty = m / TW, tx = m - ty * TW;
+    a_off[mi] = (ty * HW_ + tx) * PSB + (lane >> 5) * 16;
+  }
+
+  f32x16_t acc[MI][NB];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
+
+  const bf16_t* xb = x + (long)b * H * W * ldx;
+  for (int cc = 0; cc < nchunk; ++cc) {
+    if (cc > 0) __syncthreads();                // previous chunk's halo image and filter buffers are free
+    // ---- halo tile -> registers, filter stage 0 -> LDS (DMA), halo -> LDS: one burst
+    {
+      constexpr int IT = (NPIECE + 255) / 256;
+      uint4 v[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int piece = tid + i * 256;
+        const int pix = piece / CP, cp = piece - pix * CP;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int iy = y0 - R + hy, ix = x0 - R + hx;
+        const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        v[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cc * CK + cp * 8)
+                  : make_uint4(0, 0, 0, 0);
+      }
+      stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, 0, Bs, wave, lane);
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int piece = tid + i * 256;
+        const int pix = piece / CP, cp = piece - pix * CP;
+        if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
+      }
+    }
+    __syncthreads();                            // halo + filter stage 0 landed (vmcnt(0) + barrier)
+
+#pragma unroll
+    for (int st = 0; st < NSTAGE; ++st) {
+      if (st + 1 < NSTAGE)
+        stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, (st + 1) * TPC,
+                                         Bs + ((st + 1) % NBUF) * STAGE_BYTES, wave, lane);
+      const unsigned char* Bc = Bs + (st % NBUF) * STAGE_BYTES + lane * 16;
+#pragma unroll
+      for (int ksl = 0; ksl < STAGE_KS; ++ksl) {
+        const int tap = st * TPC + ksl / CST, cs = ksl % CST;
+        const int kh = tap / KS, kw = tap - kh * KS;
+        bf16x8_t af[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          af[mi] = *reinterpret_cast<const bf16x8_t*>(smem + a_off[mi] + (kh * HW_ + kw) * PSB + cs * 32);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * STAGE_KS + ksl) * 1024);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][nb], 0, 0, 0);
+        }
+      }
+      if (st + 1 < NSTAGE) __syncthreads();     // next stage landed; this buffer is free for stage st+2
+    }
+  }
+
+  // ---- epilogue: (+bias) -> bf16 -> LDS -> coalesced 16-byte stores; BN statistics
+  __syncthreads();                              // everyone is done reading the halo image
+  constexpr int LDC = NB * 32 + 8;              // staging row stride (elements)
+  constexpr int CPR = NB * 4;                   // 16-byte pieces per staged row
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 waves][2][NB*32]
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem + (size_t)BM * LDC * 2 + (size_t)4 * 2 * NB * 32 * sizeof(float));
+  if constexpr (AUX) {
+    // the aux tile (same pixels, same channels as the output tile) -> LDS, zero outside the image
+    const bf16_t* ab = aux + (long)b * H * W * ldaux;
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, cp = idx - row * CPR;
+      const int ty = row / TW, tx = row - ty * TW;
+      const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oy < H && ox < W && n + 8 <= Cout) v = *reinterpret_cast<const uint4*>(ab + ((long)oy * W + ox) * ldaux + n);
+      *reinterpret_cast<uint4*>(Xs + row * LDC + cp * 8) = v;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 32 + (lane & 31);
+    const int n = nb0 * 32 + col;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+    float s = 0.f, q = 0.f;
+    float ma = 0.f, mb = 0.f, mu = 0.f, is = 0.f;
+    if constexpr (AUX) {
+      if (aux_mode == 2 && n < Cout) { ma = coef[n]; mb = coef[Cout + n]; mu = coef[2 * Cout + n]; is = coef[3 * Cout + n]; }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        bf16_t o = f2bf(acc[mi][nb][r] + bv);
+        if constexpr (AUX) {
+          const float xv = bf2f(Xs[row * LDC + col]);
+          if (aux_mode == 1) {
+            o = f2bf(bf2f(o) + xv);
+          } else {
+            const int ty = row / TW, tx = row - ty * TW;
+            const float gz = (y0 + ty < H && x0 + tx < W) ? bf2f(o) : 0.f;
+            const float gm = (xv * ma + mb) > 0.f ? gz : 0.f;
+            s += gm;
+            q += gm * (xv - mu) * is;
+          }
+        }
+        Cs[row * LDC + col] = o;
+        if (!(AUX) && stats != nullptr) {
+          const int ty = row / TW, tx = row - ty * TW;
+          const float f = (y0 + ty < H && x0 + tx < W) ? bf2f(o) : 0.f;
+          s += f;
+          q += f * f;
+        }
+      }
+    }
+    if (stats != nullptr) {
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        red[(wave * 2 + 0) * NB * 32 + col] = s;
+        red[(wave * 2 + 1) * NB * 32 + col] = q;
+      }
+    }
+  }
+  __syncthreads();
+  if (stats != nullptr) {
+    // stats layout: [replica][2][C]; replica = workgroup index mod kStatReplicas
+    double* st = stats + (long)(blockIdx.x % kStatReplicas) * 2 * Cout;
+    for (int i = tid; i < 2 * NB * 32; i += 256) {
+      const int which = i / (NB * 32), col = i - which * NB * 32;
+      const int n = nb0 * 32 + col;
+      if (n < Cout) {
+        const float v = (red[(0 * 2 + which) * NB * 32 + col] + red[(1 * 2 + which) * NB * 32 + col]) +
+                        (red[(2 * 2 + which) * NB * 32 + col] + red[(3 * 2 + which) * NB * 32 + col]);
+        atomicAdd(&st[which * Cout + n], (double)v);
+      }
+    }
+  }
+  bf16_t* yb = y + (long)b * H * W * ldy;
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, cp = idx - row * CPR;
+    const int ty = row / TW, tx = row - ty * TW;
+    const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
+    if (oy >= H || ox >= W || n >= Cout) continue;
+    bf16_t* dst = yb + ((long)oy * W + ox) * ldy + n;
+    const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (n + 8 <= Cout) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+template <int CK, int KS, int NB, int MI, int TW, int TPC>
+__global__ __launch_bounds__(256) void conv_tile_aux_kernel(
+    const bf16_t* __restrict__ x, int ldx, int Cin, const uint4* __restrict__ wfrag,
+    const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
+    int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats,
+    const bf16_t* __restrict__ aux, int ldaux, const float* __restrict__ coef, int aux_mode) {
+  conv_tile_body<CK, KS, NB, MI, TW, TPC, true>(x, ldx, Cin, wfrag, bias, y, ldy, B, H, W, Cout, nb_total,
+                                                tiles_x, tiles_y, stats, aux, ldaux, coef, aux_mode);
+}
+
+struct AuxArgs {
+  const void* aux;
+  int ld;
+  const float* coef;
+  int mode;               // 1: add, 2: BatchNorm backward sums
+};
+
+template <int CK, int KS, int NB, int MI, int TW, int TPC>
+int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
+                double* stats, hipStream_t s, const AuxArgs& ax) {
+  constexpr int R = KS / 2, BM = 4 * MI * 32, TH = BM / TW;
+  constexpr int NSTAGE = KS * KS / TPC;
+  constexpr size_t halo = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (CK * 2 + 16) + 1023) / 1024 * 1024;
+  constexpr size_t filt = (size_t)(NSTAGE > 1 ? 2 : 1) * NB * TPC * (CK / 16) * 1024;
+  // epilogue staging: output tile + reduction scratch + aux tile
+  constexpr size_t stage = (size_t)2 * BM * (NB * 32 + 8) * 2 + 4 * 2 * NB * 32 * sizeof(float);
+  constexpr size_t lds = halo + filt > stage ? halo + filt : stage;
+  static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
+  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
+  const int nb_total = (d.Cout + 31) / 32;
+  auto kern = conv_tile_aux_kernel<CK, KS, NB, MI, TW, TPC>;
+  if (lds > 64 * 1024) {
+    static bool once = false;                  // per template instantiation
+    if (!once) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      once = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * d.B, (nb_total + NB - 1) / NB), dim3(256), lds, s,
+                     (const bf16_t*)x, d.ldx, d.Cin, (const uint4*)wfrag, bias, (bf16_t*)y, d.ldy, d.B, d.H,
+                     d.W, d.Cout, nb_total, tiles_x, tiles_y, stats, (const bf16_t*)ax.aux, ax.ld, ax.coef,
+                     ax.mode);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+// tile shape by image width, as in conv_tile.hip
+template <int CK, int KS, int NB, int TPC, bool BIG_OK, bool NARROW_OK = true>
+int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
+                  double* stats, hipStream_t s, bool want_big, const AuxArgs& ax) {
+  if (d.W >= 32 || !NARROW_OK) {
+    if constexpr (BIG_OK) {
+      if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s, ax);
+    }
+    return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s, ax);
+  }
+  if constexpr (NARROW_OK) {
+    if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s, ax);
+    return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s, ax);
+  }
+  return SSA_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" {
+
+namespace {
+int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias, void* y,
+              double* stats, const AuxArgs& ax, void* stream);
+}
+
+int ssa_conv2d_tile_aux(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
+                        void* y, double* stats, const void* aux, int ldaux, const float* coef,
+                        int aux_mode, void* stream) {
+  if (aux_mode != 1 && aux_mode != 2) return SSA_EINVAL;
+  if (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u)) return SSA_EINVAL;
+  if (aux_mode == 2 && (!coef || !stats)) return SSA_EINVAL;
+  if (aux_mode == 1 && stats) return SSA_EINVAL;          // forward statistics are not part of this epilogue
+  return tile_impl(dp, x, w_frag, bias, y, stats, AuxArgs{aux, ldaux, coef, aux_mode}, stream);
+}
+
+namespace {
+int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias, void* y,
+              double* stats, const AuxArgs& ax, void* stream) {
+  if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
+  if (!ssa_conv2d_tile_supported(dp)) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
+    return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  const int nbt = (d.Cout + 31) / 32;
+  // Measured on MI355X (tools/convbench, profiles/r01_convbench.txt): these layers are
+  // latency bound, more and smaller workgroups win everywhere -- 128-pixel tiles and one
+  // n-block per workgroup (2-3 workgroups per CU) -- except the 48-channel layers at
+  // >= 512 tiles, where both n-blocks in one workgroup save the second halo read.
+  // cfg >= 0 (benchmark knob): bit 0 = 128-pixel tile, bit 1 = one n-block per workgroup.
+  const long tiles128 = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
+  const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && tiles128 >= 512) ? 0 : 2)) : d.cfg;
+  const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
+  const bool split_n = (cfg & 2) != 0;
+  switch (d.Cin) {
+    case 48:
+      if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<48, 3, 2, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<48, 3, 3, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    case 64:
+      if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    case 96:
+      if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    case 192:
+    case 384:      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
+      if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    default: return SSA_EUNSUPPORTED;
+  }
+}
+}  // namespace
+
+}  // extern "C"

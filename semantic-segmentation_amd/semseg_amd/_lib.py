@@ -49,6 +49,7 @@ _SIGS = {
     "ssa_conv2d_igemm_tile": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_tile_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_tile": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
+    "ssa_conv2d_tile_aux": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stat_replicas": ([], c_int),
     "ssa_conv2d_halo_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),

@@ -325,6 +325,61 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False):
     return y
 
 
+# --------------------------------------------------------------------------
+# Backward fusions (SSA_FUSE_BWD=1, off by default until they have run on hardware):
+#   * the backward sums of a BatchNorm+ReLU layer whose output feeds ONE conv are accumulated in
+#     the epilogue of that conv's data-gradient kernel (ssa_conv2d_tile_aux mode 2) instead of a
+#     bn_bwd_reduce pass over (x, dz);
+#   * the gradient of a residual block's identity branch is added in the epilogue of conv1's
+#     data-gradient kernel (mode 1) instead of autograd's separate add.
+# The modules say which tensors qualify (nn.conv_bn(private_input=, block=)); the links below
+# carry the hand-over between the autograd Functions involved.
+# --------------------------------------------------------------------------
+_FUSE_BWD = os.environ.get("SSA_FUSE_BWD", "0") == "1"
+
+
+class BnLink:
+    """BatchNorm+ReLU layer -> the conv that alone consumes its output."""
+    __slots__ = ("x", "ldx", "coef", "C", "sums", "dz_ptr")
+
+    def __init__(self):
+        self.x = self.coef = self.sums = self.dz_ptr = None
+        self.ldx = self.C = 0
+
+
+class ResLink:
+    """Residual block: conv1 (first consumer of the block input) <-> bn2 (adds the block input)."""
+    __slots__ = ("fused", "dres", "ld")
+
+    def __init__(self):
+        self.fused = False
+        self.dres = None
+        self.ld = 0
+
+
+# side channels from the HipBackend wrappers to the next Function.forward (popped there)
+_NEXT_BN_OUT_LINK = [None]      # BatchNormActFn: link to fill for the layer's consumer
+_NEXT_CONV_IN_LINK = [None]     # Conv2dFn: link of the BN layer whose output is this conv's private input
+_NEXT_CONV_RES_LINK = [None]    # Conv2dFn: residual block this conv is conv1 of
+_NEXT_BN_RES_LINK = [None]      # BatchNormActFn: residual block this layer is bn2 of
+
+
+def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
+    """conv_tile_aux.hip: the tile data gradient with the fused epilogue tile (see header)."""
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=ACT_DTYPE, device=x.device)
+    check(lib().ssa_conv2d_tile_aux(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats), _p(aux), ldaux,
+                                    _p(coef), mode, _s()), "ssa_conv2d_tile_aux")
+    return y
+
+
+def _add_bf16(a, b):
+    """a + b for two dense bf16 tensors of one shape (ssa_sum_act without the ReLU)."""
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    check(lib().ssa_sum_act(_p(a), _p(b), None, None, _p(out), out.numel(), 0, _s()), "ssa_sum_act")
+    return out
+
+
 # (data_ptr of a conv output, its BN partial sums [nrep][2][C], nrep): handed from the conv
 # epilogue to the BatchNorm that consumes that output next (HipBackend.conv_bn_act)
 _PENDING_STATS = [None]
@@ -480,6 +535,16 @@ class Conv2dFn(torch.autograd.Function):
                 _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
         ctx.save_for_backward(x, weight)
         ctx.meta = (ldx, stride, pad, dil, bias is not None, (Ho, Wo))
+        ctx.bn_link = ctx.res_link = None
+        if _FUSE_BWD:
+            ctx.bn_link, _NEXT_CONV_IN_LINK[0] = _NEXT_CONV_IN_LINK[0], None
+            ctx.res_link, _NEXT_CONV_RES_LINK[0] = _NEXT_CONV_RES_LINK[0], None
+            if ctx.res_link is not None:
+                # bn2 hands the identity branch's gradient over only if this conv's data gradient
+                # will run on the tile kernel (decided here, bn2's forward comes later)
+                cp = _roundup(Cout, 8)
+                tdg = _tile_desc(B, Ho, Wo, cp, cp, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W, False)
+                ctx.res_link.fused = bool(Cin == Cin_real and tile_supported(tdg))
         return y
 
     @staticmethod
@@ -496,13 +561,28 @@ class Conv2dFn(torch.autograd.Function):
                             False)
             use_tile = dyb.data_ptr() % 16 == 0 and tile_supported(td)
             use_halo = (not use_tile) and dyb.data_ptr() % 16 == 0 and halo_supported(td)
+            bn_link, res_link = ctx.bn_link, ctx.res_link
+            dres = None
+            if res_link is not None:
+                dres, res_link.dres = res_link.dres, None
             if use_tile or use_halo:
                 wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
-                dx = _tile_conv(td, dyb, wpt, None, None, halo=use_halo)
+                if use_tile and bn_link is not None and bn_link.x is not None and dres is None and \
+                        tuple(bn_link.x.shape) == (B, H, W, Cin) and bn_link.x.data_ptr() % 16 == 0:
+                    sums = _ARENA.take(stat_replicas() * 2 * Cin, x.device)
+                    dx = _tile_conv_aux(td, dyb, wpt, sums, bn_link.x, bn_link.ldx, bn_link.coef, 2)
+                    bn_link.sums, bn_link.dz_ptr = sums, dx.data_ptr()
+                elif use_tile and dres is not None and dres.data_ptr() % 16 == 0:
+                    dx = _tile_conv_aux(td, dyb, wpt, None, dres, res_link.ld, None, 1)
+                    dres = None
+                else:
+                    dx = _tile_conv(td, dyb, wpt, None, None, halo=use_halo)
             else:
                 wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
                 dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
                             dil * (KH - 1) - pad, dil, stride > 1, False)
+            if dres is not None:          # handed over but not fused after all: add it here
+                dx = _add_bf16(dx, dres)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(x, ldx, (B, H, W, Cin), dyb, lddy, cout_pad, (Ho, Wo), (KH, KW), stride, pad, dil,
                         Cout, Cin_real, deferrable=weight.dtype == torch.float32)
@@ -530,6 +610,10 @@ class BatchNormActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, nbt, momentum, eps, training,
                 relu, sync, pass_stats=None):
         L = lib()
+        out_link = res_link = None
+        if _FUSE_BWD:
+            out_link, _NEXT_BN_OUT_LINK[0] = _NEXT_BN_OUT_LINK[0], None
+            res_link, _NEXT_BN_RES_LINK[0] = _NEXT_BN_RES_LINK[0], None
         x, ldx = _pixels(x)
         B, H, W, C = x.shape
         P = B * H * W
@@ -569,6 +653,12 @@ class BatchNormActFn(torch.autograd.Function):
         mask_from_x = relu and residual is None and pst is None
         ctx.save_for_backward(x, z if (relu and not mask_from_x) else None, g, coef, pst)
         ctx.meta = (ldx, relu, training, world, residual is not None, count, mask_from_x)
+        ctx.out_link = ctx.res_link = None
+        if out_link is not None and training and mask_from_x:
+            out_link.x, out_link.ldx, out_link.coef, out_link.C = x, ldx, coef, C
+            ctx.out_link = out_link
+        if res_link is not None and residual is not None and res_link.fused:
+            ctx.res_link = res_link
         return z
 
     @staticmethod
@@ -584,10 +674,17 @@ class BatchNormActFn(torch.autograd.Function):
         if lddz % 8 or dz.data_ptr() % 16:
             dz, lddz = dz.contiguous(), C
         nrep = stat_replicas() if training else 1
-        sums = _ARENA.take(nrep * 2 * C, dev)
-        check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
-                                  int(relu), _p(pst), H * W, _p(sums), nrep, 0, _p(msc), _p(msh), _s()),
-              "ssa_bn_bwd_reduce")
+        sums = None
+        link = ctx.out_link
+        if link is not None:
+            if link.sums is not None and link.dz_ptr == dz.data_ptr() and lddz == C:
+                sums = link.sums          # accumulated by the consuming conv's data-gradient epilogue
+            link.sums = link.dz_ptr = None
+        if sums is None:
+            sums = _ARENA.take(nrep * 2 * C, dev)
+            check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
+                                      int(relu), _p(pst), H * W, _p(sums), nrep, 0, _p(msc), _p(msh), _s()),
+                  "ssa_bn_bwd_reduce")
         pg = torch.empty((2, C), dtype=torch.float32, device=dev) if g is not None else None
         pscale = 1.0
         use_sums = sums
@@ -611,6 +708,10 @@ class BatchNormActFn(torch.autograd.Function):
                                  _p(msc), _p(msh), _s()),
               "ssa_bn_bwd_apply")
         dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
+        if ctx.res_link is not None and dres is not None:
+            # conv1 of this block adds the identity branch's gradient in its data-gradient epilogue
+            ctx.res_link.dres, ctx.res_link.ld = dres, C
+            dres = None
         return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
 
 

@@ -12,7 +12,7 @@ from torch import nn
 
 from .. import ops
 from ..config import cfg
-from ..nn import Conv2d, Norm2d, conv_bn
+from ..nn import Conv2d, Norm2d, conv_bn, residual_link
 
 BN_MOMENTUM = 0.1   # network/hrnetv2.py:26
 
@@ -36,8 +36,11 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         res = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
-        return conv_bn(self.conv2, self.bn2, out, residual=res, relu=True)
+        # dataflow hints for the backend's backward fusions: bn1's output feeds conv2 alone, and
+        # (without a downsample branch) the block input is consumed by conv1 and the final add only
+        link = residual_link() if self.downsample is None else None
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, block=link)
+        return conv_bn(self.conv2, self.bn2, out, residual=res, relu=True, private_input=True, block=link)
 
 
 class Bottleneck(nn.Module):
@@ -58,8 +61,8 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         res = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True)
-        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True, private_input=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True, private_input=True)
 
 
 BLOCKS = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}

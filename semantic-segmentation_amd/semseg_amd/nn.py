@@ -51,11 +51,21 @@ def BNReLU(ch):
     return nn.Sequential(Norm2d(ch), nn.ReLU())
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, post=None):
+def conv_bn(conv, bn, x, residual=None, relu=False, post=None, private_input=False, block=None):
     """conv -> norm (+ residual add, ReLU, Dropout2d mask) as one backend call, so
-    the backend may fuse the batch statistics into the conv epilogue."""
+    the backend may fuse the batch statistics into the conv epilogue.
+    private_input / block: what the caller knows about the dataflow around this call (see
+    ops.HipBackend.conv_bn_act); they enable backward fusions and never change results."""
     assert conv.groups == 1 and conv.padding_mode == "zeros"
+    if private_input or block is not None:
+        return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post, private_input=private_input, block=block)
     return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post)
+
+
+def residual_link():
+    """Per-call hand-over object of a residual block for the backend (None where unsupported)."""
+    f = getattr(ops.backend(), "residual_link", None)
+    return f() if f is not None else None
 
 
 def initialize_weights(*models):

@@ -96,23 +96,47 @@ class HipBackend:
     def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False, want_stats=False):
         return self.hb.Conv2dFn.apply(x, weight, bias, stride, padding, dilation, out_f32, want_stats)
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, private_input=False, block=None):
         """conv -> BatchNorm (+residual, ReLU, mask).  In training the conv epilogue
         accumulates the batch statistics where the kernel supports it, and the
-        normalisation picks them up instead of re-reading the conv output."""
+        normalisation picks them up instead of re-reading the conv output.
+        private_input: `x` is the output of a BatchNorm+ReLU layer and this conv is its ONLY
+        consumer; block: the residual_link() of the residual block this call belongs to (its conv1
+        call has residual=None and the block input as `x`, its last call has the block input as
+        `residual`).  Both only matter under SSA_FUSE_BWD (hip_backend.py)."""
+        hb = self.hb
+        if hb._FUSE_BWD and torch.is_grad_enabled():
+            if private_input:
+                hb._NEXT_CONV_IN_LINK[0] = getattr(x, "_ssa_bn_link", None)
+            if block is not None:
+                if residual is None:
+                    hb._NEXT_CONV_RES_LINK[0] = block
+                else:
+                    hb._NEXT_BN_RES_LINK[0] = block
         y = self.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], False,
                         bool(bn.training))
         return self.batch_norm_act(y, bn, residual, relu, post)
 
+    def residual_link(self):
+        """Hand-over object for one residual block (None unless SSA_FUSE_BWD)."""
+        return self.hb.ResLink() if (self.hb._FUSE_BWD and torch.is_grad_enabled()) else None
+
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
         track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        link = None
+        if self.hb._FUSE_BWD and bn.training and relu and residual is None and post is None and \
+                torch.is_grad_enabled():
+            link = self.hb._NEXT_BN_OUT_LINK[0] = self.hb.BnLink()
         # training: the running statistics are updated by end_forward() (deferred, in
         # issue order) because passes over the same layer run on concurrent streams
-        return self.hb.BatchNormActFn.apply(
+        z = self.hb.BatchNormActFn.apply(
             x, bn.weight, bn.bias, residual, post,
             None if bn.training else bn.running_mean, None if bn.training else bn.running_var, None,
             0.1 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu,
             getattr(bn, "sync", False), self.hb._BN_UPDATES.slot(bn) if track else None)
+        if link is not None and link.x is not None:
+            z._ssa_bn_link = link          # picked up by the conv that consumes z alone (private_input=True)
+        return z
 
     def end_forward(self):
         self.hb.end_forward()

@@ -52,7 +52,7 @@ class OracleBackend:
         xin = _to_nchw(x)[:, :weight.shape[1]]
         return _to_nhwc(O.conv2d(xin, weight, bias, stride, padding, dilation))
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, private_input=False, block=None):
         y = self.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0])
         return self.batch_norm_act(y, bn, residual, relu, post)
 

@@ -173,3 +173,41 @@ def test_deferred_wgrad_reduce_glue(dry, monkeypatch):
     first_work = next(i for i, (k, n) in enumerate(order) if k == "flush" and n > 0)
     first_merge = next(i for i, (k, n) in enumerate(order) if k == "merge")
     assert first_work < first_merge, order[:6]
+
+
+def test_backward_fusion_glue(dry, monkeypatch):
+    """SSA_FUSE_BWD: every conv1 -> bn1 -> relu -> conv2 of a basic block hands bn1's backward sums over
+    from conv2's data-gradient epilogue (no bn_bwd_reduce for those layers), every block without a
+    downsample branch adds the identity gradient in conv1's data-gradient epilogue; all parameters
+    still get gradients, and nothing is left in the hand-over slots."""
+    from semseg_amd import hip_backend
+    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
+    inputs = _batch(2, 128, 128)
+    net(inputs).backward()
+    base_reduce = dry.calls["ssa_bn_bwd_reduce"]
+    base_tile = dry.calls["ssa_conv2d_tile"]
+    assert dry.calls["ssa_conv2d_tile_aux"] == 0
+    dry.calls.clear()
+    monkeypatch.setattr(hip_backend, "_FUSE_BWD", True)
+    net.zero_grad(set_to_none=True)
+    net(inputs).backward()
+    aux = dry.calls["ssa_conv2d_tile_aux"]
+    n_basic = sum(1 for m in net.modules() if type(m).__name__ == "BasicBlock")
+    assert n_basic == 104
+    # per scale pass: one mode-2 launch per basic block (conv2's dgrad) + one mode-1 launch per basic
+    # block (conv1's dgrad; none of HRNet's basic blocks has a downsample branch) + layer1's conv2s
+    assert aux >= 2 * 2 * n_basic, aux
+    assert dry.calls["ssa_conv2d_tile"] + aux == base_tile
+    assert base_reduce - dry.calls["ssa_bn_bwd_reduce"] >= 2 * n_basic          # the fused layers skip the reduce pass
+    assert dry.calls["ssa_sum_act"] >= 0
+    assert all(p.grad is not None for p in net.parameters())
+    for slot in (hip_backend._NEXT_BN_OUT_LINK, hip_backend._NEXT_CONV_IN_LINK, hip_backend._NEXT_CONV_RES_LINK,
+                 hip_backend._NEXT_BN_RES_LINK):
+        assert slot[0] is None
+    # eval / no-grad passes create no links
+    net.eval()
+    with torch.no_grad():
+        out = net({"images": inputs["images"]})
+    assert tuple(out["pred"].shape) == (2, 19, 128, 128)
+    for slot in (hip_backend._NEXT_BN_OUT_LINK, hip_backend._NEXT_CONV_IN_LINK):
+        assert slot[0] is None

@@ -15,13 +15,16 @@ run() {  # name, timeout, command...
 # 1. tests that have not run on hardware yet (fused SGD variants, filter-cache refresh, OCRNetASPP,
 #    sibling training steps, RCCL inside a captured graph with a one-rank communicator)
 SSA_TEST_UNVERIFIED=1 run unverified_tests 420 python -m pytest tests/test_optim_gpu.py tests/test_siblings_gpu.py \
-    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py -q -s -m gpu
+    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py tests/test_fuse_bwd_gpu.py -q -s -m gpu
 # 2. fused SGD in the bench (valid now that the version counters are bumped): compare with the default
 SSA_FUSED_SGD=1 run bench_fused_sgd 120 python bench.py --no-cpu-baseline
 run bench_torch_sgd 120 python bench.py --no-cpu-baseline
 # 2b. deferred + batched weight-gradient reduces (641 -> 9 launches per step)
 SSA_DEFER_WGRAD_REDUCE=1 run bench_defer_reduce 120 python bench.py --no-cpu-baseline
 SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_defer_reduce_fused_sgd 120 python bench.py --no-cpu-baseline
+# 2c. backward fusions (BN backward sums / residual add in the data-gradient epilogue)
+SSA_FUSE_BWD=1 run bench_fuse_bwd 120 python bench.py --no-cpu-baseline
+SSA_FUSE_BWD=1 SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_all_three 120 python bench.py --no-cpu-baseline
 # 3. who launches the ~350 aten adds and ~300 D2D copies per step
 run attribute_launches 180 python tools/attribute_launches.py 512
 cat "$log"
