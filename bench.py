@@ -361,6 +361,8 @@ def main():
             out["config"]["hipgraph_error"] = graph_error
         print(json.dumps(out))
     if dist_on:
+        from semseg_amd import rccl
+        rccl.shutdown()
         dist.destroy_process_group()
 
 

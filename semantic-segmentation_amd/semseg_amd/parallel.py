@@ -36,7 +36,11 @@ def allreduce_bn_sums(sums, local_count, group=None):
     world = sync_world(True, group)
     if not world:
         return float(local_count)
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    from . import rccl
+    if rccl.ENABLED and group is None and sums.is_cuda:
+        rccl.comm().all_reduce_sum_(sums)        # one RCCL call on the stream the BN kernels run on
+    else:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return float(local_count) * world
 
 

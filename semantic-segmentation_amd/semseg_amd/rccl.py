@@ -1,0 +1,103 @@
+"""Direct RCCL collectives on the compute stream (opt-in: SSA_RCCL_DIRECT=1).
+
+The SyncBN exchange of this path is 1,264 all-reduces of <= 2*720+1 fp64 values per
+training step.  Through torch.distributed each costs a c10d dispatch, a
+stream switch to c10d's communication stream and two event fences; here the same
+`ncclAllReduce` is enqueued directly on the stream the BatchNorm kernels run on --
+one library call, no stream switch, and a plain kernel node when the step is captured
+in a hipGraph.  The communicator is RCCL's own (the librccl.so torch already loaded),
+bootstrapped over the existing torch.distributed process group; `backend="nccl"`
+process groups keep carrying the gradient buckets (they overlap with backward on
+c10d's stream).
+
+Not exercised on hardware yet: a one-rank communicator can be tested on a one-GPU box
+(tests/test_rccl_direct_gpu.py, opt-in), the multi-GPU behaviour only by the driver's
+multi-GPU runs."""
+import ctypes
+import glob
+import os
+
+import torch
+import torch.distributed as dist
+
+ENABLED = os.environ.get("SSA_RCCL_DIRECT", "0") == "1"
+
+NCCL_FLOAT32, NCCL_FLOAT64, NCCL_SUM = 7, 8, 0      # rccl.h: ncclDataType_t / ncclRedOp_t
+
+
+class _UniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]  # NCCL_UNIQUE_ID_BYTES (opaque; may contain NULs)
+
+
+def _load():
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + \
+        ["/opt/rocm/lib/librccl.so"]
+    for path in cands:
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError:
+            continue
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+        return lib
+    raise RuntimeError("librccl.so not found (looked in torch/lib and /opt/rocm/lib)")
+
+
+class DirectComm:
+    """One RCCL communicator over the ranks of a torch.distributed group (default: the world)."""
+
+    def __init__(self, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("DirectComm needs an initialised torch.distributed process group to bootstrap")
+        self.lib = _load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        uid = _UniqueId()
+        if self.rank == 0:
+            self._check(self.lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        box = [ctypes.string_at(ctypes.byref(uid), 128) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self.device = torch.cuda.current_device()
+        self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank),
+                    "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce_sum_(self, t):
+        """In-place sum over ranks of a dense fp32 / fp64 tensor, enqueued on the current stream."""
+        dt = {torch.float32: NCCL_FLOAT32, torch.float64: NCCL_FLOAT64}[t.dtype]
+        assert t.is_contiguous() and t.is_cuda
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, NCCL_SUM, self.comm,
+                                           torch.cuda.current_stream().cuda_stream), "ncclAllReduce")
+        return t
+
+    def destroy(self):
+        if self.comm:
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
+_COMM = None
+
+
+def comm():
+    """The process-wide communicator (created on first use, after init_process_group)."""
+    global _COMM
+    if _COMM is None:
+        _COMM = DirectComm()
+    return _COMM
+
+
+def shutdown():
+    global _COMM
+    if _COMM is not None:
+        _COMM.destroy()
+        _COMM = None

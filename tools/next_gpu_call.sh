@@ -15,7 +15,7 @@ run() {  # name, timeout, command...
 # 1. tests that have not run on hardware yet (fused SGD variants, filter-cache refresh, OCRNetASPP,
 #    sibling training steps, RCCL inside a captured graph with a one-rank communicator)
 SSA_TEST_UNVERIFIED=1 run unverified_tests 420 python -m pytest tests/test_optim_gpu.py tests/test_siblings_gpu.py \
-    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py tests/test_fuse_bwd_gpu.py -q -s -m gpu
+    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py tests/test_fuse_bwd_gpu.py tests/test_rccl_direct_gpu.py -q -s -m gpu
 # 2. fused SGD in the bench (valid now that the version counters are bumped): compare with the default
 SSA_FUSED_SGD=1 run bench_fused_sgd 120 python bench.py --no-cpu-baseline
 run bench_torch_sgd 120 python bench.py --no-cpu-baseline
@@ -25,6 +25,10 @@ SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_defer_reduce_fused_sgd 120 py
 # 2c. backward fusions (BN backward sums / residual add in the data-gradient epilogue)
 SSA_FUSE_BWD=1 run bench_fuse_bwd 120 python bench.py --no-cpu-baseline
 SSA_FUSE_BWD=1 SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_all_three 120 python bench.py --no-cpu-baseline
+# 2d. the N > 1 code path over a one-rank communicator: eager, captured, captured with direct RCCL calls
+SSA_FORCE_DIST=1 run bench_dist1_eager 180 python bench.py --no-cpu-baseline --no-roofline
+SSA_FORCE_DIST=1 SSA_DDP_GRAPH=1 run bench_dist1_graph 180 python bench.py --no-cpu-baseline --no-roofline
+SSA_FORCE_DIST=1 SSA_DDP_GRAPH=1 SSA_RCCL_DIRECT=1 run bench_dist1_graph_direct 180 python bench.py --no-cpu-baseline --no-roofline
 # 3. who launches the ~350 aten adds and ~300 D2D copies per step
 run attribute_launches 180 python tools/attribute_launches.py 512
 cat "$log"
