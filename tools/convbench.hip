@@ -197,6 +197,33 @@ int main(int argc, char** argv) {
         worst = fmax(worst, fabs(gq - q) / (fabs(q) + 1e-9));
       }
       printf("%-22s %-14s stats worst rel err %.3g%s\n", c.name, "tile+stats", worst, worst > 1e-3 ? "  <-- MISMATCH" : "");
+      if (c.Cin == c.Cout) {
+        // the same launch with a fused epilogue tile (conv_tile_aux.hip), as the data gradients of a residual
+        // block use it: what the extra tile costs per launch.  Correctness: tests/test_fuse_bwd_gpu.py.
+        std::vector<bf16_t> haux(Pout * c.Cout);
+        for (auto& v : haux) v = f2bf_h((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        std::vector<float> hcoef(4 * (size_t)c.Cout);
+        for (int ch = 0; ch < c.Cout; ++ch) {
+          hcoef[ch] = (rand() / (float)RAND_MAX) * 2.f - 1.f;                       // mask scale
+          hcoef[c.Cout + ch] = (rand() / (float)RAND_MAX) - 0.5f;                   // mask shift
+          hcoef[2 * c.Cout + ch] = ((rand() / (float)RAND_MAX) - 0.5f) * 0.2f;      // mean
+          hcoef[3 * c.Cout + ch] = 0.5f + (rand() / (float)RAND_MAX);               // invstd
+        }
+        bf16_t* daux; float* dcoef;
+        CK(hipMalloc(&daux, haux.size() * 2)); CK(hipMalloc(&dcoef, hcoef.size() * 4));
+        CK(hipMemcpy(daux, haux.data(), haux.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dcoef, hcoef.data(), hcoef.size() * 4, hipMemcpyHostToDevice));
+        rc = 0;
+        us = timeit([&] { rc |= ssa_conv2d_tile_aux(&d, dx, dwp, nullptr, dy, nullptr, daux, c.Cout, nullptr, 1, st); });
+        if (rc) printf("%-22s tile+add failed rc=%d\n", c.name, rc);
+        else printf("%-22s %-14s %9.2f %9.1f %9.1f\n", c.name, "tile+add", us, flops / us * 1e-6, (bytes + 2.0 * Pout * c.Cout) / us * 1e-3);
+        CK(hipMemsetAsync(dstats, 0, sizeof(double) * reps * 2 * c.Cout, st));
+        rc = 0;
+        us = timeit([&] { rc |= ssa_conv2d_tile_aux(&d, dx, dwp, nullptr, dy, dstats, daux, c.Cout, dcoef, 2, st); });
+        if (rc) printf("%-22s tile+bnsums failed rc=%d\n", c.name, rc);
+        else printf("%-22s %-14s %9.2f %9.1f %9.1f\n", c.name, "tile+bnsums", us, flops / us * 1e-6, (bytes + 2.0 * Pout * c.Cout) / us * 1e-3);
+        CK(hipFree(daux)); CK(hipFree(dcoef));
+      }
     }
     if (ssa_conv2d_halo_supported(&d)) {
       if (ssa_pack_filter(dw, dwp, c.Cout, c.Cin, c.K, c.K, c.Cin, 0, Kflat, 2, st)) { printf("pack2 failed\n"); return 1; }

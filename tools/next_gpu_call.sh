@@ -29,6 +29,8 @@ SSA_FUSE_BWD=1 SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_all_three 120 
 SSA_FORCE_DIST=1 run bench_dist1_eager 180 python bench.py --no-cpu-baseline --no-roofline
 SSA_FORCE_DIST=1 SSA_DDP_GRAPH=1 run bench_dist1_graph 180 python bench.py --no-cpu-baseline --no-roofline
 SSA_FORCE_DIST=1 SSA_DDP_GRAPH=1 SSA_RCCL_DIRECT=1 run bench_dist1_graph_direct 180 python bench.py --no-cpu-baseline --no-roofline
+# 2e. per-launch cost of the fused data-gradient epilogues next to the plain tile kernel
+run convbench 240 tools/bin/convbench 20
 # 3. who launches the ~350 aten adds and ~300 D2D copies per step
 run attribute_launches 180 python tools/attribute_launches.py 512
 cat "$log"
