@@ -211,3 +211,70 @@ def test_backward_fusion_glue(dry, monkeypatch):
     assert tuple(out["pred"].shape) == (2, 19, 128, 128)
     for slot in (hip_backend._NEXT_BN_OUT_LINK, hip_backend._NEXT_CONV_IN_LINK):
         assert slot[0] is None
+
+
+def _dist_worker(rank, world, port, q):
+    import os
+    import sys
+    import contextlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "semantic-segmentation_amd"), os.path.join(root, "tests")]
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from semseg_amd import _lib, hip_backend, ops, nn as snn
+    from semseg_amd.config import cfg
+    from semseg_amd.parallel import DistributedDataParallel
+    d = DryLib(_lib.lib())
+    _lib._LIB = d
+    hip_backend._s = lambda: None
+    be = ops.HipBackend()
+    be.concurrency = 0
+    ops._set_backend_for_tests(be)
+    cfg.MODEL.BNFUNC = snn.SyncBatchNorm
+    cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
+    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
+    n_bn = sum(1 for m in net.modules() if isinstance(m, snn.SyncBatchNorm))
+    ddp = DistributedDataParallel(net)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
+    assert not be.use_shadow_pass()
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        ddp({"images": torch.randn(1, 3, 64, 64), "gts": torch.randint(0, 19, (1, 64, 64))}).backward()
+        opt.step()
+    ok = all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
+    q.put((rank, ok, n_bn, len(calls), len(ddp.buckets), sum(p.numel() for p in net.parameters())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_syncbn_ddp_glue():
+    """The N > 1 host path (SyncBatchNorm exchanges inside the BN Functions, DDP hooks and buckets)
+    on the real glue with two gloo ranks: 2 exchanges per SyncBN layer and scale pass and step
+    (forward + backward), one all-reduce per gradient bucket."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=280) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, ok, n_bn, n_calls, n_buckets, n_params in got:
+        assert ok
+        assert n_bn == 316
+        # per step: (forward + backward) x 2 scale passes x 316 layers -- minus the two layers of the
+        # attention head in the 1.0x pass, whose output two_scale_forward does not use (no backward) --
+        # plus the gradient buckets
+        assert n_calls == 2 * (2 * 2 * n_bn - 2 + n_buckets), (n_calls, n_buckets)
