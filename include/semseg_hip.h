@@ -411,6 +411,21 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
                        const float* upstream, double coef, float* dlogits,
                        int accumulate, void* stream);
 
+/* Tail of the input pipeline on the device: joint crop window + optional
+ * horizontal flip of the cropped pair (transforms/joint_transforms.py:276-281
+ * RandomHorizontallyFlip after the crop transforms), then for the image ToTensor + Normalize
+ * (datasets/base_loader.py:141-142; mean/std of config.py:96-97) written as the NHWC bf16
+ * [ch][cw][cpad] tensor the trunk reads (channels 3.. zero), value
+ * bf16(((float)u8/255 - mean[c]) / std[c]) in IEEE fp32 -- bit-identical to the CPU transforms
+ * followed by .to(bfloat16); for the labels MaskToTensor (uint8 -> int64).
+ * img_hwc: uint8 [H][W][3] RGB on the device; lab_hw: uint8 [H][W].  mean3/std3: HOST floats.  */
+int ssa_image_u8_crop_flip_normalize(const unsigned char* img_hwc, int H, int W, int x0, int y0,
+                                     int cw, int ch, int flip, const float* mean3,
+                                     const float* std3, void* out_nhwc_bf16, int cpad,
+                                     void* stream);
+int ssa_label_u8_crop_flip(const unsigned char* lab_hw, int H, int W, int x0, int y0, int cw,
+                           int ch, int flip, int64_t* out, void* stream);
+
 /* Evaluation tail on the device (utils/trnval_utils.py:173-196 + utils/misc.py:50-67
  * fast_hist): pred[p] = first argmax_c logits[p,c] (uint8, optional) and
  * hist[gt*C + pred] += 1 for 0 <= gt < C (int64 [C*C], ACCUMULATED: clear it once per

@@ -67,3 +67,22 @@ def eval_predictions(output):
     import torch
     probs = torch.nn.functional.softmax(output, dim=1)
     return probs.max(1)[1]
+
+
+def crop_flip_normalize(img_u8, labels_u8, window, flip, mean, std):
+    """CPU restatement of the tail of the reference's input pipeline for one sample
+    (datasets/base_loader.py:120-150): the crop transforms' `img.crop((x1, y1, x1+tw, y1+th))`
+    (transforms/joint_transforms.py:88-90, 156-157), RandomHorizontallyFlip
+    (joint_transforms.py:276-281), torchvision's ToTensor (uint8 HWC -> float32 CHW / 255) and
+    Normalize ((t - mean) / std, fp32), MaskToTensor (transforms/transforms.py: int64 labels).
+    img_u8: numpy uint8 [H,W,3]; labels_u8: numpy uint8 [H,W].  Returns (float32 [3,h,w], int64 [h,w])."""
+    import numpy as np
+    x0, y0, w, h = window
+    im = img_u8[y0:y0 + h, x0:x0 + w]
+    lab = labels_u8[y0:y0 + h, x0:x0 + w]
+    if flip:
+        im, lab = im[:, ::-1], lab[:, ::-1]
+    t = np.ascontiguousarray(im.transpose(2, 0, 1)).astype(np.float32) / np.float32(255)
+    m = np.asarray(mean, dtype=np.float32)[:, None, None]
+    s = np.asarray(std, dtype=np.float32)[:, None, None]
+    return (t - m) / s, np.ascontiguousarray(lab).astype(np.int64)

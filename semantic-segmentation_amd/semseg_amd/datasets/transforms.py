@@ -50,3 +50,39 @@ def resize_labels_nearest(mask, size):
                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
           "ssa_resize_nearest_u8")
     return out[0] if squeeze else out
+
+
+# ---------------------------------------------------------------------------------------------
+# Tail of the image pipeline on the device: crop window + horizontal flip of
+# the (image, labels) pair, ToTensor + Normalize on the image, MaskToTensor on the labels
+# (datasets/base_loader.py:120-150, transforms/joint_transforms.py:276-281).  The host sends the
+# raw uint8 buffers once; what comes back is what `net({'images': ..., 'gts': ...})` consumes.
+# ---------------------------------------------------------------------------------------------
+MEAN_STD = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])      # config.py:96-97 (cfg.DATASET.MEAN / STD)
+
+
+def crop_flip_normalize(img_u8, labels_u8, window, flip, mean_std=MEAN_STD):
+    """img_u8: uint8 CUDA [H,W,3] (RGB, as np.array(PIL image)); labels_u8: uint8 CUDA [H,W] or None;
+    window = (x0, y0, w, h) as PIL's crop box origin + size; flip: mirror the cropped pair.
+    Returns (image [1,h,w,16] bf16 NHWC -- hand it to the network's trunk --, labels [1,h,w] int64)."""
+    from .._lib import lib, check
+    assert img_u8.dtype == torch.uint8 and img_u8.is_cuda and img_u8.dim() == 3 and img_u8.shape[2] == 3
+    img_u8 = img_u8.contiguous()
+    H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+    x0, y0, cw, ch = (int(v) for v in window)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mean = (ctypes.c_float * 3)(*mean_std[0])
+    std = (ctypes.c_float * 3)(*mean_std[1])
+    out = torch.empty((1, ch, cw, 16), dtype=torch.bfloat16, device=img_u8.device)
+    check(lib().ssa_image_u8_crop_flip_normalize(ctypes.c_void_p(img_u8.data_ptr()), H, W, x0, y0, cw, ch, int(bool(flip)),
+                                                 mean, std, ctypes.c_void_p(out.data_ptr()), 16, stream),
+          "ssa_image_u8_crop_flip_normalize")
+    gts = None
+    if labels_u8 is not None:
+        assert labels_u8.dtype == torch.uint8 and labels_u8.is_cuda and tuple(labels_u8.shape) == (H, W)
+        labels_u8 = labels_u8.contiguous()
+        gts = torch.empty((1, ch, cw), dtype=torch.int64, device=img_u8.device)
+        check(lib().ssa_label_u8_crop_flip(ctypes.c_void_p(labels_u8.data_ptr()), H, W, x0, y0, cw, ch,
+                                           int(bool(flip)), ctypes.c_void_p(gts.data_ptr()), stream),
+              "ssa_label_u8_crop_flip")
+    return out, gts

@@ -83,3 +83,18 @@ def test_oracle_fast_hist_matches_reference():
     gt = rng.integers(0, 19, gold["n"])
     gt[rng.random(gold["n"]) < 0.1] = 255
     assert fast_hist(pred, gt, 19).tolist() == gold["hist"]
+
+
+def test_oracle_pipeline_tail_matches_pil_and_torch():
+    """oracle.data.crop_flip_normalize == PIL crop + FLIP_LEFT_RIGHT + ToTensor + Normalize +
+    MaskToTensor (tests/golden/make_golden_pipeline.py), bit for bit in fp32."""
+    import os
+    import numpy as np
+    import torch
+    from oracle.data import crop_flip_normalize
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_golden.pt"),
+                   weights_only=False)
+    for c in g["cases"]:
+        im, lab = crop_flip_normalize(g["img"].numpy(), g["lab"].numpy(), c["window"], c["flip"], g["mean"], g["std"])
+        assert np.array_equal(im, c["image"].numpy()), c["window"]
+        assert np.array_equal(lab, c["labels"].numpy()), c["window"]

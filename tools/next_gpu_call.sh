@@ -15,7 +15,7 @@ run() {  # name, timeout, command...
 # 1. tests that have not run on hardware yet (fused SGD variants, filter-cache refresh, OCRNetASPP,
 #    sibling training steps, RCCL inside a captured graph with a one-rank communicator)
 SSA_TEST_UNVERIFIED=1 run unverified_tests 420 python -m pytest tests/test_optim_gpu.py tests/test_siblings_gpu.py \
-    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py tests/test_fuse_bwd_gpu.py tests/test_rccl_direct_gpu.py -q -s -m gpu
+    tests/test_ddp_graph_gpu.py tests/test_deferred_reduce_gpu.py tests/test_fuse_bwd_gpu.py tests/test_rccl_direct_gpu.py tests/test_data_gpu.py -q -s -m gpu
 # 2. fused SGD in the bench (valid now that the version counters are bumped): compare with the default
 SSA_FUSED_SGD=1 run bench_fused_sgd 120 python bench.py --no-cpu-baseline
 run bench_torch_sgd 120 python bench.py --no-cpu-baseline
