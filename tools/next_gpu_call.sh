@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of the next round: everything that was written after round 1's GPU budget ran
 # out, in order of value, each leg under its own timeout and with its own log under gpurun_out/.
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/next_gpu_call.sh'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/next_gpu_call.sh'
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/next_gpu_call.log
