@@ -35,6 +35,8 @@ CONFIGS = (
      torch.float64, False, 0),
     ("mscale2.DeepV3R50", "mscale2", lambda m, c: m.DeepV3R50(19, c), "ce", torch.float64, True, 0),
     ("ocrnet.OCRNetASPP", "ocrnet", lambda m, c: m.OCRNetASPP(19, criterion=c), "ce", torch.float64, False, 0),
+    # BASELINE.json configs[1]: HRNet-OCR single scale
+    ("ocrnet.HRNet", "ocrnet", lambda m, c: m.HRNet(19, c), "rmi", torch.float64, False, 0),
 )
 
 

@@ -14,7 +14,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 sys.path.insert(0, G)
 
 NAMES = ("mscale.HRNet", "mscale.HRNet_ASP", "mscale.DeepV3R50", "mscale.MscaleV3Plus.fuse2b",
-         "mscale2.DeepV3R50", "ocrnet.OCRNetASPP")
+         "mscale2.DeepV3R50", "ocrnet.OCRNetASPP", "ocrnet.HRNet")
 
 
 def sibling_shapes():
