@@ -383,7 +383,7 @@ def _add_bf16(a, b):
 # (data_ptr of a conv output, its BN partial sums [nrep][2][C], nrep): handed from the conv
 # epilogue to the BatchNorm that consumes that output next (HipBackend.conv_bn_act)
 _PENDING_STATS = [None]
-_NO_IGEMM_STATS = bool(__import__("os").environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
+_NO_IGEMM_STATS = bool(os.environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
 
 
 def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, deferrable=False):
