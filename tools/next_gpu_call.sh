@@ -21,6 +21,8 @@ SSA_FUSED_SGD=1 run bench_fused_sgd 120 python bench.py --no-cpu-baseline
 run bench_torch_sgd 120 python bench.py --no-cpu-baseline
 # 2a. the reference's actual sota crop, 1024x2048 (secondary row, exactly 2x the work)
 run bench_1024x2048 120 python bench.py --crop 1024 --crop-w 2048 --no-cpu-baseline
+# 2a'. two images per GPU (scripts/train_mapillary.yml trains 1024x1024 crops with bs_trn 2): same launch count, twice the work
+run bench_batch2 120 python bench.py --batch 2 --no-cpu-baseline
 # 2b. deferred + batched weight-gradient reduces (641 -> 9 launches per step)
 SSA_DEFER_WGRAD_REDUCE=1 run bench_defer_reduce 120 python bench.py --no-cpu-baseline
 SSA_DEFER_WGRAD_REDUCE=1 SSA_FUSED_SGD=1 run bench_defer_reduce_fused_sgd 120 python bench.py --no-cpu-baseline
