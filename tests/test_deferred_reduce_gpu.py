@@ -77,7 +77,7 @@ def test_training_step_with_deferred_reduces(monkeypatch):
         ops._set_backend_for_tests(prev)
         cfg.LOSS.SUPERVISED_MSCALE_WT = 0
     (l0, g0), (l1, g1) = grads
-    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert abs(l0 - l1) <= 1e-4 * abs(l0)
     rel = sorted(float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-30)) for n in g0)
     print("deferred vs per-layer reduce: loss %.6f / %.6f, relative gradient difference median %.3g p99 %.3g max %.3g" % (
         l0, l1, rel[len(rel) // 2], rel[len(rel) * 99 // 100], rel[-1]))
