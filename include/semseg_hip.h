@@ -34,6 +34,38 @@ extern "C" {
 
 int ssa_version(void);
 
+/* ------------------------------------------------------- grouped launches --
+ * The 2-4 resolution branches of a HighResolutionModule (network/hrnetv2.py:181-254)
+ * times the scale passes of MscaleOCR (network/ocrnet.py:264-327) are independent
+ * problems that the reference issues as separate cuDNN/ATen calls.  Between
+ * ssa_group_begin() and ssa_group_end(stream) the group-aware entry points (convolutions,
+ * BatchNorm passes, sums, bilinear resampling, weight gradients) queue their launch on
+ * the calling thread instead of issuing it; ssa_group_end issues ONE launch per kernel
+ * instantiation covering all queued problems (job table in the kernel arguments).
+ * Contract: launches queued in one bracket are mutually independent.  Other entry
+ * points launch immediately.  Brackets nest (the outermost end flushes);
+ * ssa_group_abort drops a bracket after a host-side error.
+ * ssa_launch_count: kernel launches issued by this library so far (reset != 0 clears). */
+int ssa_group_begin(void);
+int ssa_group_end(void* stream);
+int ssa_group_abort(void);
+long ssa_launch_count(int reset);
+
+/* Per-launch timing for the roofline measurement (bench.py): between ssa_profile_begin and
+ * ssa_profile_end every launch of a group-aware kernel (all convolution-class kernels,
+ * BatchNorm, sums, resampling) is bracketed by HIP events on the stream it is launched on.
+ * ssa_profile_note attaches algorithmic flops / HBM bytes to the NEXT job submitted by the
+ * calling thread.  ssa_profile_end waits for the device and returns one aggregate record
+ * per kernel instantiation (name as rocprofv3 prints the template arguments).            */
+typedef struct ssa_profile_rec {
+  char kernel[120];
+  long launches, jobs;
+  double total_us, flops, bytes;
+} ssa_profile_rec;
+int ssa_profile_begin(void);
+int ssa_profile_note(double flops, double bytes);
+int ssa_profile_end(ssa_profile_rec* out, int max_recs);
+
 /* ------------------------------------------------------------------ conv --
  * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x16_bf16), NHWC bf16 in,
  * fp32 accumulate, bf16 or fp32 out.  Replaces nn.Conv2d forward / dgrad /
@@ -122,7 +154,15 @@ int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin,
 
 /* Weight gradient, split over the pixel axis.  partial is
  * [nsplit][cout_pad][KH*KW*Cin] fp32; ssa_conv2d_wgrad_reduce sums the splits
- * and writes dW in the parameter's OIHW fp32 layout (cin_real <= d->Cin).    */
+ * and writes dW in the parameter's OIHW fp32 layout (cin_real <= d->Cin);
+ * accumulate != 0: ADDS to dW instead (dW = the layer's slice of the step's gradient
+ * arena, cleared once per step; the passes of a multi-scale step write their splits
+ * behind one another in `partial` and ONE reduce sums them all).
+ * The weight-gradient kernels and the reduce are group-aware: the host defers a
+ * module's weight gradients and issues them inside one ssa_group bracket.
+ * d->cfg > 0 in the *_plan calls: bound a workgroup's pixel strip to cfg 128-pixel
+ * stages instead of splitting for parallelism (grouped launches get their
+ * parallelism from the number of layers).                                     */
 int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit,
                           size_t* ws_bytes);
 int ssa_conv2d_wgrad(const ssa_conv_desc* d, const void* x, const void* dy,
@@ -130,19 +170,7 @@ int ssa_conv2d_wgrad(const ssa_conv_desc* d, const void* x, const void* dy,
                      void* stream);
 int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad,
                             int Cout, int Cin_pad, int Cin, int KH, int KW,
-                            float* dw_oihw, void* stream);
-
-/* The same reduce for MANY layers at once: the host glue defers the per-layer reduces of a
- * backward pass and hands the whole list over at its end (641 layers per training step ->
- * 9 launches).  `jobs` is a HOST array; up to 72 jobs travel per launch as kernel
- * arguments.  Arithmetic and summation order are those of ssa_conv2d_wgrad_reduce
- * (bit-identical results).                                                            */
-typedef struct ssa_wgrad_reduce_job {
-  const float* partial;  /* [nsplit][cout_pad][KH*KW*Cin_pad] fp32                     */
-  float* dw;             /* [Cout][Cin][KH][KW] fp32                                    */
-  int nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, pad_;
-} ssa_wgrad_reduce_job;
-int ssa_conv2d_wgrad_reduce_batched(const ssa_wgrad_reduce_job* jobs, int njobs, void* stream);
+                            float* dw_oihw, int accumulate, void* stream);
 
 /* All filters of a network repacked in ONE launch (the parameters change every
  * optimizer step; 1,276 separate pack launches cost more than the packing).
@@ -249,7 +277,9 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz,
 /* backward pass 2: dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N);
  * dres (optional) = g.  sums may have been all-reduced; count is global.
  * dgamma/dbeta (optional): = param_grad_scale * sums[C:2C] / sums[0:C]
- * (1/world under SyncBN, so that DDP's mean over ranks is unchanged).         */
+ * (1/world under SyncBN, so that DDP's mean over ranks is unchanged);
+ * accumulate_param_grads: ADD them (fp32 atomics) into buffers the caller cleared --
+ * the gradient arena of the step, shared by every pass over the layer.        */
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      const void* z, int ldz, void* dx, int lddx, void* dres,
                      int lddres, long P, int C, const float* gamma,
@@ -257,7 +287,7 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      int nrep, double count, int relu, const float* post,
                      long pix_per_img, float* dgamma, float* dbeta,
                      float param_grad_scale, const float* mask_scale,
-                     const float* mask_shift, void* stream);
+                     const float* mask_shift, int accumulate_param_grads, void* stream);
 /* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);

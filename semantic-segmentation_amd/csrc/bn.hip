@@ -12,6 +12,7 @@
 // contiguous run of 16-byte pieces.
 #include "common.h"
 #include <stdlib.h>
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -24,8 +25,8 @@ __host__ __device__ inline int active_threads(int VC) { return (NT / VC) * VC; }
 // Accumulate per-channel sums for this block into fp64 global sums.
 // v0/v1 hold 8 channels each (this thread's channel group cg).
 __device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v1, int cg, int C,
-                                                 bool active, double* gsums, float* sh, int nrep = 1) {
-  gsums += (long)(blockIdx.x % nrep) * 2 * C;   // [nrep][2][C]: spread the same-address atomics
+                                                 bool active, double* gsums, float* sh, int bx, int nrep = 1) {
+  gsums += (long)(bx % nrep) * 2 * C;   // [nrep][2][C]: spread the same-address atomics
   // sh: [2*C] floats
   for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
   __syncthreads();
@@ -40,9 +41,9 @@ __device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v
   for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&gsums[i], (double)sh[i]);
 }
 
-__global__ __launch_bounds__(NT) void bn_stats_kernel(const bf16_t* __restrict__ x, long P, int C,
+__device__ __forceinline__ void bn_stats_body(const bf16_t* __restrict__ x, long P, int C,
                                                       int ld, double* __restrict__ sums,
-                                                      long pix_per_block) {
+                                                      long pix_per_block, const int bx) {
   extern __shared__ float sh[];
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const bf16_t* __restrict__
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  const long p0 = blockIdx.x * pix_per_block;
+  const long p0 = bx * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
   if (active) {
     const bf16_t* xp = x + cg * 8;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const bf16_t* __restrict__
       for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
     }
   }
-  block_reduce_2x8(s, q, cg, C, active, sums, sh);
+  block_reduce_2x8(s, q, cg, C, active, sums, sh, bx);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C,
@@ -109,11 +110,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (invstd_out) invstd_out[c] = (float)invstd;
 }
 
-__global__ __launch_bounds__(NT) void bn_apply_kernel(
+__device__ __forceinline__ void bn_apply_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
     bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, int relu, const float* __restrict__ post, long pix_per_img,
-    long pix_per_block) {
+    long pix_per_block, const int bx) {
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   if (t >= NA) return;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(
   float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = scale[cg * 8 + j]; b[j] = shift[cg * 8 + j]; }
-  const long p0 = blockIdx.x * pix_per_block;
+  const long p0 = bx * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
 #pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
@@ -154,14 +155,14 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(
 // scale/shift for its 8 channels from the fp64 sums (2 loads + a few fp64 ops per
 // channel), block 0 additionally publishes mean/invstd/scale/shift for the
 // backward pass, updates the running statistics and bumps num_batches_tracked.
-__global__ __launch_bounds__(NT) void bn_apply_train_kernel(
+__device__ __forceinline__ void bn_apply_train_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
     bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, int nrep,
     double count, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
-    long pix_per_block) {
+    long pix_per_block, const int bx) {
   extern __shared__ float sh[];                 // [2C]: scale, shift for this launch
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
     const float sc = (float)(g * invstd), sf = (float)(b - mean * g * invstd);
     sh[c] = sc;
     sh[C + c] = sf;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
       coef[c] = sc;
       coef[C + c] = sf;
       coef[2 * C + c] = (float)mean;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
       }
     }
   }
-  if (blockIdx.x == 0 && t == 0) {
+  if (bx == 0 && t == 0) {
     if (num_batches_tracked) *num_batches_tracked += 1;
     if (pass_stats) pass_stats[2 * C] = (float)count;
   }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
   float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = sh[cg * 8 + j]; b[j] = sh[C + cg * 8 + j]; }
-  const long p0 = blockIdx.x * pix_per_block;
+  const long p0 = bx * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
 #pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
@@ -233,12 +234,12 @@ __global__ __launch_bounds__(NT) void bn_apply_train_kernel(
   }
 }
 
-__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
+__device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
     const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
     double* __restrict__ sums, int nrep, long pix_per_block, const float* __restrict__ mscale,
-    const float* __restrict__ mshift) {
+    const float* __restrict__ mshift, const int bx) {
   extern __shared__ float sh[];
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
     }
-    const long p0 = blockIdx.x * pix_per_block;
+    const long p0 = bx * pix_per_block;
     const long p1 = min(P, p0 + pix_per_block);
   #pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
@@ -282,10 +283,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(
       }
     }
   }
-  block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, nrep);
+  block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, bx, nrep);
 }
 
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
+__device__ __forceinline__ void bn_bwd_apply_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
     bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     const double* __restrict__ sums, int nrep, double count, int relu,
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
-    const float* __restrict__ mscale, const float* __restrict__ mshift) {
+    const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg, const int bx) {
   extern __shared__ float sh[];                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -306,9 +307,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     sh[2 * C + c] = (gamma ? gamma[c] : 1.f) * is_;
     sh[3 * C + c] = (float)(s1 / count);
     sh[4 * C + c] = (float)(s2 / count);
-    if (blockIdx.x == 0) {
-      if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
-      if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
+    if (bx == 0) {
+      // accumulate_pg: the gradient buffer is shared by every pass over this layer (cleared once
+      // per step); passes grouped into one launch add concurrently, hence the atomics
+      if (accumulate_pg) {
+        if (dbeta) unsafeAtomicAdd(&dbeta[c], (float)(s1 * param_grad_scale));
+        if (dgamma) unsafeAtomicAdd(&dgamma[c], (float)(s2 * param_grad_scale));
+      } else {
+        if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
+        if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
+      }
     }
   }
   __syncthreads();
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(
     c1[j] = sh[3 * C + c];
     c2[j] = sh[4 * C + c];
   }
-  const long p0 = blockIdx.x * pix_per_block;
+  const long p0 = bx * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
 #pragma unroll 4
   for (long p = p0 + pr; p < p1; p += RP) {
@@ -366,9 +374,9 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
   if (dgamma) dgamma[c] = (float)sums[C + c];
 }
 
-__global__ __launch_bounds__(NT) void colsum_kernel(const bf16_t* __restrict__ x, long P, int C,
+__device__ __forceinline__ void colsum_body(const bf16_t* __restrict__ x, long P, int C,
                                                     int ld, double* __restrict__ sums,
-                                                    long pix_per_block) {
+                                                    long pix_per_block, const int bx) {
   extern __shared__ float sh[];
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -377,7 +385,7 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const bf16_t* __restrict__ x
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  const long p0 = blockIdx.x * pix_per_block;
+  const long p0 = bx * pix_per_block;
   const long p1 = min(P, p0 + pix_per_block);
   if (active) {
   #pragma unroll 4
@@ -388,8 +396,69 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const bf16_t* __restrict__ x
       for (int j = 0; j < 8; ++j) s[j] += f[j];
     }
   }
-  block_reduce_2x8(s, q, cg, C, active, sums, sh);
+  block_reduce_2x8(s, q, cg, C, active, sums, sh, bx);
 }
+
+
+// ---- group-aware wrappers (group.h): one launch for all the BatchNorm calls of a depth level
+struct BnStatsK {
+  struct Args { const bf16_t* x; double* sums; long P, ppb; int C, ld; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_stats_body(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx);
+  }
+};
+struct ColsumK {
+  struct Args { const bf16_t* x; double* sums; long P, ppb; int C, ld; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    colsum_body(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx);
+  }
+};
+struct BnApplyK {
+  struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const float* scale; const float* shift;
+                const float* post; long P, pix_per_img, ppb; int ldx, ldr, ldz, C, relu; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_apply_body(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.scale, a.shift, a.relu, a.post,
+                  a.pix_per_img, a.ppb, bx);
+  }
+};
+struct BnApplyTrainK {
+  struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const double* sums; const float* gamma;
+                const float* beta; float* running_mean; float* running_var; long* nbt; float* coef;
+                float* pass_stats; const float* post; double count; long P, pix_per_img, ppb;
+                int ldx, ldr, ldz, C, nrep, relu; float momentum, eps; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_apply_train_body(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.gamma,
+                        a.beta, a.running_mean, a.running_var, a.nbt, a.momentum, a.eps, a.coef,
+                        a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, bx);
+  }
+};
+struct BnBwdReduceK {
+  struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
+                const float* post; double* sums; const float* mscale; const float* mshift;
+                long P, pix_per_img, ppb; int ldx, lddz, ldz, C, relu, nrep; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_bwd_reduce_body(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
+                       a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, bx);
+  }
+};
+struct BnBwdApplyK {
+  struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; bf16_t* dx; bf16_t* dres;
+                const float* gamma; const float* mean; const float* invstd; const double* sums;
+                const float* post; float* dgamma; float* dbeta; const float* mscale; const float* mshift;
+                double count; long P, pix_per_img, ppb; int ldx, lddz, ldz, lddx, lddres, C, nrep, relu;
+                float param_grad_scale; int accumulate_pg; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_bwd_apply_body(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
+                      a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
+                      a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, bx);
+  }
+};
 
 __global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -469,10 +538,8 @@ int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_su
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
-                     (const bf16_t*)x, P, C, ld, sums, g.ppb);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  BnStatsK::Args a{(const bf16_t*)x, sums, P, g.ppb, C, ld};
+  return ssa::submit<BnStatsK>(a, g.blocks, 1, 2 * C * sizeof(float), s);
 }
 
 int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
@@ -494,11 +561,9 @@ int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z,
   if (!x || !z || !scale || !shift || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8))
     return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(g.blocks), dim3(NT), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
-                     scale, shift, relu, post, pix_per_img, g.ppb);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  BnApplyK::Args a{(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, scale, shift, post, P, pix_per_img,
+                   g.ppb, ldx, ldr, ldz, C, relu};
+  return ssa::submit<BnApplyK>(a, g.blocks, 1, 0, (hipStream_t)stream);
 }
 
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz,
@@ -511,12 +576,10 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
-  hipLaunchKernelGGL(bn_apply_train_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (const bf16_t*)residual, ldr, (bf16_t*)z, ldz, P, C,
-                     sums, nrep, count, gamma, beta, running_mean, running_var, num_batches_tracked,
-                     momentum, eps, coef, pass_stats, relu, post, pix_per_img, g.ppb);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  BnApplyTrainK::Args a{(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta, running_mean,
+                        running_var, num_batches_tracked, coef, pass_stats, post, count, P, pix_per_img, g.ppb,
+                        ldx, ldr, ldz, C, nrep, relu, momentum, eps};
+  return ssa::submit<BnApplyTrainK>(a, g.blocks, 1, 2 * C * sizeof(float), (hipStream_t)stream);
 }
 
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {
@@ -542,11 +605,9 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
-                     (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, P, C,
-                     mean, invstd, relu, post, pix_per_img, sums, nrep, g.ppb, mask_scale, mask_shift);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  BnBwdReduceK::Args a{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums, mask_scale,
+                       mask_shift, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep};
+  return ssa::submit<BnBwdReduceK>(a, g.blocks, 1, 2 * C * sizeof(float), s);
 }
 
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
@@ -554,19 +615,16 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
                      const float* mean, const float* invstd, const double* sums, int nrep,
                      double count, int relu, const float* post, long pix_per_img, float* dgamma,
                      float* dbeta, float param_grad_scale, const float* mask_scale,
-                     const float* mask_shift, void* stream) {
+                     const float* mask_shift, int accumulate_param_grads, void* stream) {
   if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z && !mask_scale) || nrep < 1 ||
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.blocks), dim3(NT), 5 * C * sizeof(float), (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (const bf16_t*)dz, lddz, (const bf16_t*)z, ldz,
-                     (bf16_t*)dx, lddx, (bf16_t*)dres, lddres, P, C, gamma, mean, invstd, sums, nrep,
-                     count, relu, post, pix_per_img, g.ppb, dgamma, dbeta, param_grad_scale, mask_scale,
-                     mask_shift);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  BnBwdApplyK::Args a{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres, gamma, mean,
+                      invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift, count, P, pix_per_img, g.ppb,
+                      ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale, accumulate_param_grads};
+  return ssa::submit<BnBwdApplyK>(a, g.blocks, 1, 5 * C * sizeof(float), (hipStream_t)stream);
 }
 
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {
@@ -580,13 +638,13 @@ int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, v
 int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out, double* scratch2c,
                     void* stream) {
   if (!x || !out || !scratch2c || !ok_c(C) || ld % 8) return SSA_EINVAL;
+  if (ssa::group_state().depth > 0) return SSA_EINVAL;   // three dependent launches: not inside a group bracket
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(scratch2c, 0, sizeof(double) * 2 * C, s);
   if (e != hipSuccess) return (int)e;
   const Grid g = plan_reduce_grid(P, C);
-  hipLaunchKernelGGL(colsum_kernel, dim3(g.blocks), dim3(NT), 2 * C * sizeof(float), s,
-                     (const bf16_t*)x, P, C, ld, scratch2c, g.ppb);
-  SSA_LAUNCH_CHECK();
+  ColsumK::Args a{(const bf16_t*)x, scratch2c, P, g.ppb, C, ld};
+  if (int rc = ssa::submit<ColsumK>(a, g.blocks, 1, 2 * C * sizeof(float), s)) return rc;
   hipLaunchKernelGGL(d2f_kernel, dim3((C + 127) / 128), dim3(128), 0, s, scratch2c, out, C);
   SSA_LAUNCH_CHECK();
   return SSA_OK;

@@ -14,8 +14,11 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define SSA_EINVAL (-1)
 #define SSA_EUNSUPPORTED (-2)
 
+namespace ssa { void count_launches(int n); }   // group.hip: library-wide launch counter (ssa_launch_count)
+
 #define SSA_LAUNCH_CHECK()                          \
   do {                                              \
+    ssa::count_launches(1);                         \
     hipError_t e__ = hipGetLastError();             \
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)

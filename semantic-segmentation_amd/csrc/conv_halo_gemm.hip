@@ -21,17 +21,30 @@
 // Halo pixel stride is CK*2+16 bytes (an odd number of 16-byte slots): the 16
 // lanes ds_read_b128 services together read distinct slots.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
 
 constexpr int kStatReplicasG = 8;   // must equal conv_tile.hip's kStatReplicas
 
+struct HaloArgs {
+  const bf16_t* x; const uint4* wfrag; const float* bias; void* y; double* stats;
+  int ldx, Cin, ldy, out_f32, B, H, W, Cout, nb_total, tiles_x, tiles_y;
+};
+
 template <int CK, int KS>
-__global__ __launch_bounds__(512) void conv_halo_gemm_kernel(
-    const bf16_t* __restrict__ x, int ldx, int Cin, const uint4* __restrict__ wfrag,
-    const float* __restrict__ bias, void* __restrict__ yv, int ldy, int out_f32, int B, int H, int W,
-    int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats) {
+struct ConvHaloGemm {
+  typedef HaloArgs Args;
+  static constexpr int NT = 512;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const uint4* __restrict__ wfrag = a.wfrag;
+  const float* __restrict__ bias = a.bias;
+  void* __restrict__ yv = a.y;
+  double* __restrict__ stats = a.stats;
+  const int ldx = a.ldx, Cin = a.Cin, ldy = a.ldy, out_f32 = a.out_f32, H = a.H, W = a.W, Cout = a.Cout;
+  const int nb_total = a.nb_total, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
   constexpr int NB = 4, TW = 32, TH = 8, BM = 256, R = KS / 2;
   constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
   constexpr int PSB = CK * 2 + 16;
@@ -49,11 +62,11 @@ __global__ __launch_bounds__(512) void conv_halo_gemm_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves
-  int bid = blockIdx.x;
+  int bid = bx;
   const int tx_i = bid % tiles_x; bid /= tiles_x;
   const int ty_i = bid % tiles_y; bid /= tiles_y;
   const int b = bid;
-  const int nb0 = blockIdx.y * NB;
+  const int nb0 = by * NB;
   const int x0 = tx_i * TW, y0 = ty_i * TH;
   const int nchunk = Cin / CK;
   const int csteps = Cin / 16;                  // c-steps per tap in the packed filter
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(512) void conv_halo_gemm_kernel(
   }
   __syncthreads();
   if (stats != nullptr) {
-    double* st = stats + (long)(blockIdx.x % kStatReplicasG) * 2 * Cout;
+    double* st = stats + (long)(bx % kStatReplicasG) * 2 * Cout;
     if (tid < 256) {
       const int which = tid >> 7, col = tid & 127;
       const int n = nb0 * 32 + col;
@@ -231,7 +244,8 @@ __global__ __launch_bounds__(512) void conv_halo_gemm_kernel(
       for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
     }
   }
-}
+  }
+};
 
 template <int CK, int KS>
 int launch_halo(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
@@ -243,20 +257,12 @@ int launch_halo(const ssa_conv_desc& d, const void* x, const void* wfrag, const 
   constexpr size_t pipe = 2 * halo + 2 * bst;
   constexpr size_t lds = pipe > stage ? pipe : stage;
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
-  auto kern = conv_halo_gemm_kernel<CK, KS>;
-  static bool once = false;
-  if (!once) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    once = true;
-  }
-  const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
-  const int nb_total = (d.Cout + 31) / 32;
-  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * d.B, (nb_total + 3) / 4), dim3(512), lds, s,
-                     (const bf16_t*)x, d.ldx, d.Cin, (const uint4*)wfrag, bias, y, d.ldy, d.out_f32, d.B,
-                     d.H, d.W, d.Cout, nb_total, tiles_x, tiles_y, stats);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  HaloArgs a;
+  a.x = (const bf16_t*)x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y; a.stats = stats;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.out_f32 = d.out_f32; a.B = d.B; a.H = d.H; a.W = d.W;
+  a.Cout = d.Cout; a.nb_total = (d.Cout + 31) / 32;
+  a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 7) / 8;
+  return ssa::submit<ConvHaloGemm<CK, KS>>(a, a.tiles_x * a.tiles_y * d.B, (a.nb_total + 3) / 4, lds, s);
 }
 
 int pick_ck(int Cin) {

@@ -21,6 +21,7 @@
 // current stage's MFMAs.  LDS rows are padded to 80 bytes so the 16 lanes that
 // ds_read_b128 services together hit 16 distinct 16-byte slots.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 #include <limits.h>
 #include <stdlib.h>
@@ -56,12 +57,25 @@ __device__ __forceinline__ void mma_stage(const bf16_t* __restrict__ As,
 // ----------------------------------------------------------------------------
 // forward / dgrad kernel
 // ----------------------------------------------------------------------------
+struct IgemmArgs {
+  ssa_conv_desc d;
+  const bf16_t* x; const bf16_t* w; const float* bias; void* y; double* stats;
+  int tiles_n, tr_shift;
+};
+
 template <int WGM, int WGN, int MI, int NI>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
-    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-    const float* __restrict__ bias, void* __restrict__ yv, int tiles_n, int tr_shift,
-    double* __restrict__ stats) {
-  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
+struct ConvIgemm {
+  typedef IgemmArgs Args;
+  static constexpr int NT = 64 * WGM * WGN;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
+  const ssa_conv_desc& d = a.d;
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ w = a.w;
+  const float* __restrict__ bias = a.bias;
+  void* __restrict__ yv = a.y;
+  double* __restrict__ stats = a.stats;
+  const int tiles_n = a.tiles_n, tr_shift = a.tr_shift;
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
   constexpr int PPR = BK / 8;
   constexpr int RPP = NT / PPR;
   constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tn = bx % tiles_n, tm = bx / tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = d.B * d.Ho * d.Wo;
   const int HoWo = d.Ho * d.Wo;
@@ -101,7 +115,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
     kw = tap - kh * d.KW;
   }
   const int tr_mask = (1 << tr_shift) - 1;
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const int nk = d.Kpad / BK;
 
   uint4 ra[A_IT], rb[B_IT];
@@ -120,14 +133,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
       }
       const long pix = ok ? (long)(pb[i] + iy * d.W + ix) : 0;
       const bf16_t* p = x + pix * d.ldx + kc;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
       const int r = r0 + j * RPP, n = n0 + r;
       const bool ok = (r < BN) && (n < d.Cout);
       const bf16_t* p = w + (long)n * d.Kpad + kt * BK + pc * 8;
-      rb[j] = ok ? *reinterpret_cast<const uint4*>(p) : zero4;
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
     }
     // advance the cursor by one stage
     kc += BK;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
   }
   __syncthreads();
   if (stats != nullptr) {
-    double* st = stats + (long)(blockIdx.x % 8) * 2 * d.Cout;     // replica, as conv_tile.hip
+    double* st = stats + (long)(bx % 8) * 2 * d.Cout;     // replica, as conv_tile.hip
     for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, col = i - which * BN;
       const int n = n0 + col;
@@ -249,7 +262,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_kernel(
       for (int j = 0; n + j < d.Cout; ++j) dst[j] = src[j];
     }
   }
-}
+  }
+};
 
 // ----------------------------------------------------------------------------
 // weight-gradient kernel: [pixel][channel] LDS images (16-byte stores, exactly
@@ -289,11 +303,23 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int stride, int 
 }
 
 // BKP: pixels (GEMM k) per LDS stage, 32 or 64.
+struct WgradTrArgs {
+  ssa_conv_desc d;
+  const bf16_t* x; const bf16_t* dy; float* partial;
+  int lddy, cout_pad, tiles_n, chunk;
+};
+
 template <int WGM, int WGN, int MI, int NI, int BKP>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
-    ssa_conv_desc d, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int lddy,
-    int cout_pad, float* __restrict__ partial, int tiles_n, int chunk) {
-  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32, NT = 64 * WGM * WGN;
+struct ConvWgradTr {
+  typedef WgradTrArgs Args;
+  static constexpr int NT = 64 * WGM * WGN;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const ssa_conv_desc& d = a.d;
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ dy = a.dy;
+  float* __restrict__ partial = a.partial;
+  const int lddy = a.lddy, cout_pad = a.cout_pad, tiles_n = a.tiles_n, chunk = a.chunk;
+  constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
   constexpr int SA = tr_row_stride(BM), SB = tr_row_stride(BN);
   constexpr int PA = BM / 8, PB = BN / 8;          // 16-byte pieces per pixel row
   constexpr int A_PIECES = BKP * PA, B_PIECES = BKP * PB;
@@ -304,11 +330,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tn = bx % tiles_n, tm = bx / tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int P = d.B * d.Ho * d.Wo, HoWo = d.Ho * d.Wo;
   const int Kflat = d.KH * d.KW * d.Cin;
-  const int p_begin = blockIdx.y * chunk;
+  const int p_begin = by * chunk;
   const int p_end = min(P, p_begin + chunk);
 
   // piece -> (pixel row, channel piece): channel piece fastest => coalesced global loads
@@ -336,7 +362,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
     b_dy[j] = kh * d.dil - d.pad;
     b_dx[j] = kw * d.dil - d.pad;
   }
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   uint4 ra[A_IT], rb[B_IT];
   auto gload = [&](int kt) {
     const int pbase = p_begin + kt * BKP;
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
       const int p = pbase + a_pix[i];
       const bool ok = a_ok[i] && p < p_end;
       const bf16_t* ptr = dy + (long)(ok ? p : 0) * lddy + m0 + a_co[i];
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(ptr) : zero4;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(ptr) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
@@ -357,7 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
       const int iy = oy * d.stride + b_dy[j], ix = ox * d.stride + b_dx[j];
       ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
       const long pix = ok ? (long)((b * d.H + iy) * d.W + ix) : 0;
-      rb[j] = ok ? *reinterpret_cast<const uint4*>(x + pix * d.ldx + b_ci[j]) : zero4;
+      rb[j] = ok ? *reinterpret_cast<const uint4*>(x + pix * d.ldx + b_ci[j]) : make_uint4(0, 0, 0, 0);
     }
   };
   auto lstore = [&](int buf) {
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
       __syncthreads();
     }
   }
-  float* out = partial + (long)blockIdx.y * cout_pad * Kflat;
+  float* out = partial + (long)by * cout_pad * Kflat;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -418,39 +443,50 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_tr_kernel(
         if (co < cout_pad && kcol < Kflat) out[(long)co * Kflat + kcol] = acc[mi][ni][r];
       }
     }
-}
+  }
+};
 
 // Workgroup (co, k-chunk of 64): 64 k-columns x 4 split lanes; each thread sums
 // every 4th split (coalesced 256-byte rows), the 4 lanes meet in LDS, and the
 // chunk is written to its OIHW positions.  k = (kh,kw,ci) -> (ci,kh,kw).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(
-    const float* __restrict__ partial, int nsplit, int cout_pad, int Cout, int Cin_pad, int Cin,
-    int KH, int KW, float* __restrict__ dw) {
-  __shared__ float sh[4][64];
-  const int co = blockIdx.x;
-  const int taps = KH * KW;
-  const int Kflat = taps * Cin_pad;
-  const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int k = blockIdx.y * 64 + kk;
-  const long split_stride = (long)cout_pad * Kflat;
-  float s0 = 0.f, s1 = 0.f;
-  if (k < Kflat) {
-    const float* src = partial + (long)co * Kflat + k;
-    int sp = sl;
-    for (; sp + 4 < nsplit; sp += 8) {
-      s0 += src[(long)sp * split_stride];
-      s1 += src[(long)(sp + 4) * split_stride];
+struct WgradReduceK {
+  struct Args { const float* partial; float* dw; int nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, accumulate; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+    __shared__ float sh[4][64];
+    const float* __restrict__ partial = a.partial;
+    float* __restrict__ dw = a.dw;
+    const int nsplit = a.nsplit, cout_pad = a.cout_pad, Cin_pad = a.Cin_pad, Cin = a.Cin;
+    const int co = bx;
+    const int taps = a.KH * a.KW;
+    const int Kflat = taps * Cin_pad;
+    const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int k = by * 64 + kk;
+    const long split_stride = (long)cout_pad * Kflat;
+    float s0 = 0.f, s1 = 0.f;
+    if (k < Kflat) {
+      const float* src = partial + (long)co * Kflat + k;
+      int sp = sl;
+      for (; sp + 4 < nsplit; sp += 8) {
+        s0 += src[(long)sp * split_stride];
+        s1 += src[(long)(sp + 4) * split_stride];
+      }
+      if (sp < nsplit) s0 += src[(long)sp * split_stride];
     }
-    if (sp < nsplit) s0 += src[(long)sp * split_stride];
+    sh[sl][kk] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && k < Kflat) {
+      const float v = (sh[0][kk] + sh[1][kk]) + (sh[2][kk] + sh[3][kk]);
+      const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
+      if (ci < Cin) {
+        float* dst = dw + ((long)co * Cin + ci) * taps + tap;
+        // accumulate: dw is the layer's slice of the step's gradient arena (cleared once per step);
+        // one reduce job per layer and launch, so the read-modify-write has no concurrent writer
+        *dst = a.accumulate ? *dst + v : v;
+      }
+    }
   }
-  sh[sl][kk] = s0 + s1;
-  __syncthreads();
-  if (sl == 0 && k < Kflat) {
-    const float v = (sh[0][kk] + sh[1][kk]) + (sh[2][kk] + sh[3][kk]);
-    const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
-    if (ci < Cin) dw[((long)co * Cin + ci) * taps + tap] = v;
-  }
-}
+};
 
 struct PackJob {           // mirror of ssa_pack_job (include/semseg_hip.h)
   const float* w;
@@ -603,11 +639,10 @@ int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float
   size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
   const size_t cs = (size_t)BM * (BN + 8) * 2 + (size_t)WGM * 2 * BN * sizeof(float);
   if (cs > lds) lds = cs;
-  hipLaunchKernelGGL((conv_igemm_kernel<WGM, WGN, MI, NI>), dim3(tiles_m * tiles_n),
-                     dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)w, bias, y,
-                     tiles_n, tr_shift, stats);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  IgemmArgs a;
+  a.d = d; a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
+  a.tiles_n = tiles_n; a.tr_shift = tr_shift;
+  return ssa::submit<ConvIgemm<WGM, WGN, MI, NI>>(a, tiles_m * tiles_n, 1, lds, s);
 }
 
 template <int WGM, int WGN, int MI, int NI>
@@ -623,11 +658,10 @@ int launch_wgrad(const ssa_conv_desc& d, const void* x, const void* dy, int lddy
   // register set for two-stage-ahead prefetch (96@128^2: 36 -> 52 us).
   chunk = (chunk + 31) / 32 * 32;
   const size_t lds = (size_t)2 * 32 * (tr_row_stride(BM) + tr_row_stride(BN)) * 2;
-  hipLaunchKernelGGL((conv_wgrad_tr_kernel<WGM, WGN, MI, NI, 32>), dim3(tiles_m * tiles_n, nsplit),
-                     dim3(64 * WGM * WGN), lds, s, d, (const bf16_t*)x, (const bf16_t*)dy, lddy,
-                     cout_pad, partial, tiles_n, (int)chunk);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  WgradTrArgs a;
+  a.d = d; a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
+  a.lddy = lddy; a.cout_pad = cout_pad; a.tiles_n = tiles_n; a.chunk = (int)chunk;
+  return ssa::submit<ConvWgradTr<WGM, WGN, MI, NI, 32>>(a, tiles_m * tiles_n, nsplit, lds, s);
 }
 
 // wgrad tile ids: 0 = 128x128, 1 = 64x64, 2 = 32x128, 3 = 96x128
@@ -722,6 +756,9 @@ int ssa_conv2d_wgrad_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit, siz
   const long P = (long)d->B * d->Ho * d->Wo;
   static const long target_wgs = getenv("SSA_WGRAD_WGS") ? atol(getenv("SSA_WGRAD_WGS")) : 640;
   long ns = (target_wgs + tiles - 1) / tiles;
+  // d->cfg > 0: 128-pixel stages per split asked for by the caller (grouped launches, see
+  // ssa_conv2d_wgrad_tile_plan)
+  if (d->cfg > 0) ns = (P + 128L * d->cfg - 1) / (128L * d->cfg);
   const long max_by_pixels = (P + 127) / 128;  // at least 4 stages per split
   if (ns > max_by_pixels) ns = max_by_pixels;
   if (ns < 1) ns = 1;
@@ -749,14 +786,11 @@ int ssa_conv2d_wgrad(const ssa_conv_desc* dp, const void* x, const void* dy, int
 }
 
 int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int Cout, int Cin_pad,
-                            int Cin, int KH, int KW, float* dw_oihw, void* stream) {
+                            int Cin, int KH, int KW, float* dw_oihw, int accumulate, void* stream) {
   if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad || nsplit < 1) return SSA_EINVAL;
   const int Kflat = KH * KW * Cin_pad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout, (Kflat + 63) / 64), dim3(256), 0,
-                     (hipStream_t)stream, partial, nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW,
-                     dw_oihw);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  WgradReduceK::Args a{partial, dw_oihw, nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, accumulate};
+  return ssa::submit<WgradReduceK>(a, Cout, (Kflat + 63) / 64, 0, (hipStream_t)stream);
 }
 
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job, void* stream) {

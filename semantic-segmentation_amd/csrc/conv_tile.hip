@@ -21,7 +21,23 @@
 // LDS image: [halo pixel][Cin] bf16 with pixel stride Cin*2+16 bytes: an odd
 // number of 16-byte slots, so the 16 lanes ds_read_b128 services together
 // (consecutive pixels, same channel offset) fall on 16 distinct slots.
+// Data-gradient variants with a fused epilogue tile (ssa_conv2d_tile_aux): a second tile
+// `aux`, congruent with the output tile, is staged through LDS in the epilogue:
+//   aux_mode 1: added to the output -- the residual branch's gradient, dX = dgrad + dres,
+//               rounded as the unfused bf16 add rounds (bf16(bf16(dgrad) + dres));
+//   aux_mode 2: taken as the INPUT x of the BatchNorm+ReLU layer whose output this conv
+//               consumed (network/hrnetv2.py:44-64: conv1 -> bn1 -> relu -> conv2): the epilogue
+//               accumulates that layer's backward sums  sum(m*dz)  and  sum(m*dz*xhat),
+//               m = [scale*x+shift > 0], xhat = (x-mean)*invstd, over the bf16-rounded dz it
+//               stores (coef = [4][Cout]: scale, shift, mean, invstd) into `stats`
+//               ([replica][2][Cout] fp64) -- what bn_bwd_reduce_kernel (bn.hip) computes in a
+//               pass of its own over (x, dz).
+//
+// Group-aware (group.h): inside an ssa_group_begin/ssa_group_end bracket the launches of the
+// independent problems of one depth level (branches x scale passes) that share a kernel
+// instantiation become one launch.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -56,11 +72,26 @@ __device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfr
 
 // CK: input channels staged per halo image (= Cin for 48/64/96; 192 for Cin = 192/384,
 // which run Cin/CK passes over the taps), TPC: taps per filter stage.
-template <int CK, int KS, int NB, int MI, int TW, int TPC>
-__global__ __launch_bounds__(256) void conv_tile_kernel(
-    const bf16_t* __restrict__ x, int ldx, int Cin, const uint4* __restrict__ wfrag,
-    const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
-    int Cout, int nb_total, int tiles_x, int tiles_y, double* __restrict__ stats) {
+struct TileArgs {
+  const bf16_t* x; const uint4* wfrag; const float* bias; bf16_t* y; double* stats;
+  const bf16_t* aux; const float* coef;
+  int ldx, Cin, ldy, B, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux, aux_mode;
+};
+
+template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
+struct ConvTile {
+  typedef TileArgs Args;
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const uint4* __restrict__ wfrag = a.wfrag;
+  const float* __restrict__ bias = a.bias;
+  bf16_t* __restrict__ y = a.y;
+  double* __restrict__ stats = a.stats;
+  const bf16_t* __restrict__ aux = a.aux;
+  const float* __restrict__ coef = a.coef;
+  const int ldx = a.ldx, Cin = a.Cin, ldy = a.ldy, H = a.H, W = a.W, Cout = a.Cout, nb_total = a.nb_total;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ldaux = a.ldaux, aux_mode = a.aux_mode;
   constexpr int R = KS / 2;
   constexpr int BM = 4 * MI * 32;              // output pixels per workgroup
   constexpr int TH = BM / TW;                  // tile rows
@@ -81,11 +112,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
+  int bid = bx;
   const int tx_i = bid % tiles_x; bid /= tiles_x;
   const int ty_i = bid % tiles_y; bid /= tiles_y;
   const int b = bid;
-  const int nb0 = blockIdx.y * NB;
+  const int nb0 = by * NB;
   const int x0 = tx_i * TW, y0 = ty_i * TH;
   const int nchunk = Cin / CK;
   const int csteps_total = Cin / 16;
@@ -164,22 +195,53 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
   // ---- epilogue: (+bias) -> bf16 -> LDS -> coalesced 16-byte stores; BN statistics
   __syncthreads();                              // everyone is done reading the halo image
   constexpr int LDC = NB * 32 + 8;              // staging row stride (elements)
+  constexpr int CPR = NB * 4;                   // 16-byte pieces per staged row
   bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
   float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 waves][2][NB*32]
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem + (size_t)BM * LDC * 2 + (size_t)4 * 2 * NB * 32 * sizeof(float));
+  if constexpr (AUX) {
+    // the aux tile (same pixels, same channels as the output tile) -> LDS, zero outside the image
+    const bf16_t* ab = aux + (long)b * H * W * ldaux;
+    for (int idx = tid; idx < BM * CPR; idx += 256) {
+      const int row = idx / CPR, cp = idx - row * CPR;
+      const int ty = row / TW, tx = row - ty * TW;
+      const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oy < H && ox < W && n + 8 <= Cout) v = *reinterpret_cast<const uint4*>(ab + ((long)oy * W + ox) * ldaux + n);
+      *reinterpret_cast<uint4*>(Xs + row * LDC + cp * 8) = v;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int col = nb * 32 + (lane & 31);
     const int n = nb0 * 32 + col;
     const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
     float s = 0.f, q = 0.f;
+    float ma = 0.f, mb = 0.f, mu = 0.f, is = 0.f;
+    if constexpr (AUX) {
+      if (aux_mode == 2 && n < Cout) { ma = coef[n]; mb = coef[Cout + n]; mu = coef[2 * Cout + n]; is = coef[3 * Cout + n]; }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const bf16_t o = f2bf(acc[mi][nb][r] + bv);
+        bf16_t o = f2bf(acc[mi][nb][r] + bv);
+        if constexpr (AUX) {
+          const float xv = bf2f(Xs[row * LDC + col]);
+          if (aux_mode == 1) {
+            o = f2bf(bf2f(o) + xv);
+          } else {
+            const int ty = row / TW, tx = row - ty * TW;
+            const float gz = (y0 + ty < H && x0 + tx < W) ? bf2f(o) : 0.f;
+            const float gm = (xv * ma + mb) > 0.f ? gz : 0.f;
+            s += gm;
+            q += gm * (xv - mu) * is;
+          }
+        }
         Cs[row * LDC + col] = o;
-        if (stats != nullptr) {
+        if (!(AUX) && stats != nullptr) {
           const int ty = row / TW, tx = row - ty * TW;
           const float f = (y0 + ty < H && x0 + tx < W) ? bf2f(o) : 0.f;
           s += f;
@@ -199,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
   __syncthreads();
   if (stats != nullptr) {
     // stats layout: [replica][2][C]; replica = workgroup index mod kStatReplicas
-    double* st = stats + (long)(blockIdx.x % kStatReplicas) * 2 * Cout;
+    double* st = stats + (long)(bx % kStatReplicas) * 2 * Cout;
     for (int i = tid; i < 2 * NB * 32; i += 256) {
       const int which = i / (NB * 32), col = i - which * NB * 32;
       const int n = nb0 * 32 + col;
@@ -211,7 +273,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
     }
   }
   bf16_t* yb = y + (long)b * H * W * ldy;
-  constexpr int CPR = NB * 4;                   // 16-byte pieces per staged row
   for (int idx = tid; idx < BM * CPR; idx += 256) {
     const int row = idx / CPR, cp = idx - row * CPR;
     const int ty = row / TW, tx = row - ty * TW;
@@ -225,69 +286,65 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(
       for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
     }
   }
-}
+  }
+};
 
-template <int CK, int KS, int NB, int MI, int TW, int TPC>
-int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
-                double* stats, hipStream_t s) {
+struct AuxArgs {
+  const void* aux;
+  int ld;
+  const float* coef;
+  int mode;               // 0: none, 1: add, 2: BatchNorm backward sums
+};
+
+template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
+int launch_tile_v(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
+                  double* stats, hipStream_t s, const AuxArgs& ax) {
   constexpr int R = KS / 2, BM = 4 * MI * 32, TH = BM / TW;
   constexpr int NSTAGE = KS * KS / TPC;
   constexpr size_t halo = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (CK * 2 + 16) + 1023) / 1024 * 1024;
   constexpr size_t filt = (size_t)(NSTAGE > 1 ? 2 : 1) * NB * TPC * (CK / 16) * 1024;
-  constexpr size_t stage = (size_t)BM * (NB * 32 + 8) * 2 + 4 * 2 * NB * 32 * sizeof(float);
+  // epilogue staging: output tile (+ aux tile) + reduction scratch
+  constexpr size_t stage = (size_t)(AUX ? 2 : 1) * BM * (NB * 32 + 8) * 2 + 4 * 2 * NB * 32 * sizeof(float);
   constexpr size_t lds = halo + filt > stage ? halo + filt : stage;
   static_assert(lds <= 160 * 1024, "tile does not fit in LDS");
-  const int tiles_x = (d.W + TW - 1) / TW, tiles_y = (d.H + TH - 1) / TH;
-  const int nb_total = (d.Cout + 31) / 32;
-  auto kern = conv_tile_kernel<CK, KS, NB, MI, TW, TPC>;
-  if (lds > 64 * 1024) {
-    static bool once = false;                  // per template instantiation
-    if (!once) {
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      once = true;
-    }
-  }
-  hipLaunchKernelGGL(kern, dim3(tiles_x * tiles_y * d.B, (nb_total + NB - 1) / NB), dim3(256), lds, s,
-                     (const bf16_t*)x, d.ldx, d.Cin, (const uint4*)wfrag, bias, (bf16_t*)y, d.ldy, d.B, d.H,
-                     d.W, d.Cout, nb_total, tiles_x, tiles_y, stats);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  TileArgs a;
+  a.x = (const bf16_t*)x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = (bf16_t*)y; a.stats = stats;
+  a.aux = (const bf16_t*)ax.aux; a.coef = ax.coef;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.B = d.B; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
+  a.nb_total = (d.Cout + 31) / 32;
+  a.tiles_x = (d.W + TW - 1) / TW; a.tiles_y = (d.H + TH - 1) / TH;
+  a.ldaux = ax.ld; a.aux_mode = ax.mode;
+  return ssa::submit<ConvTile<CK, KS, NB, MI, TW, TPC, AUX>>(a, a.tiles_x * a.tiles_y * d.B,
+                                                             (a.nb_total + NB - 1) / NB, lds, s);
+}
+
+template <int CK, int KS, int NB, int MI, int TW, int TPC>
+int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
+                double* stats, hipStream_t s, const AuxArgs& ax) {
+  if (ax.mode) return launch_tile_v<CK, KS, NB, MI, TW, TPC, true>(d, x, wfrag, bias, y, stats, s, ax);
+  return launch_tile_v<CK, KS, NB, MI, TW, TPC, false>(d, x, wfrag, bias, y, stats, s, ax);
 }
 
 // tile shape by image width: TW = 32 where the image is at least 32 wide.
 // big: two MFMA row blocks per wave (256 pixels per workgroup) where LDS allows.
 template <int CK, int KS, int NB, int TPC, bool BIG_OK, bool NARROW_OK = true>
 int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
-                  double* stats, hipStream_t s, bool want_big) {
+                  double* stats, hipStream_t s, bool want_big, const AuxArgs& ax) {
   if (d.W >= 32 || !NARROW_OK) {
     if constexpr (BIG_OK) {
-      if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s);
+      if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s, ax);
     }
-    return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s);
+    return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s, ax);
   }
   if constexpr (NARROW_OK) {
-    if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s);
-    return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s);
+    if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s, ax);
+    return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s, ax);
   }
   return SSA_EUNSUPPORTED;
 }
 
-}  // namespace
-
-extern "C" {
-
-int ssa_conv2d_tile_supported(const ssa_conv_desc* d) {
-  if (!d) return 0;
-  if (d->KH != d->KW || d->KH != 3) return 0;
-  if (d->stride != 1 || d->dil != 1 || d->transposed || d->pad != d->KH / 2) return 0;
-  if (d->Ho != d->H || d->Wo != d->W || d->out_f32) return 0;
-  if (d->Cout % 8 || d->ldy % 8 || d->ldx % 8) return 0;
-  return d->Cin == 48 || d->Cin == 64 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
-}
-
-int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
-                    void* y, double* stats, void* stream) {
+int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias, void* y,
+              double* stats, const AuxArgs& ax, void* stream) {
   if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
   if (!ssa_conv2d_tile_supported(dp)) return SSA_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
@@ -306,22 +363,50 @@ int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   const bool split_n = (cfg & 2) != 0;
   switch (d.Cin) {
     case 48:
-      if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big);
-      if (nbt == 2 || nbt == 4) return dispatch_geom<48, 3, 2, 9, true>(d, x, w_frag, bias, y, stats, s, big);
-      return dispatch_geom<48, 3, 3, 9, false>(d, x, w_frag, bias, y, stats, s, big);
+      if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<48, 3, 2, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<48, 3, 3, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     case 64:
-      if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big);
-      return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big);
+      if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     case 96:
-      if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big);
-      if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big);
-      return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big);
+      if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     case 192:
     case 384:      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
-      if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big);
-      return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big);
+      if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     default: return SSA_EUNSUPPORTED;
   }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_conv2d_tile_supported(const ssa_conv_desc* d) {
+  if (!d) return 0;
+  if (d->KH != d->KW || d->KH != 3) return 0;
+  if (d->stride != 1 || d->dil != 1 || d->transposed || d->pad != d->KH / 2) return 0;
+  if (d->Ho != d->H || d->Wo != d->W || d->out_f32) return 0;
+  if (d->Cout % 8 || d->ldy % 8 || d->ldx % 8) return 0;
+  return d->Cin == 48 || d->Cin == 64 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
+}
+
+int ssa_conv2d_tile(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
+                    void* y, double* stats, void* stream) {
+  return tile_impl(dp, x, w_frag, bias, y, stats, AuxArgs{nullptr, 0, nullptr, 0}, stream);
+}
+
+int ssa_conv2d_tile_aux(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
+                        void* y, double* stats, const void* aux, int ldaux, const float* coef,
+                        int aux_mode, void* stream) {
+  if (aux_mode != 1 && aux_mode != 2) return SSA_EINVAL;
+  if (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u)) return SSA_EINVAL;
+  if (aux_mode == 2 && (!coef || !stats)) return SSA_EINVAL;
+  if (aux_mode == 1 && stats) return SSA_EINVAL;          // forward statistics are not part of this epilogue
+  return tile_impl(dp, x, w_frag, bias, y, stats, AuxArgs{aux, ldaux, coef, aux_mode}, stream);
 }
 
 int ssa_bn_stat_replicas(void) { return kStatReplicas; }

@@ -15,10 +15,11 @@
 //     ds_read_b64_tr_b16 transposing reads, pixel stride 64*odd bytes (conflict free);
 //   * the next tile's global loads are issued into registers before the current
 //     tile's MFMAs and stored to LDS after them (one barrier pair per tile);
-//   * blockIdx.x = pixel split: only G = 256 / (#output blocks) partials per layer
+//   * grid.x = pixel split: only G = 256 / (#output blocks) partials per layer
 //     ([G][cout_pad][taps*Cin] fp32, summed by wgrad_reduce_kernel).
 // Replaces the K-pipelined conv_wgrad_tr_kernel (195 TFLOP/s on 720->512) for these shapes.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -42,11 +43,21 @@ __device__ __forceinline__ bf16x8_t tr8(const unsigned char* p, int stride_bytes
 
 // KS = 3: NT = 3 (the kw taps of kernel row kh), 128 input channels per workgroup.
 // KS = 1: NT = 2 (two 32-channel blocks per wave), 256 input channels per workgroup.
+struct WgradHeadArgs {
+  const bf16_t* x; const bf16_t* dy; float* partial;
+  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, ci_tiles;
+};
+
 template <int KS>
-__global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
-    const bf16_t* __restrict__ x, int ldx, int Cin, const bf16_t* __restrict__ dy, int lddy,
-    int cout_pad, int B, int H, int W, int tiles_x, int tiles_y, int tiles_per_wg, int ci_tiles,
-    float* __restrict__ partial) {
+struct ConvWgradHead {
+  typedef WgradHeadArgs Args;
+  static constexpr int NT = 512;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by_, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ dy = a.dy;
+  float* __restrict__ partial = a.partial;
+  const int ldx = a.ldx, Cin = a.Cin, lddy = a.lddy, cout_pad = a.cout_pad, B = a.B, H = a.H, W = a.W;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, tiles_per_wg = a.tiles_per_wg, ci_tiles = a.ci_tiles;
   constexpr int TW = 32, TH = 4, NT = KS == 3 ? 3 : 2;
   constexpr int CX = KS == 3 ? 128 : 256;                // input channels per workgroup
   constexpr int XW = KS == 3 ? TW + 2 : TW;              // x image width in pixels
@@ -62,8 +73,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  // blockIdx.y -> (co tile, ci tile, kh)
-  int by = blockIdx.y;
+  // grid.y -> (co tile, ci tile, kh)
+  int by = by_;
   const int kh = KS == 3 ? by % 3 : 0;
   if (KS == 3) by /= 3;
   const int ci_t = by % ci_tiles, co_t = by / ci_tiles;
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
       for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
   const int total_tiles = B * tiles_x * tiles_y;
-  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_begin = bx * tiles_per_wg;
   const int t_end = min(total_tiles, t_begin + tiles_per_wg);
   uint4 xv[XI], dv[DI];
   auto fetch = [&](int t) {
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
     }
   }
 
-  float* out = partial + (long)blockIdx.x * cout_pad * Kflat;
+  float* out = partial + (long)bx * cout_pad * Kflat;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -173,7 +184,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_head_kernel(
         if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[m][j][r];
       }
     }
-}
+  }
+};
 
 bool head_shape_ok(const ssa_conv_desc* d, int cout_pad) {
   if (!d || d->KH != d->KW || (d->KH != 3 && d->KH != 1)) return false;
@@ -207,18 +219,11 @@ int launch_head(const ssa_conv_desc& d, const HeadPlan& p, const void* x, const 
   constexpr int XW = KS == 3 ? 34 : 32, CX = KS == 3 ? 128 : 256;
   constexpr size_t lds = (size_t)4 * XW * trs(CX * 2) + (size_t)128 * trs(256);
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
-  auto kern = conv_wgrad_head_kernel<KS>;
-  static bool once = false;
-  if (!once) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    once = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.G, p.wgs_y), dim3(512), lds, s, (const bf16_t*)x, d.ldx, d.Cin,
-                     (const bf16_t*)dy, lddy, cout_pad, d.B, d.H, d.W, (d.W + 31) / 32, (d.H + 3) / 4, p.tpw,
-                     p.ci_tiles, partial);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  WgradHeadArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
+  a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = p.tpw; a.ci_tiles = p.ci_tiles;
+  return ssa::submit<ConvWgradHead<KS>>(a, p.G, p.wgs_y, lds, s);
 }
 
 }  // namespace

@@ -20,12 +20,13 @@
 //     probed on the device, tests/test_kernels_gpu.py::test_probe_tr16).  The
 //     pixel stride is 64*odd bytes, which puts the 4 pixels a 16-lane group reads
 //     in 4 distinct 64-byte windows of the 256-byte bank row: conflict free.
-// blockIdx.y partitions the output (co part, n part) so that a workgroup owns at
+// grid.y partitions the output (co part, n part) so that a workgroup owns at
 // most 12 accumulator tiles per wave:
 //     C=48: 2 m-blocks x 14 n-blocks (all taps)      C=64: 2 x 18
 //     C=96: 3 x 9 (one kernel row kh per part)       C=192/384: 6 x 6 (one tap,
 //     192 input channels and 192 output channels per part)
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 #include <stdlib.h>
 
@@ -48,11 +49,21 @@ __device__ __forceinline__ bf16x8_t tr_read8(const unsigned char* p, int stride_
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+struct WgradTileArgs {
+  const bf16_t* x; const bf16_t* dy; float* partial;
+  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, n_parts;
+};
+
 template <int CX, int MB, int NBW>
-__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
-    const bf16_t* __restrict__ x, int ldx, int Cin, const bf16_t* __restrict__ dy, int lddy,
-    int cout_pad, int B, int H, int W, int tiles_x, int tiles_y, int tiles_per_wg, int n_parts,
-    float* __restrict__ partial) {
+struct ConvWgradTile {
+  typedef WgradTileArgs Args;
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ dy = a.dy;
+  float* __restrict__ partial = a.partial;
+  const int ldx = a.ldx, Cin = a.Cin, lddy = a.lddy, cout_pad = a.cout_pad, B = a.B, H = a.H, W = a.W;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, tiles_per_wg = a.tiles_per_wg, n_parts = a.n_parts;
   constexpr int TW = 32, TH = 4, HW_ = TW + 2, HH_ = TH + 2;
   constexpr int SX = tr_stride_bytes(CX * 2), SD = tr_stride_bytes(MB * 64);
   constexpr int HALO_BYTES = HH_ * HW_ * SX;
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_part = blockIdx.y % n_parts, co_part = blockIdx.y / n_parts;
+  const int n_part = by % n_parts, co_part = by / n_parts;
   const int co0 = co_part * MB * 32;
   const int n0 = n_part * NBW * 32;
   const int Kflat = 9 * Cin;
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
       for (int r = 0; r < 16; ++r) acc[mb][l][r] = 0.f;
 
   const int total_tiles = B * tiles_x * tiles_y;
-  const int t_begin = blockIdx.x * tiles_per_wg;
+  const int t_begin = bx * tiles_per_wg;
   const int t_end = min(total_tiles, t_begin + tiles_per_wg);
   constexpr int XN = HH_ * HW_ * XP, DN = TH * TW * DP;
   constexpr int XI = (XN + 255) / 256, DI = (DN + 255) / 256;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
   }
 
   // ---- this workgroup's block of partial[g][co][k] (zeros if it had no tile)
-  float* out = partial + (long)blockIdx.x * cout_pad * Kflat;
+  float* out = partial + (long)bx * cout_pad * Kflat;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(
         if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[mb][l][r];
       }
     }
-}
+  }
+};
 
 struct Plan { int cx, mb, nbw, n_parts, co_parts; };
 
@@ -234,19 +246,11 @@ int launch(const ssa_conv_desc& d, const Plan& p, const void* x, const void* dy,
            int G, int tiles_per_wg, float* partial, hipStream_t s) {
   constexpr size_t lds = (size_t)6 * 34 * tr_stride_bytes(CX * 2) + (size_t)128 * tr_stride_bytes(MB * 64);
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
-  auto kern = conv_wgrad_tile_kernel<CX, MB, NBW>;
-  static bool once = false;
-  if (!once && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    once = true;
-  }
-  const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 3) / 4;
-  hipLaunchKernelGGL(kern, dim3(G, p.n_parts * p.co_parts), dim3(256), lds, s, (const bf16_t*)x, d.ldx, d.Cin,
-                     (const bf16_t*)dy, lddy, cout_pad, d.B, d.H, d.W, tiles_x, tiles_y, tiles_per_wg,
-                     p.n_parts, partial);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  WgradTileArgs a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
+  a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = tiles_per_wg; a.n_parts = p.n_parts;
+  return ssa::submit<ConvWgradTile<CX, MB, NBW>>(a, G, p.n_parts * p.co_parts, lds, s);
 }
 
 bool shape_ok(const ssa_conv_desc* d) {
@@ -267,6 +271,11 @@ int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit
   long g = (budget_mb << 20) / per_split;       // bounded partial traffic per layer
   if (g > 192) g = 192;
   if (g < 2) g = 2;
+  // d->cfg > 0: tiles per workgroup asked for by the caller -- grouped launches (group.h) get
+  // their parallelism from the number of layers in the launch, so a layer is split only far
+  // enough to bound a workgroup's serial strip; the partials then cost less than the operands
+  if (d->cfg > 0) g = (tiles + d->cfg - 1) / d->cfg;
+  if (g < 1) g = 1;
   if (g > tiles) g = tiles;
   const long tpw = (tiles + g - 1) / g;
   g = (tiles + tpw - 1) / tpw;

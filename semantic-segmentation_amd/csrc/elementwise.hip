@@ -4,14 +4,15 @@
 //   * sigmoid of the scale-attention logit (network/utils.py:363)
 //   * attention-weighted two-scale fusion (network/ocrnet.py:289-298)
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
 
-__global__ void sum_act_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+__device__ __forceinline__ void sum_act_kernel_body(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                const uint4* __restrict__ c, const uint4* __restrict__ d,
-                               uint4* __restrict__ z, long nv, int relu) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+                               uint4* __restrict__ z, long nv, int relu, const int bx, const int gx) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gx * blockDim.x) {
     float f[8], g[8];
     unpack8(a[i], f);
     if (b) { unpack8(b[i], g);
@@ -31,9 +32,9 @@ __global__ void sum_act_kernel(const uint4* __restrict__ a, const uint4* __restr
   }
 }
 
-__global__ void relu_bwd_kernel(const uint4* __restrict__ dz, const uint4* __restrict__ z,
-                                uint4* __restrict__ g, long nv) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void relu_bwd_kernel_body(const uint4* __restrict__ dz, const uint4* __restrict__ z,
+                                uint4* __restrict__ g, long nv, const int bx, const int gx) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gx * blockDim.x) {
     float f[8], zz[8];
     unpack8(dz[i], f);
     unpack8(z[i], zz);
@@ -42,6 +43,22 @@ __global__ void relu_bwd_kernel(const uint4* __restrict__ dz, const uint4* __res
     g[i] = pack8(f);
   }
 }
+
+
+struct SumActK {
+  struct Args { const uint4* a; const uint4* b; const uint4* c; const uint4* d; uint4* z; long nv; int relu; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    sum_act_kernel_body(a.a, a.b, a.c, a.d, a.z, a.nv, a.relu, bx, gx);
+  }
+};
+struct ReluBwdK {
+  struct Args { const uint4* dz; const uint4* z; uint4* g; long nv; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    relu_bwd_kernel_body(a.dz, a.z, a.g, a.nv, bx, gx);
+  }
+};
 
 // one thread per output pixel-group: reads C planes (coalesced along W), writes
 // one cpad-wide NHWC pixel.
@@ -146,20 +163,15 @@ int ssa_sum_act(const void* a, const void* b, const void* c, const void* d, void
                 int relu, void* stream) {
   if (!a || !z || n <= 0 || n % 8) return SSA_EINVAL;
   const long nv = n / 8;
-  hipLaunchKernelGGL(sum_act_kernel, dim3(grid_for(nv)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)a, (const uint4*)b, (const uint4*)c, (const uint4*)d, (uint4*)z,
-                     nv, relu);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  SumActK::Args k{(const uint4*)a, (const uint4*)b, (const uint4*)c, (const uint4*)d, (uint4*)z, nv, relu};
+  return ssa::submit<SumActK>(k, grid_for(nv), 1, 0, (hipStream_t)stream);
 }
 
 int ssa_relu_bwd(const void* dz, const void* z, void* g, long n, void* stream) {
   if (!dz || !z || !g || n <= 0 || n % 8) return SSA_EINVAL;
   const long nv = n / 8;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(nv)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)dz, (const uint4*)z, (uint4*)g, nv);
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  ReluBwdK::Args k{(const uint4*)dz, (const uint4*)z, (uint4*)g, nv};
+  return ssa::submit<ReluBwdK>(k, grid_for(nv), 1, 0, (hipStream_t)stream);
 }
 
 int ssa_nchw_f32_to_nhwc_bf16(const float* x, void* y, int B, int C, int H, int W, int cpad,

@@ -1,0 +1,183 @@
+// Multi-problem ("grouped") launches.
+//
+// A B=1 training step of HRNet-OCR-MScale is ~5,500 kernel launches of 5-20 us each
+// (profiles/r01_bench_graph_summary.txt): the 2-4 resolution branches of a
+// HighResolutionModule (network/hrnetv2.py:181-254) times the two scale passes of
+// MscaleOCR.two_scale_forward (network/ocrnet.py:264-327) are up to 8 INDEPENDENT problems
+// of 8..512 workgroups each, none of which fills 256 CUs.  The host glue therefore walks
+// those problems in lockstep and brackets the launches of one depth level with
+// ssa_group_begin() / ssa_group_end(stream): inside the bracket every group-aware entry
+// point appends its (arguments, grid) to a per-thread list instead of launching, and
+// ssa_group_end issues ONE launch per kernel instantiation whose grid is the concatenation
+// of the problems' grids.  The job table travels as a kernel argument (<= 4 KB, so a
+// captured hipGraph owns it); a workgroup finds its problem by a scalar scan over at most
+// 16 prefix sums and then runs the unchanged kernel body with a virtual block index.
+//
+// Contract: launches submitted inside one bracket are mutually independent (no job reads
+// what another job of the bracket writes).  Entry points that are not group-aware launch
+// immediately, which is always correct under that contract.
+//
+// A kernel takes part by being written as
+//     struct MyKernel { struct Args {...}; static constexpr int NT = 256;
+//                       static __device__ void run(const Args& a, int bx, int by, int gx); };
+// and launched with ssa::submit<MyKernel>(args, grid_x, grid_y, lds_bytes, stream).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+
+namespace ssa {
+
+constexpr int kKernargBudget = 3840;   // bytes of kernel arguments a grouped launch may use
+
+template <class K>
+struct GroupLimits {
+  static constexpr int per_job = (int)sizeof(typename K::Args) + 8;
+  static constexpr int raw = (kKernargBudget - 16) / per_job;
+  static constexpr int jobs = raw > 16 ? 16 : (raw < 1 ? 1 : raw);
+};
+
+template <class K>
+struct GroupTable {
+  int n, pad_;
+  int end[GroupLimits<K>::jobs];        // exclusive prefix sums of the problems' workgroup counts
+  int gx[GroupLimits<K>::jobs];         // grid.x of each problem (virtual blockIdx.x = v % gx, .y = v / gx)
+  typename K::Args a[GroupLimits<K>::jobs];
+};
+
+template <class K>
+__global__ __launch_bounds__(K::NT) void k_single(const typename K::Args a) {
+  K::run(a, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+template <class K>
+__global__ __launch_bounds__(K::NT) void k_grouped(const GroupTable<K> t) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < t.n && (int)blockIdx.x >= t.end[j]) ++j;
+  const int v = (int)blockIdx.x - (j ? t.end[j - 1] : 0);
+  const int gx = t.gx[j];
+  K::run(t.a[j], v % gx, v / gx, gx);
+}
+
+struct Bucket {
+  const void* key;                                   // identity of the kernel instantiation
+  int (*flush)(Bucket&, hipStream_t);
+  std::vector<unsigned char> args;
+  std::vector<int> gx, gy;
+  std::vector<double> flops, bytes;                  // profile notes of the queued jobs (ssa_profile_note)
+  size_t lds;
+};
+
+// Per-launch timing (ssa_profile_begin/_end): every launch that goes through submit<> is
+// bracketed by HIP events on its stream and keyed by the kernel instantiation's name, with the
+// algorithmic flops/bytes the host attached to its jobs -- what bench.py's roofline leg reads.
+bool profiling();
+void profile_take_note(double* flops, double* bytes);          // note attached to the next job (cleared)
+void* profile_open(const char* kernel, hipStream_t s);          // records the start event
+void profile_close(void* h, hipStream_t s, int jobs, double flops, double bytes);
+
+template <class K>
+const char* kernel_name() { return __PRETTY_FUNCTION__; }
+
+struct GroupState {
+  int depth = 0;
+  int error = 0;
+  std::vector<Bucket> buckets;
+};
+
+GroupState& group_state();      // per host thread (forward: main thread, backward: autograd thread)
+void count_launches(int n);     // library-wide launch counter (ssa_launch_count)
+
+template <class K>
+int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
+  if (lds > 64 * 1024 && lds > *set_to) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    *set_to = lds;
+  }
+  return 0;
+}
+
+template <class K>
+int flush_bucket(Bucket& b, hipStream_t s) {
+  typedef typename K::Args Args;
+  constexpr int J = GroupLimits<K>::jobs;
+  static size_t lds_single = 0, lds_grouped = 0;
+  const int n = (int)b.gx.size();
+  for (int j0 = 0; j0 < n; j0 += J) {
+    const int cnt = n - j0 < J ? n - j0 : J;
+    if (cnt == 1) {
+      Args a;
+      memcpy(&a, b.args.data() + (size_t)j0 * sizeof(Args), sizeof(Args));
+      if (int e = ensure_lds<K>((const void*)k_single<K>, b.lds, &lds_single)) return e;
+      void* ph = profiling() ? profile_open(kernel_name<K>(), s) : nullptr;
+      hipLaunchKernelGGL(k_single<K>, dim3(b.gx[j0], b.gy[j0]), dim3(K::NT), b.lds, s, a);
+      if (ph) profile_close(ph, s, 1, b.flops[j0], b.bytes[j0]);
+    } else {
+      GroupTable<K> t;
+      memset(&t, 0, sizeof(t));
+      t.n = cnt;
+      int total = 0;
+      for (int i = 0; i < cnt; ++i) {
+        total += b.gx[j0 + i] * b.gy[j0 + i];
+        t.end[i] = total;
+        t.gx[i] = b.gx[j0 + i];
+        memcpy(&t.a[i], b.args.data() + (size_t)(j0 + i) * sizeof(Args), sizeof(Args));
+      }
+      if (int e = ensure_lds<K>((const void*)k_grouped<K>, b.lds, &lds_grouped)) return e;
+      void* ph = profiling() ? profile_open(kernel_name<K>(), s) : nullptr;
+      hipLaunchKernelGGL(k_grouped<K>, dim3(total), dim3(K::NT), b.lds, s, t);
+      if (ph) {
+        double fl = 0, by = 0;
+        for (int i = 0; i < cnt; ++i) { fl += b.flops[j0 + i]; by += b.bytes[j0 + i]; }
+        profile_close(ph, s, cnt, fl, by);
+      }
+    }
+    count_launches(1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// Launch now, or -- inside an ssa_group_begin/ssa_group_end bracket -- queue for the grouped launch.
+template <class K>
+int submit(const typename K::Args& a, int gx, int gy, size_t lds, hipStream_t s) {
+  typedef typename K::Args Args;
+  static_assert(sizeof(GroupTable<K>) <= kKernargBudget + 64, "job table exceeds the kernel-argument budget");
+  if (gx <= 0 || gy <= 0) return -1;
+  GroupState& g = group_state();
+  double note_f = 0, note_b = 0;
+  const bool prof = profiling();
+  if (prof) profile_take_note(&note_f, &note_b);
+  if (g.depth == 0) {
+    static size_t lds_single = 0;
+    if (int e = ensure_lds<K>((const void*)k_single<K>, lds, &lds_single)) return e;
+    void* ph = prof ? profile_open(kernel_name<K>(), s) : nullptr;
+    hipLaunchKernelGGL(k_single<K>, dim3(gx, gy), dim3(K::NT), lds, s, a);
+    if (ph) profile_close(ph, s, 1, note_f, note_b);
+    count_launches(1);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+  }
+  const void* key = (const void*)k_grouped<K>;
+  Bucket* b = nullptr;
+  for (Bucket& c : g.buckets)
+    if (c.key == key) { b = &c; break; }
+  if (!b) {
+    g.buckets.push_back(Bucket{key, &flush_bucket<K>, {}, {}, {}, {}, {}, 0});
+    b = &g.buckets.back();
+  }
+  const size_t off = b->args.size();
+  b->args.resize(off + sizeof(Args));
+  memcpy(b->args.data() + off, &a, sizeof(Args));
+  b->gx.push_back(gx);
+  b->gy.push_back(gy);
+  b->flops.push_back(note_f);
+  b->bytes.push_back(note_b);
+  if (lds > b->lds) b->lds = lds;
+  return 0;
+}
+
+}  // namespace ssa

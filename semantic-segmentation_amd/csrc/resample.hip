@@ -6,6 +6,7 @@
 // The backward is a gather over the output pixels that reference an input
 // pixel -- deterministic, no atomics.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -25,11 +26,11 @@ __device__ __forceinline__ Src src_index(int o, float scale, int in_size) {
 }
 
 // ---- forward, 8 bf16 channels per thread
-__global__ void bilinear_fwd_v8(const bf16_t* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
-                                bf16_t* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw) {
+__device__ __forceinline__ void bilinear_fwd_v8_body(const bf16_t* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
+                                bf16_t* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw, const int bx, const int gx) {
   const int VC = C >> 3;
   const long n = (long)B * Ho * Wo * VC;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
     const int cg = (int)(i % VC);
     long t = i / VC;
     const int ox = (int)(t % Wo); t /= Wo;
@@ -51,10 +52,10 @@ __global__ void bilinear_fwd_v8(const bf16_t* __restrict__ x, int B, int Hi, int
 
 // ---- forward, one element per thread (any C, any dtype pair)
 template <typename InT, typename OutT>
-__global__ void bilinear_fwd_s(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
-                               OutT* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw) {
+__device__ __forceinline__ void bilinear_fwd_s_body(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
+                               OutT* __restrict__ y, int Ho, int Wo, int ldy, float sh, float sw, const int bx, const int gx) {
   const long n = (long)B * Ho * Wo * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
     const int c = (int)(i % C);
     long t = i / C;
     const int ox = (int)(t % Wo); t /= Wo;
@@ -88,12 +89,12 @@ __device__ __forceinline__ float weight_for(int o, float scale, int in_size, int
 }
 
 // ---- backward gather, 8 bf16 channels per thread
-__global__ void bilinear_bwd_v8(const bf16_t* __restrict__ dy, int B, int Ho, int Wo, int C,
+__device__ __forceinline__ void bilinear_bwd_v8_body(const bf16_t* __restrict__ dy, int B, int Ho, int Wo, int C,
                                 int lddy, bf16_t* __restrict__ dx, int Hi, int Wi, int lddx, float sh,
-                                float sw) {
+                                float sw, const int bx, const int gx) {
   const int VC = C >> 3;
   const long n = (long)B * Hi * Wi * VC;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
     const int cg = (int)(i % VC);
     long t = i / VC;
     const int ix = (int)(t % Wi); t /= Wi;
@@ -124,10 +125,10 @@ __global__ void bilinear_bwd_v8(const bf16_t* __restrict__ dy, int B, int Ho, in
 }
 
 template <typename InT, typename OutT>
-__global__ void bilinear_bwd_s(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
-                               OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw) {
+__device__ __forceinline__ void bilinear_bwd_s_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
+                               OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw, const int bx, const int gx) {
   const long n = (long)B * Hi * Wi * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
     const int c = (int)(i % C);
     long t = i / C;
     const int ix = (int)(t % Wi); t /= Wi;
@@ -208,6 +209,28 @@ __global__ void resize_nearest_u8_kernel(const unsigned char* __restrict__ src, 
   }
 }
 
+
+// ---- group-aware wrappers (group.h)
+template <typename InT, typename OutT, bool V8, bool BWD>
+struct BilinearK {
+  // forward: (x [B,Hi,Wi,C] ldx) -> (y [B,Ho,Wo,C] ldy); backward: (dy [B,Ho,Wo,C]) -> (dx [B,Hi,Wi,C])
+  struct Args { const InT* src; OutT* dst; int B, Hs, Ws, C, lds, Hd, Wd, ldd; float sh, sw; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    if constexpr (V8 && !BWD) bilinear_fwd_v8_body(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+    else if constexpr (V8 && BWD) bilinear_bwd_v8_body(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+    else if constexpr (!BWD) bilinear_fwd_s_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+    else bilinear_bwd_s_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+  }
+};
+template <typename InT, typename OutT, bool V8, bool BWD>
+int launch_bilinear(const void* src, int B, int Hs, int Ws, int C, int lds, void* dst, int Hd, int Wd, int ldd,
+                    float sh, float sw, long nthreads, hipStream_t s) {
+  typedef BilinearK<InT, OutT, V8, BWD> K;
+  typename K::Args a{(const InT*)src, (OutT*)dst, B, Hs, Ws, C, lds, Hd, Wd, ldd, sh, sw};
+  return ssa::submit<K>(a, grid_for(nthreads), 1, 0, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -218,26 +241,17 @@ int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C, 
   hipStream_t s = (hipStream_t)stream;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   const long n = (long)B * Ho * Wo * C;
-  if (in_dtype == 0 && out_dtype == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0) {
-    hipLaunchKernelGGL(bilinear_fwd_v8, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)x, B,
-                       Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
-  } else if (in_dtype == 0 && out_dtype == 0) {
-    hipLaunchKernelGGL((bilinear_fwd_s<bf16_t, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const bf16_t*)x, B, Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
-  } else if (in_dtype == 0 && out_dtype == 1) {
-    hipLaunchKernelGGL((bilinear_fwd_s<bf16_t, float>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const bf16_t*)x, B, Hi, Wi, C, ldx, (float*)y, Ho, Wo, ldy, sh, sw);
-  } else if (in_dtype == 1 && out_dtype == 1) {
-    hipLaunchKernelGGL((bilinear_fwd_s<float, float>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const float*)x, B, Hi, Wi, C, ldx, (float*)y, Ho, Wo, ldy, sh, sw);
-  } else if (in_dtype == 1 && out_dtype == 0) {
-    hipLaunchKernelGGL((bilinear_fwd_s<float, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const float*)x, B, Hi, Wi, C, ldx, (bf16_t*)y, Ho, Wo, ldy, sh, sw);
-  } else {
-    return SSA_EINVAL;
-  }
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  if (in_dtype == 0 && out_dtype == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
+    return launch_bilinear<bf16_t, bf16_t, true, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n / 8, s);
+  if (in_dtype == 0 && out_dtype == 0)
+    return launch_bilinear<bf16_t, bf16_t, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
+  if (in_dtype == 0 && out_dtype == 1)
+    return launch_bilinear<bf16_t, float, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
+  if (in_dtype == 1 && out_dtype == 1)
+    return launch_bilinear<float, float, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
+  if (in_dtype == 1 && out_dtype == 0)
+    return launch_bilinear<float, bf16_t, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
+  return SSA_EINVAL;
 }
 
 int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C, int lddy, void* dx,
@@ -246,23 +260,15 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
   hipStream_t s = (hipStream_t)stream;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   const long n = (long)B * Hi * Wi * C;
-  if (dy_dtype == 0 && dx_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0) {
-    hipLaunchKernelGGL(bilinear_bwd_v8, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)dy,
-                       B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
-  } else if (dy_dtype == 1 && dx_dtype == 1) {
-    hipLaunchKernelGGL((bilinear_bwd_s<float, float>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const float*)dy, B, Ho, Wo, C, lddy, (float*)dx, Hi, Wi, lddx, sh, sw);
-  } else if (dy_dtype == 1 && dx_dtype == 0) {
-    hipLaunchKernelGGL((bilinear_bwd_s<float, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const float*)dy, B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
-  } else if (dy_dtype == 0 && dx_dtype == 0) {
-    hipLaunchKernelGGL((bilinear_bwd_s<bf16_t, bf16_t>), dim3(grid_for(n)), dim3(256), 0, s,
-                       (const bf16_t*)dy, B, Ho, Wo, C, lddy, (bf16_t*)dx, Hi, Wi, lddx, sh, sw);
-  } else {
-    return SSA_EINVAL;
-  }
-  SSA_LAUNCH_CHECK();
-  return SSA_OK;
+  if (dy_dtype == 0 && dx_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0)
+    return launch_bilinear<bf16_t, bf16_t, true, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n / 8, s);
+  if (dy_dtype == 1 && dx_dtype == 1)
+    return launch_bilinear<float, float, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
+  if (dy_dtype == 1 && dx_dtype == 0)
+    return launch_bilinear<float, bf16_t, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
+  if (dy_dtype == 0 && dx_dtype == 0)
+    return launch_bilinear<bf16_t, bf16_t, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
+  return SSA_EINVAL;
 }
 
 int ssa_image_resize_to_nhwc_bf16(const float* x, int B, int C, int Hi, int Wi, void* y, int Ho,

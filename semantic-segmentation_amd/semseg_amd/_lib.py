@@ -28,10 +28,10 @@ class BnUpdateJob(ctypes.Structure):
                 ("pad_", c_int)]
 
 
-class WgradReduceJob(ctypes.Structure):
-    """Mirror of ssa_wgrad_reduce_job (48 bytes)."""
-    _fields_ = [("partial", c_void_p), ("dw", c_void_p)] + [(n, c_int) for n in (
-        "nsplit", "cout_pad", "Cout", "Cin_pad", "Cin", "KH", "KW", "pad_")]
+class ProfileRec(ctypes.Structure):
+    """Mirror of ssa_profile_rec."""
+    _fields_ = [("kernel", ctypes.c_char * 120), ("launches", c_long), ("jobs", c_long),
+                ("total_us", c_double), ("flops", c_double), ("bytes", c_double)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -44,6 +44,13 @@ class ConvDesc(ctypes.Structure):
 _P = c_void_p
 _SIGS = {
     "ssa_version": ([], c_int),
+    "ssa_group_begin": ([], c_int),
+    "ssa_group_end": ([_P], c_int),
+    "ssa_group_abort": ([], c_int),
+    "ssa_launch_count": ([c_int], c_long),
+    "ssa_profile_begin": ([], c_int),
+    "ssa_profile_note": ([c_double, c_double], c_int),
+    "ssa_profile_end": ([POINTER(ProfileRec), c_int], c_int),
     "ssa_conv2d_igemm": ([POINTER(ConvDesc), _P, _P, _P, _P, _P], c_int),
     "ssa_conv2d_igemm_stats": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_conv2d_igemm_tile": ([POINTER(ConvDesc)], c_int),
@@ -60,8 +67,7 @@ _SIGS = {
     "ssa_conv2d_wgrad_tile": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_head_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_head": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
-    "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, _P], c_int),
-    "ssa_conv2d_wgrad_reduce_batched": ([_P, c_int, _P], c_int),
+    "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, c_int, _P], c_int),
     "ssa_colsum_bf16": ([_P, c_long, c_int, c_int, _P, _P, _P], c_int),
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
@@ -76,7 +82,7 @@ _SIGS = {
     "ssa_bn_bwd_reduce": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
                            c_long, _P, c_int, c_int, _P, _P, _P], c_int),
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
-                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, _P], c_int),
+                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
     "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
     "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),

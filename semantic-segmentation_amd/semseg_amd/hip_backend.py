@@ -6,17 +6,30 @@ and losses fp32.  PyTorch provides device memory, streams and autograd
 bookkeeping only.  Nothing here falls back to ATen math: a missing or stale
 library raises in `_lib.lib()`.
 
+Multi-problem execution.  The resolution branches of a HighResolutionModule and the
+scale passes of MscaleOCR are independent problems; the network code walks them in
+lockstep and hands every depth level to ONE autograd Function here (ConvGroupFn,
+BnActGroupFn, BasicBlockGroupFn, ...), which issues the problems' launches inside an
+ssa_group_begin/ssa_group_end bracket -- one launch per kernel instantiation instead
+of one per problem (csrc/group.h).
+
+Parameter gradients never travel through autograd's AccumulateGrad: weight-gradient
+kernels and the BatchNorm backward ADD into slices of a per-step fp32 gradient arena
+(cleared by one memset), the weight gradients of a whole module are deferred and
+issued as grouped launches, and an end-of-backward callback publishes the slices as
+`param.grad` (and hands the arena to the data-parallel wrapper for its all-reduce).
+
 hipGraph-capture safe: no host synchronisation, no `.item()`, allocations come
 from torch's caching allocator, kernels are enqueued on the current stream.
 """
+import contextlib
 import ctypes
-import math
 import os
+import weakref
 
 import torch
-import torch.distributed as dist
 
-from ._lib import lib, check, ConvDesc, WgradReduceJob
+from ._lib import lib, check, ConvDesc, PackJob, BnUpdateJob, ProfileRec
 
 ACT_DTYPE = torch.bfloat16
 
@@ -62,16 +75,56 @@ def _pixels(t):
 
 
 # --------------------------------------------------------------------------
+# grouped launches (csrc/group.h)
+# --------------------------------------------------------------------------
+@contextlib.contextmanager
+def group():
+    """Launches of group-aware entry points issued inside the bracket are mutually
+    independent problems; they leave as one launch per kernel instantiation."""
+    L = lib()
+    check(L.ssa_group_begin(), "ssa_group_begin")
+    try:
+        yield
+    except BaseException:
+        L.ssa_group_abort()
+        raise
+    check(L.ssa_group_end(_s()), "ssa_group_end")
+
+
+_PROFILING = [False]
+
+
+def profile_begin():
+    """bench.py's roofline leg: time every launch of the group-aware kernels with HIP events."""
+    check(lib().ssa_profile_begin(), "ssa_profile_begin")
+    _PROFILING[0] = True
+
+
+def profile_end(max_recs=512):
+    """-> list of dicts {kernel, launches, jobs, total_us, flops, bytes} per kernel instantiation."""
+    _PROFILING[0] = False
+    arr = (ProfileRec * max_recs)()
+    n = lib().ssa_profile_end(arr, max_recs)
+    if n < 0:
+        raise RuntimeError("ssa_profile_end failed")
+    return [{"kernel": arr[i].kernel.decode(), "launches": arr[i].launches, "jobs": arr[i].jobs,
+             "total_us": arr[i].total_us, "flops": arr[i].flops, "bytes": arr[i].bytes} for i in range(min(n, max_recs))]
+
+
+def _note(flops, nbytes):
+    if _PROFILING[0]:
+        lib().ssa_profile_note(float(flops), float(nbytes))
+
+
+# --------------------------------------------------------------------------
 # packed filters: persistent bf16 GEMM operands, one per (parameter, form).
 # They are re-derived from the fp32 parameters whenever those changed (every
 # optimizer step) by ONE batched launch at the start of the step -- captured in
 # the step's hipGraph -- instead of 1,276 separate pack launches.
+# The cache keys on the parameter's storage address and autograd version counter:
+# optimizers that write through `p.data` (no version bump) must call
+# invalidate_packed_filters() after their step (FusedSGD bumps the counters itself).
 # --------------------------------------------------------------------------
-import weakref
-
-from ._lib import PackJob
-
-
 class _Packed:
     __slots__ = ("wref", "out", "Kpad", "version", "job", "shape")
 
@@ -83,6 +136,12 @@ _JOB_TABLE = {"key": None, "dev": None, "n": 0}
 def clear_pack_cache():
     _PACKED.clear()
     _JOB_TABLE.update(key=None, dev=None, n=0)
+
+
+def invalidate_packed_filters():
+    """Force a re-pack of every cached filter at the next step."""
+    for e in _PACKED.values():
+        e.version = -1
 
 
 def _make_job(w, out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows):
@@ -102,7 +161,9 @@ def refresh_packed_filters():
             stale.append((key, e, w))
     if not stale:
         return
-    tkey = tuple(k for k, _, _ in stale)
+    # the table is valid for exactly these (source, destination) buffers: a model rebuilt at the
+    # same parameter addresses has new destination buffers and must not reuse the old table
+    tkey = tuple((k, e.out.data_ptr()) for k, e, _ in stale)
     if _JOB_TABLE["key"] != tkey:
         arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
@@ -116,8 +177,6 @@ def refresh_packed_filters():
 def _packed_filter(weight, mode, cin_pad, cout_pad):
     key = (weight.data_ptr(), mode, cin_pad, cout_pad)
     e = _PACKED.get(key)
-    # same storage + same version counter = same values: also true for the detached "shadow"
-    # leaves the 0.5x pass runs on (MscaleOCR._shadow_parameters), which alias the parameter
     if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
@@ -142,6 +201,7 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
         e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows)
         if direct:              # only parameters packed straight from their own storage are batched
             _PACKED[key] = e
+            _JOB_TABLE.update(key=None)      # a new destination buffer: the device table is stale
     check(lib().ssa_pack_filter(_p(w), _p(e.out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, _s()),
           "ssa_pack_filter")
     e.version = weight._version
@@ -150,24 +210,33 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
 
 # --------------------------------------------------------------------------
 # fp64 statistics arena: BN (and bias-gradient) partial sums are carved out of
-# one buffer that is cleared with a single memset per step instead of one
-# memset per BatchNorm call (1,262 per training step).
+# chunks that are cleared with a single memset instead of one memset per
+# BatchNorm call (1,262 per training step).  A chunk that runs full is left alone
+# (kernels in flight may still accumulate into it); a fresh one is started.
 # --------------------------------------------------------------------------
 class _Arena:
+    CHUNK = 1 << 22             # doubles (32 MB)
+
     def __init__(self):
         self.buf = None
         self.cur = 0
+        self.spill = []         # full chunks of this step, kept alive until the next reset
 
     def reset(self, device):
+        self.spill = []
         if self.buf is None or self.buf.device != device:
-            self.buf = torch.empty((1 << 22,), dtype=torch.float64, device=device)   # 32 MB
+            self.buf = torch.empty((self.CHUNK,), dtype=torch.float64, device=device)
         self.buf.zero_()
         self.cur = 0
 
     def take(self, n, device):
         n = _roundup(n, 32)
-        if self.buf is None or self.buf.device != device or self.cur + n > self.buf.numel():
+        if self.buf is None or self.buf.device != device:
             self.reset(device)
+        if self.cur + n > self.buf.numel():
+            self.spill.append(self.buf)
+            self.buf = torch.zeros((max(self.CHUNK, n),), dtype=torch.float64, device=device)
+            self.cur = 0
         out = self.buf[self.cur:self.cur + n]
         self.cur += n
         return out
@@ -179,9 +248,6 @@ _ARENA = _Arena()
 # --------------------------------------------------------------------------
 # deferred BatchNorm running-statistics updates (see ssa_bn_update_running_batched)
 # --------------------------------------------------------------------------
-from ._lib import BnUpdateJob
-
-
 class _BnUpdates:
     def __init__(self):
         self.slots = {}       # id(bn) -> (bn, [persistent pass_stats tensors])
@@ -237,59 +303,97 @@ def end_forward():
 
 def begin_step(device=None):
     _BN_UPDATES.step = {}
-    del _PENDING_REDUCES[:]                  # (left over only if a backward pass was aborted)
-    _REDUCE_CALLBACK_QUEUED[0] = False
+    _PENDING_STATS.clear()
     refresh_packed_filters()
     if device is not None:
         _ARENA.reset(device)
 
 
-def _pack_matrix(src, R, C, ld, transpose, rows_out, Kpad):
-    out = torch.empty((rows_out, Kpad), dtype=ACT_DTYPE, device=src.device)
-    dt = 0 if src.dtype == ACT_DTYPE else 1
-    check(lib().ssa_pack_matrix(_p(src), dt, R, C, ld, int(transpose), _p(out), rows_out, Kpad, _s()),
-          "ssa_pack_matrix")
-    return out
+# --------------------------------------------------------------------------
+# gradient arena: parameter gradients are accumulated by the kernels themselves
+# --------------------------------------------------------------------------
+def _is_param(t):
+    return isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32
 
 
-# Optional per-launch timing (bench.py's roofline leg): a list that receives
-# (kind, tile, flops, start_event, end_event) for every GEMM-class launch.
-_PROFILE = None
+_GRAD_SINK = [None]     # callable(list of (chunk, used_elements)) run before publication (DDP all-reduce)
 
 
-def set_profile(store):
-    global _PROFILE
-    _PROFILE = store
+def set_grad_sink(fn):
+    _GRAD_SINK[0] = fn
 
 
-def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
-           cfg=-1, stats=None):
-    """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
-    B, H, W, Cin = geom_in
-    Ho, Wo = geom_out
-    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE, device=x.device)
-    d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, int(transposed),
-                 Kpad, int(out_f32), cfg)
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        tile = lib().ssa_conv2d_igemm_tile(ctypes.byref(d))
-        e0.record()
-    check(lib().ssa_conv2d_igemm_stats(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _p(stats), _s()),
-          "ssa_conv2d_igemm")
-    if _PROFILE is not None:
-        e1.record()
-        # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
-        taps = k[0] * k[1] / (stride * stride if transposed else 1)
-        _PROFILE.append(("igemm", tile, 2.0 * B * Ho * Wo * Cout * Cin * taps, e0, e1, (k[0], stride, Cin, Cout, Ho, Wo)))
-    return y
+class _GradArena:
+    """fp32 slices, one per parameter, of buffers cleared on allocation.  Weight-gradient
+    reduces and the BatchNorm backward ADD into a parameter's slice (every scale pass, every
+    flush), so autograd never launches an accumulation; at the end of backward the slices
+    become `param.grad` (added to an existing .grad, as autograd would)."""
+    FIRST_CHUNK = 1 << 24       # elements, until the total of a step is known
+
+    def __init__(self):
+        self.chunks = []        # [tensor, used]
+        self.slots = {}         # id(param) -> (param, view)
+        self.total_last = 0
+        self.armed = False
+
+    def slot(self, p):
+        e = self.slots.get(id(p))
+        if e is not None and e[0] is p:
+            return e[1]
+        n = _roundup(p.numel(), 64)
+        if not self.chunks or self.chunks[-1][1] + n > self.chunks[-1][0].numel() or \
+                self.chunks[-1][0].device != p.device:
+            size = max(n, self.total_last if not self.chunks else self.FIRST_CHUNK, 1)
+            if not self.chunks and not self.total_last:
+                size = max(n, self.FIRST_CHUNK)
+            self.chunks.append([torch.zeros((size,), dtype=torch.float32, device=p.device), 0])
+        c = self.chunks[-1]
+        v = c[0][c[1]:c[1] + p.numel()].view(p.shape)
+        c[1] += n
+        self.slots[id(p)] = (p, v)
+        if not self.armed:
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self.publish)
+            self.armed = True
+        return v
+
+    def publish(self):
+        self.armed = False
+        flush_wgrads()
+        if not self.slots:
+            return
+        if _GRAD_SINK[0] is not None:
+            _GRAD_SINK[0]([(c[0], c[1]) for c in self.chunks])
+        dst, src = [], []
+        for p, v in self.slots.values():
+            if p.grad is None:
+                p.grad = v
+            else:
+                dst.append(p.grad)
+                src.append(v)
+        if dst:
+            torch._foreach_add_(dst, src)
+        self.total_last = sum(c[1] for c in self.chunks)
+        self.chunks = []
+        self.slots = {}
 
 
+_GRADS = _GradArena()
+
+
+# --------------------------------------------------------------------------
+# raw conv launches
+# --------------------------------------------------------------------------
 def _tile_desc(B, H, W, Cin, ldx, Cout, k, stride, pad, dil, Ho, Wo, out_f32):
     return ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, 0, 0, int(out_f32), -1)
 
 
 def tile_supported(d):
     return bool(lib().ssa_conv2d_tile_supported(ctypes.byref(d)))
+
+
+def halo_supported(d):
+    return bool(lib().ssa_conv2d_halo_supported(ctypes.byref(d)))
 
 
 _STAT_REPLICAS = None
@@ -302,74 +406,128 @@ def stat_replicas():
     return _STAT_REPLICAS
 
 
-def halo_supported(d):
-    return bool(lib().ssa_conv2d_halo_supported(ctypes.byref(d)))
+def _conv_bytes(P_in, Cin, P_out, Cout, k, out_bytes=2):
+    return 2.0 * P_in * Cin + float(out_bytes) * P_out * Cout + 2.0 * Cout * Cin * k[0] * k[1]
 
 
-def _tile_conv(d, x, wfrag, bias, stats, halo=False):
-    """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs) or
-    conv_halo_gemm.hip (large-channel 3x3 / 1x1 convs), and their data gradients."""
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
-                    device=x.device)
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    fn = lib().ssa_conv2d_halo if halo else lib().ssa_conv2d_tile
-    check(fn(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()),
-          "ssa_conv2d_halo" if halo else "ssa_conv2d_tile")
-    if _PROFILE is not None:
-        e1.record()
-        _PROFILE.append(("halo" if halo else "tile", 101 if halo else 100,
-                         2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW, e0, e1,
-                         (d.KH, 1, d.Cin, d.Cout, d.Ho, d.Wo)))
+def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
+           cfg=-1, stats=None):
+    """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
+    B, H, W, Cin = geom_in
+    Ho, Wo = geom_out
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE, device=x.device)
+    d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, int(transposed),
+                 Kpad, int(out_f32), cfg)
+    # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
+    taps = k[0] * k[1] / (stride * stride if transposed else 1)
+    _note(2.0 * B * Ho * Wo * Cout * Cin * taps, _conv_bytes(B * H * W, Cin, B * Ho * Wo, Cout, k, 4 if out_f32 else 2))
+    check(lib().ssa_conv2d_igemm_stats(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _p(stats), _s()),
+          "ssa_conv2d_igemm")
     return y
 
 
-# --------------------------------------------------------------------------
-# Backward fusions (SSA_FUSE_BWD=1, off by default until they have run on hardware):
-#   * the backward sums of a BatchNorm+ReLU layer whose output feeds ONE conv are accumulated in
-#     the epilogue of that conv's data-gradient kernel (ssa_conv2d_tile_aux mode 2) instead of a
-#     bn_bwd_reduce pass over (x, dz);
-#   * the gradient of a residual block's identity branch is added in the epilogue of conv1's
-#     data-gradient kernel (mode 1) instead of autograd's separate add.
-# The modules say which tensors qualify (nn.conv_bn(private_input=, block=)); the links below
-# carry the hand-over between the autograd Functions involved.
-# --------------------------------------------------------------------------
-_FUSE_BWD = os.environ.get("SSA_FUSE_BWD", "0") == "1"
-
-
-class BnLink:
-    """BatchNorm+ReLU layer -> the conv that alone consumes its output."""
-    __slots__ = ("x", "ldx", "coef", "C", "sums", "dz_ptr")
-
-    def __init__(self):
-        self.x = self.coef = self.sums = self.dz_ptr = None
-        self.ldx = self.C = 0
-
-
-class ResLink:
-    """Residual block: conv1 (first consumer of the block input) <-> bn2 (adds the block input)."""
-    __slots__ = ("fused", "dres", "ld")
-
-    def __init__(self):
-        self.fused = False
-        self.dres = None
-        self.ld = 0
-
-
-# side channels from the HipBackend wrappers to the next Function.forward (popped there)
-_NEXT_BN_OUT_LINK = [None]      # BatchNormActFn: link to fill for the layer's consumer
-_NEXT_CONV_IN_LINK = [None]     # Conv2dFn: link of the BN layer whose output is this conv's private input
-_NEXT_CONV_RES_LINK = [None]    # Conv2dFn: residual block this conv is conv1 of
-_NEXT_BN_RES_LINK = [None]      # BatchNormActFn: residual block this layer is bn2 of
+def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0):
+    """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs; aux = fused epilogue tile of
+    the data gradient, see ssa_conv2d_tile_aux) or conv_halo_gemm.hip (large-channel 3x3 / 1x1)."""
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
+                    device=x.device)
+    P = d.B * d.Ho * d.Wo
+    _note(2.0 * P * d.Cout * d.Cin * d.KH * d.KW,
+          _conv_bytes(P, d.Cin, P, d.Cout, (d.KH, d.KW), 4 if d.out_f32 else 2) + (2.0 * P * d.Cout if mode else 0.0))
+    L = lib()
+    if mode:
+        check(L.ssa_conv2d_tile_aux(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _p(aux), ldaux,
+                                    _p(coef), mode, _s()), "ssa_conv2d_tile_aux")
+    elif halo:
+        check(L.ssa_conv2d_halo(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()), "ssa_conv2d_halo")
+    else:
+        check(L.ssa_conv2d_tile(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()), "ssa_conv2d_tile")
+    return y
 
 
 def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
-    """conv_tile_aux.hip: the tile data gradient with the fused epilogue tile (see header)."""
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=ACT_DTYPE, device=x.device)
-    check(lib().ssa_conv2d_tile_aux(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats), _p(aux), ldaux,
-                                    _p(coef), mode, _s()), "ssa_conv2d_tile_aux")
-    return y
+    return _tile_conv(d, x, wfrag, None, stats, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
+
+
+# conv output data_ptr -> (BN partial sums [nrep][2][C], nrep): handed from the conv epilogue to
+# the BatchNorm that consumes that output next
+_PENDING_STATS = {}
+_NO_IGEMM_STATS = bool(os.environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
+
+
+def _conv_fwd(x, ldx, weight, b, stride, pad, dil, out_f32, want_stats):
+    """One forward convolution launch (possibly queued in the open group bracket).
+    x: dense-pixel [B,H,W,Cin] bf16.  Returns (y, stats or None)."""
+    B, H, W, Cin = x.shape
+    Cout, Cin_real, KH, KW = weight.shape
+    assert Cin >= Cin_real and Cin % 8 == 0, (Cin, Cin_real)
+    Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    if not out_f32:
+        assert Cout % 8 == 0, "bf16 conv outputs need Cout % 8 == 0"
+    td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, out_f32)
+    al = x.data_ptr() % 16 == 0
+    use_tile = al and tile_supported(td)
+    use_halo = (not use_tile) and al and halo_supported(td)
+    stats = None
+    if want_stats and not out_f32 and not (_NO_IGEMM_STATS and not (use_tile or use_halo)):
+        stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
+    if use_tile or use_halo:
+        wp, _ = _packed_filter(weight, 2, Cin, 0)
+        y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
+    else:
+        wp, Kpad = _packed_filter(weight, 0, Cin, 0)
+        y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
+                   out_f32, stats=stats)
+    if stats is not None:
+        _PENDING_STATS[y.data_ptr()] = (stats, stat_replicas())
+    return y, stats
+
+
+def _dgrad_desc(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw):
+    B, H, W, Cin = x_shape
+    Cout, Cin_real, KH, KW = weight.shape
+    Ho, Wo = out_hw
+    return _tile_desc(B, Ho, Wo, cout_pad, lddy, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W, False)
+
+
+def _conv_dgrad(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw, aux=None, ldaux=0, coef=None,
+                mode=0, stats=None):
+    """Data gradient of a forward conv (possibly queued).  mode 1/2: fused epilogue tile
+    (only where dgrad_tile_ok())."""
+    B, H, W, Cin = x_shape
+    Cout, Cin_real, KH, KW = weight.shape
+    Ho, Wo = out_hw
+    assert Cin == Cin_real
+    td = _dgrad_desc(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw)
+    al = dyb.data_ptr() % 16 == 0
+    use_tile = al and tile_supported(td)
+    use_halo = (not use_tile) and al and halo_supported(td)
+    if mode:
+        assert use_tile
+    if use_tile or use_halo:
+        wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
+        return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
+    wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
+    return _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
+                  dil * (KH - 1) - pad, dil, stride > 1, False)
+
+
+def dgrad_tile_ok(x_shape, weight, stride, pad, dil, out_hw):
+    """True if the data gradient of this conv runs on the halo-tile kernel (whose epilogue can
+    fold in the residual gradient / the BatchNorm backward sums)."""
+    Cout = weight.shape[0]
+    cp = _roundup(Cout, 8)
+    td = _dgrad_desc(x_shape, weight, None, cp, cp, stride, pad, dil, out_hw)
+    return x_shape[3] == weight.shape[1] and cp == Cout and tile_supported(td)
+
+
+def _pack_matrix(src, R, C, ld, transpose, rows_out, Kpad):
+    out = torch.empty((rows_out, Kpad), dtype=ACT_DTYPE, device=src.device)
+    dt = 0 if src.dtype == ACT_DTYPE else 1
+    check(lib().ssa_pack_matrix(_p(src), dt, R, C, ld, int(transpose), _p(out), rows_out, Kpad, _s()),
+          "ssa_pack_matrix")
+    return out
 
 
 def _add_bf16(a, b):
@@ -380,102 +538,106 @@ def _add_bf16(a, b):
     return out
 
 
-# (data_ptr of a conv output, its BN partial sums [nrep][2][C], nrep): handed from the conv
-# epilogue to the BatchNorm that consumes that output next (HipBackend.conv_bn_act)
-_PENDING_STATS = [None]
-_NO_IGEMM_STATS = bool(os.environ.get("SSA_NO_IGEMM_STATS"))   # debugging switch
-
-
-def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, deferrable=False):
-    """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)].
-    deferrable: the result is a parameter gradient that nobody reads before the end of backward
-    (Conv2dFn.backward) -- its reduce may be batched with the others (SSA_DEFER_WGRAD_REDUCE)."""
-    B, H, W, Cin = geom_in
-    Ho, Wo = geom_out
-    d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, 0, 0, 0, -1)
-    nsplit = ctypes.c_int(0)
-    ws = ctypes.c_size_t(0)
-    L = lib()
-    # large-channel head convs: persistent 8-wave kernel (conv_wgrad_head.hip); everything else:
-    # the K-pipelined kernel
-    head = (x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and
-            L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0)
-    if not head:
-        check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
-              "ssa_conv2d_wgrad_plan")
-    partial = torch.empty((ws.value // 4,), dtype=torch.float32, device=x.device)
-    if _PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    fn = L.ssa_conv2d_wgrad_head if head else L.ssa_conv2d_wgrad
-    check(fn(ctypes.byref(d), _p(x), _p(dy), lddy, cout_pad, nsplit.value, _p(partial), _s()),
-          "ssa_conv2d_wgrad_head" if head else "ssa_conv2d_wgrad")
-    if _PROFILE is not None:
-        e1.record()
-        _PROFILE.append(("wgrad_head" if head else "wgrad", 102 if head else -1,
-                         2.0 * B * Ho * Wo * Cout * Cin_real * k[0] * k[1], e0, e1,
-                         (k[0], stride, Cin, Cout, Ho, Wo)))
-    dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
-    if deferrable and _DEFER_WGRAD_REDUCE and _defer_allowed():
-        _defer_reduce(partial, dw, WgradReduceJob(partial.data_ptr(), dw.data_ptr(), nsplit.value, cout_pad, Cout,
-                                                  Cin, Cin_real, k[0], k[1], 0))
-        return dw
-    check(L.ssa_conv2d_wgrad_reduce(_p(partial), nsplit.value, cout_pad, Cout, Cin, Cin_real, k[0], k[1],
-                                    _p(dw), _s()), "ssa_conv2d_wgrad_reduce")
-    return dw
-
-
 # --------------------------------------------------------------------------
-# Deferred weight-gradient reduces (SSA_DEFER_WGRAD_REDUCE=1, off by default until it has run on
-# hardware): every conv's backward ends in a ~6 us reduce of its split-K partials, 641 per
-# training step.  Nobody reads a weight gradient before backward has finished (autograd only
-# stores the tensor), so the reduces are collected and issued at the end of backward in ~9
-# launches (ssa_conv2d_wgrad_reduce_batched).  Not under torch.distributed: DDP's hooks read
-# the gradients while backward is still running.
+# weight gradients: deferred, grouped, accumulated into the gradient arena
 # --------------------------------------------------------------------------
-_DEFER_WGRAD_REDUCE = os.environ.get("SSA_DEFER_WGRAD_REDUCE", "0") == "1"
-_PENDING_REDUCES = []
-_REDUCE_CALLBACK_QUEUED = [False]
+_WGRAD_TILE = os.environ.get("SSA_WGRAD_TILE", "1") != "0"       # halo-staged kernel for the trunk 3x3 convs
+_WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "16"))       # 128-pixel stages per workgroup in grouped launches
+_WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "96"))  # queued layers that trigger a flush
+_WGRAD_Q = []
 
 
-def _defer_allowed():
-    from .parallel import sync_world
-    return not sync_world()
+class _WJob:
+    __slots__ = ("x", "ldx", "geom_in", "dy", "lddy", "cout_pad", "geom_out", "k", "stride", "pad", "dil",
+                 "Cout", "Cin_real", "target", "accumulate", "kind", "nsplit", "ws", "desc")
 
 
-def _defer_reduce(partial, dw, job):
-    _PENDING_REDUCES.append((partial, dw, job))
-    if not _REDUCE_CALLBACK_QUEUED[0]:
-        from torch.autograd import Variable
-        Variable._execution_engine.queue_callback(flush_wgrad_reduces)
-        _REDUCE_CALLBACK_QUEUED[0] = True
+def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, target, accumulate):
+    j = _WJob()
+    j.x, j.ldx, j.geom_in, j.dy, j.lddy, j.cout_pad, j.geom_out = x, ldx, geom_in, dy, lddy, cout_pad, geom_out
+    j.k, j.stride, j.pad, j.dil, j.Cout, j.Cin_real, j.target, j.accumulate = k, stride, pad, dil, Cout, Cin_real, target, accumulate
+    return j
 
 
-def flush_wgrad_reduces(side_streams=()):
-    """Issue the deferred reduces on the current stream.  Runs as an end-of-backward callback;
-    anything that reads weight gradients from another end-of-backward callback (the shadow
-    gradient merge of MscaleOCR) calls it first -- a second call finds nothing to do."""
-    _REDUCE_CALLBACK_QUEUED[0] = False
-    if not _PENDING_REDUCES:
+def _run_wgrad_jobs(jobs, strip):
+    """Plan every job, launch all weight-gradient kernels in one bracket, all reduces in a second."""
+    if not jobs:
         return
-    jobs = list(_PENDING_REDUCES)
-    del _PENDING_REDUCES[:]
-    on_gpu = jobs[0][0].is_cuda
-    if on_gpu:
-        main = torch.cuda.current_stream()
-        for st in side_streams or _all_side_streams():
-            main.wait_stream(st)             # partials of the other scale pass were produced there
-    arr = (WgradReduceJob * len(jobs))(*[j for _, _, j in jobs])
-    check(lib().ssa_conv2d_wgrad_reduce_batched(arr, len(jobs), _s()), "ssa_conv2d_wgrad_reduce_batched")
-    if on_gpu:
-        for partial, dw, _ in jobs:          # allocated on the producing stream, used on this one
-            partial.record_stream(main)
-            dw.record_stream(main)
+    L = lib()
+    dev = jobs[0].x.device
+    by_target = {}
+    for j in jobs:
+        B, H, W, Cin = j.geom_in
+        Ho, Wo = j.geom_out
+        d = ConvDesc(B, H, W, Cin, j.ldx, Ho, Wo, j.Cout, j.Cout, j.k[0], j.k[1], j.stride, j.pad, j.dil, 0, 0, 0, strip)
+        nsplit, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        al = j.x.data_ptr() % 16 == 0 and j.dy.data_ptr() % 16 == 0
+        d.cfg = -1
+        if al and L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
+            j.kind = "head"
+        else:
+            d.cfg = strip
+            if _WGRAD_TILE and al and j.lddy % 8 == 0 and \
+                    L.ssa_conv2d_wgrad_tile_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
+                j.kind = "tile"
+            else:
+                check(L.ssa_conv2d_wgrad_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
+                      "ssa_conv2d_wgrad_plan")
+                j.kind = "tr"
+        j.nsplit, j.ws, j.desc = nsplit.value, ws.value, d
+        by_target.setdefault(j.target.data_ptr(), []).append(j)
+    # one partial buffer per parameter: the passes' splits lie behind one another, ONE reduce sums them
+    plan = []
+    for js in by_target.values():
+        partial = torch.empty((sum(j.ws for j in js) // 4,), dtype=torch.float32, device=dev)
+        plan.append((js, partial))
+    fns = {"head": (L.ssa_conv2d_wgrad_head, "ssa_conv2d_wgrad_head"), "tile": (L.ssa_conv2d_wgrad_tile, "ssa_conv2d_wgrad_tile"),
+           "tr": (L.ssa_conv2d_wgrad, "ssa_conv2d_wgrad")}
+    with group():
+        for js, partial in plan:
+            off = 0
+            for j in js:
+                B, H, W, Cin = j.geom_in
+                Ho, Wo = j.geom_out
+                _note(2.0 * B * Ho * Wo * j.Cout * j.Cin_real * j.k[0] * j.k[1],
+                      2.0 * B * (H * W * Cin + Ho * Wo * j.Cout) + 4.0 * j.Cout * Cin * j.k[0] * j.k[1])
+                fn, name = fns[j.kind]
+                check(fn(ctypes.byref(j.desc), _p(j.x), _p(j.dy), j.lddy, j.cout_pad, j.nsplit,
+                         ctypes.c_void_p(partial.data_ptr() + off), _s()), name)
+                off += j.ws
+    with group():
+        for js, partial in plan:
+            j0 = js[0]
+            check(L.ssa_conv2d_wgrad_reduce(_p(partial), sum(j.nsplit for j in js), j0.cout_pad, j0.Cout, j0.geom_in[3],
+                                            j0.Cin_real, j0.k[0], j0.k[1], _p(j0.target), int(j0.accumulate), _s()),
+                  "ssa_conv2d_wgrad_reduce")
 
 
-def _all_side_streams():
-    from . import ops
-    return ops.backend().side_streams() if hasattr(ops.backend(), "side_streams") else []
+def flush_wgrads():
+    """Issue the queued weight gradients (grouped) -- at the end of backward, when enough layers
+    are queued, and before anything reads a gradient slice."""
+    if not _WGRAD_Q:
+        return
+    jobs = list(_WGRAD_Q)
+    del _WGRAD_Q[:]
+    _run_wgrad_jobs(jobs, _WGRAD_STRIP)
+
+
+def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, weight=None):
+    """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)].
+    weight = an nn.Parameter: queued, accumulated into its gradient-arena slice, returns None
+    (the gradient is published at the end of backward).  Otherwise computed now and returned."""
+    if weight is not None and _is_param(weight):
+        tgt = _GRADS.slot(weight)
+        _WGRAD_Q.append(_wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real,
+                                   tgt, True))
+        if len(_WGRAD_Q) >= _WGRAD_FLUSH_AT:
+            flush_wgrads()
+        return None
+    dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
+    _run_wgrad_jobs([_wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real,
+                                dw, False)], -1)
+    return dw
 
 
 def _grad_as_bf16(dy, Cout):
@@ -495,106 +657,86 @@ def _grad_as_bf16(dy, Cout):
     return out, cout_pad, cout_pad
 
 
-class Conv2dFn(torch.autograd.Function):
-    """nn.Conv2d forward/backward (groups=1).  x NHWC bf16, weight OIHW fp32."""
+def _bias_grad(dyb, lddy, cout_pad, Cout):
+    B, Ho, Wo, _ = dyb.shape
+    out = torch.empty((cout_pad,), dtype=torch.float32, device=dyb.device)
+    scratch = torch.empty((2 * cout_pad,), dtype=torch.float64, device=dyb.device)
+    check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()), "ssa_colsum_bf16")
+    return out[:Cout]
+
+
+class ConvGroupFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward (groups=1) for N independent problems: one grouped launch per
+    kernel instantiation.  spec[i] = (stride, pad, dil, out_f32, want_stats); tensors =
+    (x_0, w_0, b_0, x_1, ...), x NHWC bf16, weight OIHW fp32, bias fp32 or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil, out_f32, want_stats=False):
-        x, ldx = _pixels(x)
-        B, H, W, Cin = x.shape
-        Cout, Cin_real, KH, KW = weight.shape
-        assert Cin >= Cin_real and Cin % 8 == 0, (Cin, Cin_real)
-        Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
-        Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
-        b = None
-        if bias is not None:
-            b = bias.detach()
-            if b.dtype != torch.float32:
-                b = b.float()
-        if not out_f32:
-            assert Cout % 8 == 0, "bf16 conv outputs need Cout % 8 == 0"
-        td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, out_f32)
-        use_tile = x.data_ptr() % 16 == 0 and tile_supported(td)
-        use_halo = (not use_tile) and x.data_ptr() % 16 == 0 and halo_supported(td)
-        if use_tile or use_halo:
-            wp, _ = _packed_filter(weight, 2, Cin, 0)
-            stats = None
-            if want_stats and not out_f32:
-                stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-            y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
-            if stats is not None:
-                _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
-        else:
-            wp, Kpad = _packed_filter(weight, 0, Cin, 0)
-            stats = None
-            if want_stats and not out_f32 and not _NO_IGEMM_STATS:
-                stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-            y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
-                       out_f32, stats=stats)
-            if stats is not None:
-                _PENDING_STATS[0] = (y.data_ptr(), stats, stat_replicas())
-        ctx.save_for_backward(x, weight)
-        ctx.meta = (ldx, stride, pad, dil, bias is not None, (Ho, Wo))
-        ctx.bn_link = ctx.res_link = None
-        if _FUSE_BWD:
-            ctx.bn_link, _NEXT_CONV_IN_LINK[0] = _NEXT_CONV_IN_LINK[0], None
-            ctx.res_link, _NEXT_CONV_RES_LINK[0] = _NEXT_CONV_RES_LINK[0], None
-            if ctx.res_link is not None:
-                # bn2 hands the identity branch's gradient over only if this conv's data gradient
-                # will run on the tile kernel (decided here, bn2's forward comes later)
-                cp = _roundup(Cout, 8)
-                tdg = _tile_desc(B, Ho, Wo, cp, cp, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W, False)
-                ctx.res_link.fused = bool(Cin == Cin_real and tile_supported(tdg))
-        return y
+    def forward(ctx, spec, *tensors):
+        n = len(spec)
+        xs, lds, ws, bs = [], [], [], []
+        for i in range(n):
+            x, ldx = _pixels(tensors[3 * i])
+            xs.append(x)
+            lds.append(ldx)
+            ws.append(tensors[3 * i + 1])
+            b = tensors[3 * i + 2]
+            if b is not None:
+                b = b.detach()
+                if b.dtype != torch.float32:
+                    b = b.float()
+            bs.append(b)
+        ys = []
+        with group():
+            for i in range(n):
+                stride, pad, dil, out_f32, want_stats = spec[i]
+                y, _ = _conv_fwd(xs[i], lds[i], ws[i], bs[i], stride, pad, dil, out_f32, want_stats)
+                ys.append(y)
+        ctx.save_for_backward(*(xs + ws))
+        ctx.meta = (spec, lds, [b is not None for b in bs], [tuple(y.shape[1:3]) for y in ys])
+        return tuple(ys)
 
     @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        ldx, stride, pad, dil, has_bias, (Ho, Wo) = ctx.meta
-        B, H, W, Cin = x.shape
-        Cout, Cin_real, KH, KW = weight.shape
-        dyb, lddy, cout_pad = _grad_as_bf16(dy, Cout)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            assert Cin == Cin_real
-            td = _tile_desc(B, Ho, Wo, cout_pad, lddy, Cin, (KH, KW), stride, dil * (KH - 1) - pad, dil, H, W,
-                            False)
-            use_tile = dyb.data_ptr() % 16 == 0 and tile_supported(td)
-            use_halo = (not use_tile) and dyb.data_ptr() % 16 == 0 and halo_supported(td)
-            bn_link, res_link = ctx.bn_link, ctx.res_link
-            dres = None
-            if res_link is not None:
-                dres, res_link.dres = res_link.dres, None
-            if use_tile or use_halo:
-                wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
-                if use_tile and bn_link is not None and bn_link.x is not None and dres is None and \
-                        tuple(bn_link.x.shape) == (B, H, W, Cin) and bn_link.x.data_ptr() % 16 == 0:
-                    sums = _ARENA.take(stat_replicas() * 2 * Cin, x.device)
-                    dx = _tile_conv_aux(td, dyb, wpt, sums, bn_link.x, bn_link.ldx, bn_link.coef, 2)
-                    bn_link.sums, bn_link.dz_ptr = sums, dx.data_ptr()
-                elif use_tile and dres is not None and dres.data_ptr() % 16 == 0:
-                    dx = _tile_conv_aux(td, dyb, wpt, None, dres, res_link.ld, None, 1)
-                    dres = None
-                else:
-                    dx = _tile_conv(td, dyb, wpt, None, None, halo=use_halo)
-            else:
-                wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
-                dx = _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
-                            dil * (KH - 1) - pad, dil, stride > 1, False)
-            if dres is not None:          # handed over but not fused after all: add it here
-                dx = _add_bf16(dx, dres)
-        if ctx.needs_input_grad[1]:
-            dw = _wgrad(x, ldx, (B, H, W, Cin), dyb, lddy, cout_pad, (Ho, Wo), (KH, KW), stride, pad, dil,
-                        Cout, Cin_real, deferrable=weight.dtype == torch.float32)
-            if dw.dtype != weight.dtype:
-                dw = dw.to(weight.dtype)
-        if has_bias and ctx.needs_input_grad[2]:
-            out = torch.empty((cout_pad,), dtype=torch.float32, device=x.device)
-            scratch = torch.empty((2 * cout_pad,), dtype=torch.float64, device=x.device)
-            check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()),
-                  "ssa_colsum_bf16")
-            db = out[:Cout]
-        return dx, dw, db, None, None, None, None, None
+    def backward(ctx, *dys):
+        spec, lds, has_bias, out_hw = ctx.meta
+        n = len(spec)
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        prep = [None] * n
+        for i in range(n):
+            if dys[i] is not None:
+                prep[i] = _grad_as_bf16(dys[i], ws[i].shape[0])
+        dxs = [None] * n
+        with group():
+            for i in range(n):
+                if prep[i] is None or not ctx.needs_input_grad[1 + 3 * i]:
+                    continue
+                stride, pad, dil = spec[i][:3]
+                dyb, lddy, cout_pad = prep[i]
+                dxs[i] = _conv_dgrad(tuple(xs[i].shape), ws[i], dyb, lddy, cout_pad, stride, pad, dil, out_hw[i])
+        grads = [None]
+        for i in range(n):
+            dw = db = None
+            if prep[i] is not None:
+                stride, pad, dil = spec[i][:3]
+                dyb, lddy, cout_pad = prep[i]
+                x, w = xs[i], ws[i]
+                Cout, Cin_real, KH, KW = w.shape
+                if ctx.needs_input_grad[2 + 3 * i]:
+                    dw = _wgrad(x, lds[i], tuple(x.shape), dyb, lddy, cout_pad, out_hw[i], (KH, KW), stride, pad, dil,
+                                Cout, Cin_real, weight=w)
+                    if dw is not None and dw.dtype != w.dtype:
+                        dw = dw.to(w.dtype)
+                if has_bias[i] and ctx.needs_input_grad[3 + 3 * i]:
+                    db = _bias_grad(dyb, lddy, cout_pad, Cout)
+            grads += [dxs[i], dw, db]
+        return tuple(grads)
+
+
+class Conv2dFn:
+    """Single-problem form of ConvGroupFn (kept for the op-level tests and the heads)."""
+
+    @staticmethod
+    def apply(x, weight, bias, stride, pad, dil, out_f32, want_stats=False):
+        return ConvGroupFn.apply(((stride, pad, dil, bool(out_f32), bool(want_stats)),), x, weight, bias)[0]
 
 
 # --------------------------------------------------------------------------
@@ -605,143 +747,441 @@ def _sync_world(sync):
     return sync_world(sync)
 
 
-class BatchNormActFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, gamma, beta, residual, post, running_mean, running_var, nbt, momentum, eps, training,
-                relu, sync, pass_stats=None):
-        L = lib()
-        out_link = res_link = None
-        if _FUSE_BWD:
-            out_link, _NEXT_BN_OUT_LINK[0] = _NEXT_BN_OUT_LINK[0], None
-            res_link, _NEXT_BN_RES_LINK[0] = _NEXT_BN_RES_LINK[0], None
-        x, ldx = _pixels(x)
-        B, H, W, C = x.shape
-        P = B * H * W
-        dev = x.device
-        g = gamma.detach().float() if gamma is not None else None
-        bta = beta.detach().float() if beta is not None else None
-        coef = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
-        world = _sync_world(sync) if training else 0
-        count = float(P)
-        res = ldr = None
-        if residual is not None:
-            res, ldr = _pixels(residual)
-        z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
-        pst = post.float().contiguous() if post is not None else None
-        if training:
-            pend, _PENDING_STATS[0] = _PENDING_STATS[0], None
-            if pend is not None and pend[0] == x.data_ptr() and pend[1].numel() >= pend[2] * 2 * C:
-                sums, nrep = pend[1], pend[2]          # accumulated by the producing conv's epilogue
-            else:
-                sums, nrep = _ARENA.take(2 * C, dev), 1
-                check(L.ssa_bn_stats(_p(x), P, C, ldx, _p(sums), 0, _s()), "ssa_bn_stats")
-            if world:
-                from .parallel import allreduce_bn_sums
-                count = allreduce_bn_sums(sums, P)
-            check(L.ssa_bn_apply_train(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(sums), nrep, count, _p(g),
-                                       _p(bta), _p(running_mean), _p(running_var), _p(nbt), float(momentum),
-                                       float(eps), _p(coef), _p(pass_stats), int(relu), _p(pst), H * W, _s()),
-                  "ssa_bn_apply_train")
+def _allreduce_sums(sums_list):
+    """SyncBN exchange for every problem of a level: ONE all-reduce when the partial sums lie
+    behind one another in the statistics arena (they do when one Function took them)."""
+    from .parallel import allreduce_bn_sums
+    spans = []
+    for s in sums_list:
+        if spans and spans[-1][0].data_ptr() + spans[-1][1] * 8 == s.data_ptr() and \
+                spans[-1][0].untyped_storage().data_ptr() == s.untyped_storage().data_ptr():
+            spans[-1][1] += s.numel()
         else:
-            check(L.ssa_bn_finalize(None, 1.0, C, _p(g), _p(bta), _p(running_mean), _p(running_var),
-                                    float(momentum), float(eps), 1, _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                                    _p(coef[3]), _s()), "ssa_bn_finalize")
-            check(L.ssa_bn_apply(_p(x), ldx, _p(res), ldr or 0, _p(z), C, P, C, _p(coef[0]), _p(coef[1]),
-                                 int(relu), _p(pst), H * W, _s()), "ssa_bn_apply")
+            spans.append([s, s.numel()])
+    for s, n in spans:
+        flat = s if n == s.numel() else torch.as_strided(s, (n,), (1,))
+        allreduce_bn_sums(flat)
+
+
+class BnMeta:
+    """Non-tensor description of one BatchNorm call (built by the operator surface)."""
+    __slots__ = ("momentum", "eps", "training", "relu", "sync", "pass_stats", "running_mean", "running_var", "nbt")
+
+    def __init__(self, momentum, eps, training, relu, sync, pass_stats, running_mean, running_var, nbt=None):
+        # training: running_mean/var/nbt given = updated by the normalisation kernel itself (one pass
+        # per layer and step only); pass_stats given = deferred to ssa_bn_update_running_batched
+        self.momentum, self.eps, self.training, self.relu, self.sync = momentum, eps, training, relu, sync
+        self.pass_stats, self.running_mean, self.running_var, self.nbt = pass_stats, running_mean, running_var, nbt
+
+
+def _bn_take_stats(jobs):
+    """Per job (x, ldx): the batch sums [nrep][2][C] -- from the producing conv's epilogue, or by a
+    (grouped) statistics pass.  Returns [(sums, nrep)]."""
+    out = [None] * len(jobs)
+    todo = []
+    for i, (x, ldx) in enumerate(jobs):
+        C = x.shape[3]
+        pend = _PENDING_STATS.pop(x.data_ptr(), None)
+        if pend is not None and pend[0].numel() >= pend[1] * 2 * C:
+            out[i] = pend
+        else:
+            out[i] = (_ARENA.take(2 * C, x.device), 1)
+            todo.append(i)
+    if todo:
+        with group():
+            for i in todo:
+                x, ldx = jobs[i]
+                B, H, W, C = x.shape
+                check(lib().ssa_bn_stats(_p(x), B * H * W, C, ldx, _p(out[i][0]), 0, _s()), "ssa_bn_stats")
+    return out
+
+
+def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts):
+    """Training-mode normalisation of N problems: returns (zs, coefs, counts, worlds)."""
+    L = lib()
+    n = len(xs)
+    stats = _bn_take_stats(list(zip(xs, ldxs)))
+    worlds = [_sync_world(m.sync) for m in metas]
+    counts = [float(x.shape[0] * x.shape[1] * x.shape[2]) for x in xs]
+    sync_ids = [i for i in range(n) if worlds[i]]
+    if sync_ids:
+        _allreduce_sums([stats[i][0] for i in sync_ids])
+        for i in sync_ids:
+            counts[i] *= worlds[i]
+    zs, coefs = [], []
+    with group():
+        for i in range(n):
+            x, m = xs[i], metas[i]
+            B, H, W, C = x.shape
+            P = B * H * W
+            coef = torch.empty((4, C), dtype=torch.float32, device=x.device)  # scale, shift, mean, invstd
+            z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=x.device)
+            res, ldr = ress[i] if ress[i] is not None else (None, 0)
+            _note(0.0, 2.0 * P * C * (2 + (1 if res is not None else 0)))
+            check(L.ssa_bn_apply_train(_p(x), ldxs[i], _p(res), ldr, _p(z), C, P, C, _p(stats[i][0]), stats[i][1],
+                                       counts[i], _p(gammas[i]), _p(betas[i]), _p(m.running_mean), _p(m.running_var),
+                                       _p(m.nbt), float(m.momentum),
+                                       float(m.eps), _p(coef), _p(m.pass_stats), int(m.relu), _p(posts[i]), H * W, _s()),
+                  "ssa_bn_apply_train")
+            zs.append(z)
+            coefs.append(coef)
+    return zs, coefs, counts, worlds
+
+
+def _bn_bwd(jobs):
+    """Backward of N BatchNorm(+ReLU/residual/mask) problems.  job: dict with x, ldx, dz, lddz, z,
+    coef, g (gamma fp32 or None), gamma_param, beta_param, relu, pst, training, world, count,
+    has_res, mask_from_x, sums (already accumulated by a conv epilogue, or None).
+    Returns per job (dx, dres, dgamma, dbeta)."""
+    L = lib()
+    nrep_t = stat_replicas()
+    todo = []
+    for j in jobs:
+        C = j["x"].shape[3]
+        j["nrep"] = nrep_t if j["training"] else 1
+        if j.get("sums") is None:
+            j["sums"] = _ARENA.take(j["nrep"] * 2 * C, j["x"].device)
+            todo.append(j)
+    if todo:
+        with group():
+            for j in todo:
+                x = j["x"]
+                B, H, W, C = x.shape
+                coef = j["coef"]
+                msc, msh = (coef[0], coef[1]) if j["mask_from_x"] else (None, None)
+                _note(0.0, 4.0 * B * H * W * C)
+                check(L.ssa_bn_bwd_reduce(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, B * H * W, C, _p(coef[2]),
+                                          _p(coef[3]), int(j["relu"]), _p(j["pst"]), H * W, _p(j["sums"]), j["nrep"], 0,
+                                          _p(msc), _p(msh), _s()), "ssa_bn_bwd_reduce")
+    sync = [j for j in jobs if j["training"] and j["world"]]
+    if sync:
+        _allreduce_sums([j["sums"] for j in sync])
+    out = []
+    tails = []
+    with group():
+        for j in jobs:
+            x = j["x"]
+            B, H, W, C = x.shape
+            P = B * H * W
+            dev = x.device
+            coef = j["coef"]
+            msc, msh = (coef[0], coef[1]) if j["mask_from_x"] else (None, None)
+            g = j["g"]
+            pscale = 1.0 / j["world"] if (j["training"] and j["world"]) else 1.0
+            use_sums = j["sums"]
+            pg_g = pg_b = None
+            ret_g = ret_b = None
+            accumulate = 0
+            if g is not None:
+                gp, bp = j["gamma_param"], j["beta_param"]
+                if gp is not None and _is_param(gp) and bp is not None and _is_param(bp):
+                    pg_g, pg_b = _GRADS.slot(gp), _GRADS.slot(bp)
+                    accumulate = 1
+                else:
+                    pg = torch.empty((2, C), dtype=torch.float32, device=dev)
+                    pg_g, pg_b = pg[0], pg[1]
+                    ret_g, ret_b = pg[0], pg[1]
+            fuse_pg = pg_g is not None and j["training"]
+            if not j["training"]:
+                # eval-mode BN: statistics are constants -> no mean/projection terms, but the
+                # parameter gradients still come from the reduced sums
+                if pg_g is not None:
+                    if accumulate:
+                        tmp = torch.empty((2, C), dtype=torch.float32, device=dev)
+                        tails.append((j["sums"], C, tmp, pg_g, pg_b))
+                    else:
+                        tails.append((j["sums"], C, None, pg_g, pg_b))
+                use_sums = _ARENA.take(2 * C, dev)
+            dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
+            dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if j["has_res"] else None
+            _note(0.0, 2.0 * P * C * (3 + (1 if dres is not None else 0)))
+            check(L.ssa_bn_bwd_apply(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, _p(dx), C, _p(dres), C, P, C,
+                                     _p(g), _p(coef[2]), _p(coef[3]), _p(use_sums), j["nrep"], j["count"], int(j["relu"]),
+                                     _p(j["pst"]), H * W, _p(pg_g) if fuse_pg else None, _p(pg_b) if fuse_pg else None,
+                                     pscale, _p(msc), _p(msh), accumulate if fuse_pg else 0, _s()), "ssa_bn_bwd_apply")
+            out.append((dx, dres, ret_g, ret_b))
+    for sums, C, tmp, pg_g, pg_b in tails:
+        if tmp is None:
+            check(L.ssa_bn_param_grads(_p(sums), C, _p(pg_g), _p(pg_b), _s()), "ssa_bn_param_grads")
+        else:
+            check(L.ssa_bn_param_grads(_p(sums), C, _p(tmp[0]), _p(tmp[1]), _s()), "ssa_bn_param_grads")
+            pg_g.add_(tmp[0])
+            pg_b.add_(tmp[1])
+    return out
+
+
+def _dz_bf16(dz, C):
+    dz, lddz = _pixels(dz if dz.dtype == ACT_DTYPE else dz.to(ACT_DTYPE))
+    if lddz % 8 or dz.data_ptr() % 16:
+        dz, lddz = dz.contiguous(), C
+    return dz, lddz
+
+
+class BnActGroupFn(torch.autograd.Function):
+    """z = post * act(bn(x) + residual) for N independent problems.
+    metas[i]: BnMeta; tensors = (x_0, gamma_0, beta_0, residual_0, post_0, x_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, metas, *tensors):
+        L = lib()
+        n = len(metas)
+        xs, ldxs, gs, bs, ress, posts = [], [], [], [], [], []
+        for i in range(n):
+            x, gamma, beta, residual, post = tensors[5 * i:5 * i + 5]
+            x, ldx = _pixels(x)
+            xs.append(x)
+            ldxs.append(ldx)
+            gs.append(gamma.detach().float() if gamma is not None else None)
+            bs.append(beta.detach().float() if beta is not None else None)
+            ress.append(_pixels(residual) if residual is not None else None)
+            posts.append(post.float().contiguous() if post is not None else None)
+        training = [m.training for m in metas]
+        assert all(training) or not any(training), "one grouped BatchNorm call mixes training and eval layers"
+        if training[0]:
+            zs, coefs, counts, worlds = _bn_train_fwd(xs, ldxs, metas, gs, bs, ress, posts)
+        else:
+            zs, coefs, counts, worlds = [], [], [], [0] * n
+            for i in range(n):
+                C = xs[i].shape[3]
+                coef = torch.empty((4, C), dtype=torch.float32, device=xs[i].device)
+                check(L.ssa_bn_finalize(None, 1.0, C, _p(gs[i]), _p(bs[i]), _p(metas[i].running_mean),
+                                        _p(metas[i].running_var), float(metas[i].momentum), float(metas[i].eps), 1,
+                                        _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _s()), "ssa_bn_finalize")
+                coefs.append(coef)
+                counts.append(float(xs[i].shape[0] * xs[i].shape[1] * xs[i].shape[2]))
+            with group():
+                for i in range(n):
+                    x = xs[i]
+                    B, H, W, C = x.shape
+                    z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=x.device)
+                    res, ldr = ress[i] if ress[i] is not None else (None, 0)
+                    check(L.ssa_bn_apply(_p(x), ldxs[i], _p(res), ldr, _p(z), C, B * H * W, C, _p(coefs[i][0]),
+                                         _p(coefs[i][1]), int(metas[i].relu), _p(posts[i]), H * W, _s()), "ssa_bn_apply")
+                    zs.append(z)
         # BN + ReLU without residual / mask: the backward recomputes the ReLU mask from x with the
         # forward's own scale/shift, so z is neither kept for nor read by the backward
-        mask_from_x = relu and residual is None and pst is None
-        ctx.save_for_backward(x, z if (relu and not mask_from_x) else None, g, coef, pst)
-        ctx.meta = (ldx, relu, training, world, residual is not None, count, mask_from_x)
-        ctx.out_link = ctx.res_link = None
-        if out_link is not None and training and mask_from_x:
-            out_link.x, out_link.ldx, out_link.coef, out_link.C = x, ldx, coef, C
-            ctx.out_link = out_link
-        if res_link is not None and residual is not None and res_link.fused:
-            ctx.res_link = res_link
-        return z
+        saved, info = [], []
+        for i in range(n):
+            relu = metas[i].relu
+            mask_from_x = relu and ress[i] is None and posts[i] is None
+            saved += [xs[i], zs[i] if (relu and not mask_from_x) else None, gs[i], coefs[i], posts[i]]
+            info.append((ldxs[i], relu, metas[i].training, worlds[i], ress[i] is not None, counts[i], mask_from_x))
+        ctx.save_for_backward(*saved)
+        ctx.info = info
+        ctx.params = [(tensors[5 * i + 1], tensors[5 * i + 2]) for i in range(n)]
+        return tuple(zs)
 
     @staticmethod
-    def backward(ctx, dz):
-        L = lib()
-        x, z, g, coef, pst = ctx.saved_tensors
-        ldx, relu, training, world, has_res, count, mask_from_x = ctx.meta
-        msc, msh = (coef[0], coef[1]) if mask_from_x else (None, None)
-        B, H, W, C = x.shape
-        P = B * H * W
-        dev = x.device
-        dz, lddz = _pixels(dz if dz.dtype == ACT_DTYPE else dz.to(ACT_DTYPE))
-        if lddz % 8 or dz.data_ptr() % 16:
-            dz, lddz = dz.contiguous(), C
-        nrep = stat_replicas() if training else 1
-        sums = None
-        link = ctx.out_link
-        if link is not None:
-            if link.sums is not None and link.dz_ptr == dz.data_ptr() and lddz == C:
-                sums = link.sums          # accumulated by the consuming conv's data-gradient epilogue
-            link.sums = link.dz_ptr = None
-        if sums is None:
-            sums = _ARENA.take(nrep * 2 * C, dev)
-            check(L.ssa_bn_bwd_reduce(_p(x), ldx, _p(dz), lddz, _p(z), C, P, C, _p(coef[2]), _p(coef[3]),
-                                      int(relu), _p(pst), H * W, _p(sums), nrep, 0, _p(msc), _p(msh), _s()),
-                  "ssa_bn_bwd_reduce")
-        pg = torch.empty((2, C), dtype=torch.float32, device=dev) if g is not None else None
-        pscale = 1.0
-        use_sums = sums
-        if training:
-            if world:
-                from .parallel import allreduce_bn_sums
-                allreduce_bn_sums(sums, P)
-                pscale = 1.0 / world
-        else:
-            # eval-mode BN: statistics are constants -> no mean/projection terms, but
-            # the parameter gradients still come from the reduced sums
-            if pg is not None:
-                check(L.ssa_bn_param_grads(_p(sums), C, _p(pg[0]), _p(pg[1]), _s()), "ssa_bn_param_grads")
-            use_sums = _ARENA.take(2 * C, dev)
-        dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
-        dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if has_res else None
-        fuse_pg = pg is not None and training
-        check(L.ssa_bn_bwd_apply(_p(x), ldx, _p(dz), lddz, _p(z), C, _p(dx), C, _p(dres), C, P, C, _p(g),
-                                 _p(coef[2]), _p(coef[3]), _p(use_sums), nrep, count, int(relu), _p(pst), H * W,
-                                 _p(pg[0]) if fuse_pg else None, _p(pg[1]) if fuse_pg else None, pscale,
-                                 _p(msc), _p(msh), _s()),
-              "ssa_bn_bwd_apply")
-        dgamma, dbeta = (pg[0], pg[1]) if pg is not None else (None, None)
-        if ctx.res_link is not None and dres is not None:
-            # conv1 of this block adds the identity branch's gradient in its data-gradient epilogue
-            ctx.res_link.dres, ctx.res_link.ld = dres, C
-            dres = None
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+    def backward(ctx, *dzs):
+        info = ctx.info
+        n = len(info)
+        saved = ctx.saved_tensors
+        jobs, idx = [], []
+        for i in range(n):
+            if dzs[i] is None:
+                continue
+            x, z, g, coef, pst = saved[5 * i:5 * i + 5]
+            ldx, relu, training, world, has_res, count, mask_from_x = info[i]
+            dz, lddz = _dz_bf16(dzs[i], x.shape[3])
+            jobs.append(dict(x=x, ldx=ldx, dz=dz, lddz=lddz, z=z, coef=coef, g=g, gamma_param=ctx.params[i][0],
+                             beta_param=ctx.params[i][1], relu=relu, pst=pst, training=training, world=world,
+                             count=count, has_res=has_res, mask_from_x=mask_from_x, sums=None))
+            idx.append(i)
+        res = _bn_bwd(jobs) if jobs else []
+        grads = [None] * (1 + 5 * n)
+        for (dx, dres, dg, db), i in zip(res, idx):
+            grads[1 + 5 * i] = dx
+            grads[2 + 5 * i] = dg
+            grads[3 + 5 * i] = db
+            grads[4 + 5 * i] = dres
+        return tuple(grads)
 
 
-class SumActFn(torch.autograd.Function):
-    """z = relu(sum of up to 4 same-shape bf16 tensors): HRNet fuse sum."""
+class BatchNormActFn:
+    """Single-problem form of BnActGroupFn (argument list of the first version, kept for the
+    op-level tests)."""
 
     @staticmethod
-    def forward(ctx, relu, *ts):
-        assert 1 <= len(ts) <= 4
-        cs = [t.contiguous() for t in ts]
-        z = torch.empty_like(cs[0])
-        n = z.numel()
-        args = [_p(c) for c in cs] + [None] * (4 - len(cs))
-        check(lib().ssa_sum_act(args[0], args[1], args[2], args[3], _p(z), n, int(relu), _s()), "ssa_sum_act")
-        ctx.relu = relu
-        ctx.n_in = len(ts)
+    def apply(x, gamma, beta, residual, post, running_mean, running_var, nbt, momentum, eps, training, relu, sync,
+              pass_stats=None):
+        m = BnMeta(momentum, eps, training, relu, sync, pass_stats, running_mean, running_var, nbt)
+        return BnActGroupFn.apply((m,), x, gamma, beta, residual, post)[0]
+
+
+# --------------------------------------------------------------------------
+# residual BasicBlock (network/hrnetv2.py:37-66) as ONE autograd node for N problems
+# --------------------------------------------------------------------------
+class BasicBlockGroupFn(torch.autograd.Function):
+    """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), training mode, 3x3 stride-1 convs without
+    bias, for N independent problems (branches x scale passes).
+    Forward: 4 grouped launches per kernel instantiation (conv1+stats, bn1, conv2+stats, bn2+add+relu).
+    Backward, hand-written: bn2 reduce, bn2 apply (-> dy2, g = the identity branch's gradient),
+    conv2 data gradient whose epilogue accumulates bn1's backward sums, bn1 apply, conv1 data
+    gradient whose epilogue adds g -- 5 grouped launches; no separate bn1 reduce pass, no autograd
+    add for the residual; the weight gradients are queued (flush_wgrads).
+    metas[i] = (BnMeta bn1, BnMeta bn2); tensors = (x, w1, g1, b1, w2, g2, b2) per problem."""
+
+    @staticmethod
+    def forward(ctx, metas, *tensors):
+        n = len(metas)
+        T = [tensors[7 * i:7 * i + 7] for i in range(n)]
+        xs, ldxs = [], []
+        for i in range(n):
+            x, ldx = _pixels(T[i][0])
+            xs.append(x)
+            ldxs.append(ldx)
+        f32 = lambda t: t.detach().float()
+        y1s = []
+        with group():
+            for i in range(n):
+                y1s.append(_conv_fwd(xs[i], ldxs[i], T[i][1], None, 1, 1, 1, False, True)[0])
+        a1s, coef1, cnt1, wd1 = _bn_train_fwd(y1s, [y.shape[3] for y in y1s], [m[0] for m in metas],
+                                              [f32(T[i][2]) for i in range(n)], [f32(T[i][3]) for i in range(n)],
+                                              [None] * n, [None] * n)
+        y2s = []
+        with group():
+            for i in range(n):
+                y2s.append(_conv_fwd(a1s[i], a1s[i].shape[3], T[i][4], None, 1, 1, 1, False, True)[0])
+        outs, coef2, cnt2, wd2 = _bn_train_fwd(y2s, [y.shape[3] for y in y2s], [m[1] for m in metas],
+                                               [f32(T[i][5]) for i in range(n)], [f32(T[i][6]) for i in range(n)],
+                                               [(xs[i], ldxs[i]) for i in range(n)], [None] * n)
+        saved = []
+        for i in range(n):
+            saved += [xs[i], y1s[i], a1s[i], y2s[i], outs[i], coef1[i], coef2[i], T[i][1], T[i][4], f32(T[i][2]), f32(T[i][5])]
+        ctx.save_for_backward(*saved)
+        ctx.info = (ldxs, cnt1, wd1, cnt2, wd2)
+        ctx.params = [(T[i][2], T[i][3], T[i][5], T[i][6]) for i in range(n)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        ldxs, cnt1, wd1, cnt2, wd2 = ctx.info
+        n = len(ldxs)
+        S = [ctx.saved_tensors[11 * i:11 * i + 11] for i in range(n)]
+        act = [i for i in range(n) if douts[i] is not None]
+        grads = [None] * (1 + 7 * n)
+        if not act:
+            return tuple(grads)
+        # ---- bn2 (+ residual add + ReLU)
+        jobs2 = []
+        for i in act:
+            x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+            C = y2.shape[3]
+            dz, lddz = _dz_bf16(douts[i], C)
+            jobs2.append(dict(x=y2, ldx=C, dz=dz, lddz=lddz, z=out, coef=c2, g=g2, gamma_param=ctx.params[i][2],
+                              beta_param=ctx.params[i][3], relu=True, pst=None, training=True, world=wd2[i],
+                              count=cnt2[i], has_res=True, mask_from_x=False, sums=None))
+        r2 = _bn_bwd(jobs2)          # (dy2, g, None, None)
+        # ---- conv2 data gradient; its epilogue accumulates bn1's backward sums where it runs on the tile kernel
+        da1 = {}
+        sums1 = {}
+        with group():
+            for k, i in enumerate(act):
+                x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+                dy2 = r2[k][0]
+                C = y2.shape[3]
+                shp = tuple(a1.shape)
+                if y1.data_ptr() % 16 == 0 and dgrad_tile_ok(shp, w2, 1, 1, 1, tuple(y2.shape[1:3])):
+                    sums1[i] = _ARENA.take(stat_replicas() * 2 * shp[3], y1.device)
+                    da1[i] = _conv_dgrad(shp, w2, dy2, C, C, 1, 1, 1, tuple(y2.shape[1:3]), aux=y1, ldaux=y1.shape[3],
+                                         coef=c1, mode=2, stats=sums1[i])
+                else:
+                    sums1[i] = None
+                    da1[i] = _conv_dgrad(shp, w2, dy2, C, C, 1, 1, 1, tuple(y2.shape[1:3]))
+        # ---- bn1 (+ ReLU, mask recomputed from y1)
+        jobs1 = []
+        for i in act:
+            x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+            C = y1.shape[3]
+            jobs1.append(dict(x=y1, ldx=C, dz=da1[i], lddz=C, z=None, coef=c1, g=g1, gamma_param=ctx.params[i][0],
+                              beta_param=ctx.params[i][1], relu=True, pst=None, training=True, world=wd1[i],
+                              count=cnt1[i], has_res=False, mask_from_x=True, sums=sums1[i]))
+        r1 = _bn_bwd(jobs1)          # (dy1, None, None, None)
+        # ---- conv1 data gradient + the identity branch's gradient
+        dxs = {}
+        late_add = []
+        need_dx = [i for i in act if ctx.needs_input_grad[1 + 7 * i]]
+        with group():
+            for k, i in enumerate(act):
+                if i not in need_dx:
+                    continue
+                x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+                dy1, gres = r1[k][0], r2[k][1]
+                C = y1.shape[3]
+                shp = tuple(x.shape)
+                if gres.data_ptr() % 16 == 0 and dgrad_tile_ok(shp, w1, 1, 1, 1, tuple(y1.shape[1:3])):
+                    dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]), aux=gres, ldaux=gres.shape[3],
+                                         mode=1)
+                else:
+                    dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]))
+                    late_add.append((i, gres))
+        for i, gres in late_add:
+            dxs[i] = _add_bf16(dxs[i], gres)
+        # ---- weight gradients (queued)
+        for k, i in enumerate(act):
+            x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+            dy2, dy1 = r2[k][0], r1[k][0]
+            C2, C1 = y2.shape[3], y1.shape[3]
+            dw2 = _wgrad(a1, a1.shape[3], tuple(a1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
+                         w2.shape[0], w2.shape[1], weight=w2)
+            dw1 = _wgrad(x, ldxs[i], tuple(x.shape), dy1, C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
+                         w1.shape[0], w1.shape[1], weight=w1)
+            base = 1 + 7 * i
+            grads[base] = dxs.get(i)
+            grads[base + 1] = dw1
+            grads[base + 2], grads[base + 3] = r1[k][2], r1[k][3]
+            grads[base + 4] = dw2
+            grads[base + 5], grads[base + 6] = r2[k][2], r2[k][3]
+        return tuple(grads)
+
+
+class SumActGroupFn(torch.autograd.Function):
+    """z_i = relu(sum of up to 4 same-shape bf16 tensors) for N problems: HRNet fuse sums.
+    counts[i] = number of terms of problem i; tensors = the terms, problem after problem."""
+
+    @staticmethod
+    def forward(ctx, relu, counts, *ts):
+        zs, off = [], 0
+        with group():
+            for c in counts:
+                assert 1 <= c <= 4
+                cs = [t.contiguous() for t in ts[off:off + c]]
+                off += c
+                z = torch.empty_like(cs[0])
+                args = [_p(t) for t in cs] + [None] * (4 - c)
+                check(lib().ssa_sum_act(args[0], args[1], args[2], args[3], _p(z), z.numel(), int(relu), _s()), "ssa_sum_act")
+                zs.append(z)
+        ctx.relu, ctx.counts = relu, counts
         if relu:
-            ctx.save_for_backward(z)
-        return z
+            ctx.save_for_backward(*zs)
+        return tuple(zs)
 
     @staticmethod
-    def backward(ctx, dz):
-        dz = dz.contiguous()
+    def backward(ctx, *dzs):
+        gs = []
         if ctx.relu:
-            (z,) = ctx.saved_tensors
-            g = torch.empty_like(z)
-            check(lib().ssa_relu_bwd(_p(dz), _p(z), _p(g), z.numel(), _s()), "ssa_relu_bwd")
+            zs = ctx.saved_tensors
+            dzc = [None if d is None else d.contiguous() for d in dzs]
+            with group():
+                for z, dz in zip(zs, dzc):
+                    if dz is None:
+                        gs.append(None)
+                        continue
+                    g = torch.empty_like(z)
+                    check(lib().ssa_relu_bwd(_p(dz), _p(z), _p(g), z.numel(), _s()), "ssa_relu_bwd")
+                    gs.append(g)
         else:
-            g = dz
-        return (None,) + (g,) * ctx.n_in
+            gs = list(dzs)
+        out = [None, None]
+        for g, c in zip(gs, ctx.counts):
+            out += [g] * c
+        return tuple(out)
+
+
+class SumActFn:
+    @staticmethod
+    def apply(relu, *ts):
+        return SumActGroupFn.apply(relu, (len(ts),), *ts)[0]
 
 
 def _dt(t):
@@ -752,27 +1192,53 @@ def _dt(t):
     raise TypeError(t.dtype)
 
 
-class BilinearFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, Ho, Wo, out_f32):
-        x, ldx = _pixels(x)
-        B, Hi, Wi, C = x.shape
-        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
-        check(lib().ssa_bilinear_fwd(_p(x), _dt(x), B, Hi, Wi, C, ldx, _p(y), _dt(y), Ho, Wo, C, _s()),
-              "ssa_bilinear_fwd")
-        ctx.meta = (B, Hi, Wi, C, Ho, Wo, x.dtype)
-        return y
+class BilinearGroupFn(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=False) of N tensors; spec[i] = (Ho, Wo, out_f32)."""
 
     @staticmethod
-    def backward(ctx, dy):
-        B, Hi, Wi, C, Ho, Wo, in_dtype = ctx.meta
-        dy, lddy = _pixels(dy)
-        if dy.dtype == ACT_DTYPE and (lddy % 8 or dy.data_ptr() % 16):
-            dy, lddy = dy.contiguous(), C
-        dx = torch.empty((B, Hi, Wi, C), dtype=in_dtype, device=dy.device)
-        check(lib().ssa_bilinear_bwd(_p(dy), _dt(dy), B, Ho, Wo, C, lddy, _p(dx), _dt(dx), Hi, Wi, C, _s()),
-              "ssa_bilinear_bwd")
-        return dx, None, None, None
+    def forward(ctx, spec, *xs):
+        prep = [_pixels(x) for x in xs]
+        ys, meta = [], []
+        with group():
+            for (x, ldx), (Ho, Wo, out_f32) in zip(prep, spec):
+                B, Hi, Wi, C = x.shape
+                y = torch.empty((B, Ho, Wo, C), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+                check(lib().ssa_bilinear_fwd(_p(x), _dt(x), B, Hi, Wi, C, ldx, _p(y), _dt(y), Ho, Wo, C, _s()),
+                      "ssa_bilinear_fwd")
+                ys.append(y)
+                meta.append((B, Hi, Wi, C, Ho, Wo, x.dtype))
+        ctx.meta = meta
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        prep = []
+        for dy, (B, Hi, Wi, C, Ho, Wo, in_dtype) in zip(dys, ctx.meta):
+            if dy is None:
+                prep.append(None)
+                continue
+            dy, lddy = _pixels(dy)
+            if dy.dtype == ACT_DTYPE and (lddy % 8 or dy.data_ptr() % 16):
+                dy, lddy = dy.contiguous(), C
+            prep.append((dy, lddy))
+        dxs = [None]
+        with group():
+            for pr, (B, Hi, Wi, C, Ho, Wo, in_dtype) in zip(prep, ctx.meta):
+                if pr is None:
+                    dxs.append(None)
+                    continue
+                dy, lddy = pr
+                dx = torch.empty((B, Hi, Wi, C), dtype=in_dtype, device=dy.device)
+                check(lib().ssa_bilinear_bwd(_p(dy), _dt(dy), B, Ho, Wo, C, lddy, _p(dx), _dt(dx), Hi, Wi, C, _s()),
+                      "ssa_bilinear_bwd")
+                dxs.append(dx)
+        return tuple(dxs)
+
+
+class BilinearFn:
+    @staticmethod
+    def apply(x, Ho, Wo, out_f32):
+        return BilinearGroupFn.apply(((int(Ho), int(Wo), bool(out_f32)),), x)[0]
 
 
 class MaxPool3x3s2Fn(torch.autograd.Function):

@@ -4,6 +4,13 @@ Same module tree (hence the same 1,5xx state_dict keys) as the reference's
 network/hrnetv2.py; the forward passes are written against fused operators:
 conv -> BN(+residual)(+ReLU) is two kernels, the cross-resolution fuse sum is
 one kernel, all tensors are NHWC bf16.
+
+Lockstep over independent problems.  The trunk takes ONE image or a LIST of images (the
+scale passes of MscaleOCR, network/ocrnet.py:264-327); inside a HighResolutionModule the
+2-4 resolution branches are independent until the fuse layers.  Every depth level of
+(branch x pass) problems is handed to the operator surface as one list, which the HIP
+backend turns into one launch per kernel instantiation (csrc/group.h) -- where the
+reference issues one cuDNN call per (layer, branch, pass).
 """
 import os
 
@@ -12,7 +19,7 @@ from torch import nn
 
 from .. import ops
 from ..config import cfg
-from ..nn import Conv2d, Norm2d, conv_bn, residual_link
+from ..nn import Conv2d, Norm2d, conv_bn
 
 BN_MOMENTUM = 0.1   # network/hrnetv2.py:26
 
@@ -35,12 +42,20 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        res = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
-        # dataflow hints for the backend's backward fusions: bn1's output feeds conv2 alone, and
-        # (without a downsample branch) the block input is consumed by conv1 and the final add only
-        link = residual_link() if self.downsample is None else None
-        out = conv_bn(self.conv1, self.bn1, x, relu=True, block=link)
-        return conv_bn(self.conv2, self.bn2, out, residual=res, relu=True, private_input=True, block=link)
+        """x: a tensor or a list of tensors (the scale passes)."""
+        return run_basic_blocks([self] * len(x), x) if isinstance(x, (list, tuple)) else run_basic_blocks([self], [x])[0]
+
+
+def run_basic_blocks(blocks, xs):
+    """blocks[i] applied to xs[i], all problems in lockstep."""
+    if all(b.downsample is None for b in blocks):
+        return ops.backend().basic_block(blocks, list(xs))
+    outs = []
+    for b, x in zip(blocks, xs):
+        res = x if b.downsample is None else conv_bn(b.downsample[0], b.downsample[1], x)
+        out = conv_bn(b.conv1, b.bn1, x, relu=True)
+        outs.append(conv_bn(b.conv2, b.bn2, out, residual=res, relu=True))
+    return outs
 
 
 class Bottleneck(nn.Module):
@@ -59,10 +74,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        """x: a tensor or a list of tensors (the scale passes)."""
         res = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True, private_input=True)
-        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True, private_input=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True)
 
 
 BLOCKS = {"BASIC": BasicBlock, "BOTTLENECK": Bottleneck}
@@ -125,27 +141,55 @@ class HighResolutionModule(nn.Module):
         return self.num_inchannels
 
     def forward(self, xs):
+        """xs[i]: branch i's input -- a tensor, or a list of tensors (the scale passes)."""
         B = ops.backend()
-        # the resolution branches are independent until the fuse layers
-        xs = B.parallel([(lambda i=i: self.branches[i](xs[i])) for i in range(self.num_branches)], level=2)
-        if self.num_branches == 1:
-            return xs
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
-            terms = []
-            for j in range(self.num_branches):
-                if j == i:
-                    terms.append(xs[j])
-                elif j > i:
-                    t = conv_bn(row[j][0], row[j][1], xs[j])
-                    terms.append(B.bilinear(t, xs[i].shape[1:3]))
-                else:
-                    t = xs[j]
-                    for stage in row[j]:
-                        t = conv_bn(stage[0], stage[1], t, relu=len(stage) == 3)
-                    terms.append(t)
-            outs.append(B.sum_act(terms, relu=True))
-        return outs
+        nb = self.num_branches
+        multi = isinstance(xs[0], (list, tuple))
+        xs = [list(x) if multi else [x] for x in xs]
+        P = len(xs[0])
+        # ---- branches: every depth level of all (branch, pass) problems in lockstep
+        jobs = [(i, p) for i in range(nb) for p in range(P)]
+        cur = [xs[i][p] for i, p in jobs]
+        for d in range(max(len(br) for br in self.branches)):
+            sel = [k for k, (i, p) in enumerate(jobs) if d < len(self.branches[i])]
+            blocks = [self.branches[jobs[k][0]][d] for k in sel]
+            if all(isinstance(b, BasicBlock) for b in blocks):
+                outs = run_basic_blocks(blocks, [cur[k] for k in sel])
+            else:
+                outs = [b(cur[k]) for b, k in zip(blocks, sel)]
+            for k, o in zip(sel, outs):
+                cur[k] = o
+        ys = [[cur[i * P + p] for p in range(P)] for i in range(nb)]
+        if nb == 1:
+            return ys if multi else [y[0] for y in ys]
+        # ---- fuse layers (network/hrnetv2.py:236-252), level by level over all (i, j, pass)
+        rows = self.fuse_layers
+        term = {}
+        up = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j > i for p in range(P)]
+        if up:
+            ts = conv_bn([rows[i][j][0] for i, j, p in up], [rows[i][j][1] for i, j, p in up], [ys[j][p] for i, j, p in up])
+            ts = B.bilinear(ts, [tuple(ys[i][p].shape[1:3]) for i, j, p in up])
+            term.update(zip(up, ts))
+        down = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j < i for p in range(P)]
+        state = {k: ys[k[1]][k[2]] for k in down}
+        step = 0
+        while True:
+            sel = [k for k in down if step < len(rows[k[0]][k[1]])]
+            if not sel:
+                break
+            stages = [rows[i][j][step] for i, j, p in sel]
+            outs = conv_bn([st[0] for st in stages], [st[1] for st in stages], [state[k] for k in sel],
+                           relu=[len(st) == 3 for st in stages])
+            state.update(zip(sel, outs))
+            step += 1
+        term.update(state)
+        sums = []
+        for i in range(len(rows)):
+            for p in range(P):
+                sums.append([ys[i][p] if j == i else term[(i, j, p)] for j in range(nb)])
+        outs = B.sum_act(sums, relu=True)
+        outs = [[outs[i * P + p] for p in range(P)] for i in range(len(rows))]
+        return outs if multi else [o[0] for o in outs]
 
 
 class HighResolutionNet(nn.Module):
@@ -214,31 +258,67 @@ class HighResolutionNet(nn.Module):
 
     @staticmethod
     def _apply_transition(trans, ys, n_prev):
-        xs = []
+        """ys[i]: list over the scale passes.  The convs of one chain depth run as one list."""
+        xs = [None] * len(trans)
+        chains = []                     # (new branch index, [stages], source)
         for i, t in enumerate(trans):
             src = ys[i] if i < n_prev else ys[-1]
             if t is None:
-                xs.append(src)
+                xs[i] = src
             elif i < n_prev:
-                xs.append(conv_bn(t[0], t[1], src, relu=True))
+                chains.append((i, [t], src))
             else:
-                for stage in t:
-                    src = conv_bn(stage[0], stage[1], src, relu=True)
-                xs.append(src)
+                chains.append((i, list(t), src))
+        step = 0
+        while True:
+            sel = [c for c in chains if step < len(c[1])]
+            if not sel:
+                break
+            convs, bns, ins, owner = [], [], [], []
+            for ci, c in enumerate(chains):
+                if step < len(c[1]):
+                    for x in c[2]:
+                        convs.append(c[1][step][0])
+                        bns.append(c[1][step][1])
+                        ins.append(x)
+                        owner.append(ci)
+            outs = conv_bn(convs, bns, ins, relu=True)
+            new_src = {}
+            for ci, o in zip(owner, outs):
+                new_src.setdefault(ci, []).append(o)
+            chains = [(c[0], c[1], new_src.get(ci, c[2])) for ci, c in enumerate(chains)]
+            step += 1
+        for i, stages, src in chains:
+            xs[i] = src
+        return xs
+
+    @staticmethod
+    def _run_stage(stage, xs):
+        for m in stage:
+            xs = m(xs)
         return xs
 
     def forward(self, x):
+        """x: NHWC bf16 image [B,H,W,16], or a list of images (the scale passes, run in lockstep).
+        Returns (None, None, feats) -- feats a tensor or a list like x."""
         B = ops.backend()
-        x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        x = conv_bn(self.conv2, self.bn2, x, relu=True)
-        x = self.layer1(x)
-        ys = [x]
-        ys = self.stage2(self._apply_transition(self.transition1, ys, 1))
-        ys = self.stage3(self._apply_transition(self.transition2, ys, self.stage2_cfg["NUM_BRANCHES"]))
-        ys = self.stage4(self._apply_transition(self.transition3, ys, self.stage3_cfg["NUM_BRANCHES"]))
-        size = ys[0].shape[1:3]
-        feats = B.cat([ys[0]] + [B.bilinear(y, size) for y in ys[1:]])
-        return None, None, feats
+        multi = isinstance(x, (list, tuple))
+        xs = list(x) if multi else [x]
+        xs = conv_bn(self.conv1, self.bn1, xs, relu=True)
+        xs = conv_bn(self.conv2, self.bn2, xs, relu=True)
+        for blk in self.layer1:
+            xs = blk(xs)
+        ys = [xs]
+        ys = self._run_stage(self.stage2, self._apply_transition(self.transition1, ys, 1))
+        ys = self._run_stage(self.stage3, self._apply_transition(self.transition2, ys, self.stage2_cfg["NUM_BRANCHES"]))
+        ys = self._run_stage(self.stage4, self._apply_transition(self.transition3, ys, self.stage3_cfg["NUM_BRANCHES"]))
+        P = len(xs)
+        sizes = [tuple(ys[0][p].shape[1:3]) for p in range(P)]
+        low = [(i, p) for i in range(1, len(ys)) for p in range(P)]
+        ups = B.bilinear([ys[i][p] for i, p in low], [sizes[p] for i, p in low]) if low else []
+        up = dict(zip(low, ups))
+        feats = [B.cat([ys[0][p]] + [up[(i, p)] for i in range(1, len(ys))]) for p in range(P)]
+        return None, None, (feats if multi else feats[0])
 
     def init_weights(self, pretrained=None):
         """network/hrnetv2.py:451-477: N(0, 1e-3) convs / unit BN outside the

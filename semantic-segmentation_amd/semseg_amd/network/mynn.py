@@ -8,6 +8,7 @@ from ..nn import Norm2d, initialize_weights  # noqa: F401
 
 
 def Upsample(x, size):
+    """x / size: a tensor and its target size, or lists of them (independent problems)."""
     return ops.backend().bilinear(x, size, out_f32=True)
 
 

@@ -19,7 +19,10 @@ class SpatialGather_Module(nn.Module):
         assert scale == 1
 
     def forward(self, feats, probs):
+        """feats / probs: tensors, or lists of tensors (the scale passes)."""
         B = ops.backend()
+        if isinstance(feats, (list, tuple)):
+            return [self.forward(f, p) for f, p in zip(feats, probs)]
         ctx = B.ocr_gather(feats, probs)            # [B,K,C] fp32
         return B.to_act(ctx).unsqueeze(2)           # [B,K,1,C]
 
@@ -54,11 +57,17 @@ class ObjectAttentionBlock(nn.Module):
         self.f_up = _conv_bnrelu_stack(key_channels, in_channels, 1)
 
     def forward(self, x, proxy):
+        """x / proxy: tensors, or lists of tensors (the scale passes; the 1x1 conv stacks then run
+        as grouped launches)."""
         B = ops.backend()
         q = _run_stack(self.f_pixel, x)                     # [B,H,W,D]
         k = _run_stack(self.f_object, proxy)                # [B,K,1,D]
         v = _run_stack(self.f_down, proxy)                  # [B,K,1,D]
-        ctx = B.ocr_attention(q, k.squeeze(2), v.squeeze(2), self.key_channels ** -0.5)
+        scale = self.key_channels ** -0.5
+        if isinstance(x, (list, tuple)):
+            ctx = [B.ocr_attention(qi, ki.squeeze(2), vi.squeeze(2), scale) for qi, ki, vi in zip(q, k, v)]
+        else:
+            ctx = B.ocr_attention(q, k.squeeze(2), v.squeeze(2), scale)
         return _run_stack(self.f_up, ctx)
 
 
@@ -74,14 +83,22 @@ class SpatialOCR_Module(nn.Module):
             BNReLU(out_channels),
             nn.Dropout2d(dropout))
 
+    def _mask(self, x):
+        drop = self.conv_bn_dropout[2]
+        if not (self.training and drop.p > 0):
+            return None
+        n, c = x.shape[0], self.conv_bn_dropout[0].out_channels
+        keep = 1.0 - drop.p
+        return (torch.rand(n, c, device=x.device) < keep).to(torch.float32) / keep
+
     def forward(self, feats, proxy_feats):
+        """feats / proxy_feats: tensors, or lists of tensors (the scale passes)."""
         B = ops.backend()
         context = self.object_context_block(feats, proxy_feats)
-        x = B.cat([context, feats])
-        drop = self.conv_bn_dropout[2]
-        post = None
-        if self.training and drop.p > 0:
-            n, c = x.shape[0], self.conv_bn_dropout[0].out_channels
-            keep = 1.0 - drop.p
-            post = (torch.rand(n, c, device=x.device) < keep).to(torch.float32) / keep
+        if isinstance(feats, (list, tuple)):
+            x = [B.cat([c, f]) for c, f in zip(context, feats)]
+            post = [self._mask(xi) for xi in x]
+        else:
+            x = B.cat([context, feats])
+            post = self._mask(x)
         return conv_bn(self.conv_bn_dropout[0], self.conv_bn_dropout[1][0], x, relu=True, post=post)

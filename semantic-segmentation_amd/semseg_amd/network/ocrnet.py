@@ -8,7 +8,6 @@ the HIP kernels; the NCHW tensors handed back are zero-copy permuted views.
 """
 import torch
 from torch import nn
-from torch.nn.utils import stateless
 
 from .. import ops
 from ..config import cfg
@@ -50,6 +49,8 @@ class OCR_block(nn.Module):
                                self.cls_head, self.aux_head)
 
     def forward(self, high_level_features):
+        """high_level_features: a tensor, or a list of tensors (the scale passes in lockstep);
+        every output is a list for a list."""
         feats = conv_bn(self.conv3x3_ocr[0], self.conv3x3_ocr[1][0], high_level_features, relu=True)
         aux = conv_bn(self.aux_head[0], self.aux_head[1][0], high_level_features, relu=True)
         aux_out = self.aux_head[2](aux, out_f32=True)              # [B,H,W,K] fp32
@@ -128,14 +129,17 @@ class MscaleOCR(_Base):
         self.ocr = OCR_block(high_level_ch)
         self.scale_attn = make_attn_head(in_ch=cfg.MODEL.OCR.MID_CHANNELS, out_ch=1)
 
-    def _fwd(self, x, size):
-        """One trunk+heads pass; outputs bilinearly resampled to `size` in fp32
+    def _fwd(self, xs, sizes):
+        """Trunk + heads for every scale pass in `xs`, in lockstep (the passes are problems of the
+        same grouped launches); per pass the outputs are bilinearly resampled to sizes[p] in fp32
         (network/ocrnet.py:170-183)."""
-        _, _, feats = self.backbone(x)
+        _, _, feats = self.backbone(list(xs))
         cls_out, aux_out, mid = self.ocr(feats)
         attn = self.scale_attn(mid)
-        return {"cls_out": Upsample(cls_out, size), "aux_out": Upsample(aux_out, size),
-                "logit_attn": Upsample(attn, size)}
+        cls_up = Upsample(cls_out, sizes)
+        aux_up = Upsample(aux_out, sizes)
+        attn_up = Upsample(attn, sizes)
+        return [{"cls_out": c, "aux_out": a, "logit_attn": t} for c, a, t in zip(cls_up, aux_up, attn_up)]
 
     def nscale_forward(self, inputs, scales):
         """Hierarchical attention over N scales, high to low (network/ocrnet.py:185-262)."""
@@ -144,14 +148,9 @@ class MscaleOCR(_Base):
         pred = aux = None
         out = {}
         order = sorted(scales, reverse=True)
-
-        def one_scale(s):
-            x, size = self._images(inputs, s)
-            return self._fwd(x, size)
-
-        # the per-scale passes are independent (only the fusion below is sequential): issue them
-        # on concurrent streams, the target scale on the calling stream
-        passes = B.parallel([(lambda s=s: one_scale(s)) for s in order])
+        # the per-scale passes are independent (only the fusion below is sequential): lockstep
+        imgs = [self._images(inputs, s) for s in order]
+        passes = self._fwd([x for x, _ in imgs], [size for _, size in imgs])
         for s, o in zip(order, passes):
             cls_out, attn_out, aux_out = o["cls_out"], o["logit_attn"], o["aux_out"]
             out[fmt_scale("pred", s)] = _nchw(cls_out)
@@ -178,26 +177,12 @@ class MscaleOCR(_Base):
 
     def two_scale_forward(self, inputs):
         """Training path: 0.5x and 1.0x passes fused by the 0.5x attention
-        (network/ocrnet.py:264-327)."""
+        (network/ocrnet.py:264-327).  The two passes share nothing but the weights: they run in
+        lockstep, low scale first (the reference's order: BatchNorm running statistics)."""
         B = ops.backend()
-
-        shadow = None
-        if self.training and torch.is_grad_enabled() and getattr(B, "use_shadow_pass", lambda: False)():
-            shadow = self._shadow_parameters()
-
-        def lo_pass():
-            x_lo, lo_size = self._images(inputs, cfg.MODEL.MSCALE_LO_SCALE)
-            if shadow is None:
-                return self._fwd(x_lo, lo_size)
-            with stateless._reparametrize_module(self, shadow):
-                return self._fwd(x_lo, lo_size)
-
-        def hi_pass():
-            x_1x, size = self._images(inputs)
-            return self._fwd(x_1x, size), size
-
-        # the two scale passes share nothing but the weights: run them concurrently
-        (hi, size), lo = B.parallel([hi_pass, lo_pass])
+        x_lo, lo_size = self._images(inputs, cfg.MODEL.MSCALE_LO_SCALE)
+        x_1x, size = self._images(inputs)
+        lo, hi = self._fwd([x_lo, x_1x], [lo_size, size])
         pred_05x, aux_lo, attn_05x = lo["cls_out"], lo["aux_out"], lo["logit_attn"]
         pred_10x, aux_1x = hi["cls_out"], hi["aux_out"]
 
@@ -217,50 +202,9 @@ class MscaleOCR(_Base):
                 loss_lo = self.criterion(_nchw(B.bilinear(pred_05x, size)), gts, do_rmi=False)
                 loss_hi = self.criterion(_nchw(pred_10x), gts, do_rmi=False)
                 loss = loss + wt * loss_lo + wt * loss_hi
-            if shadow is not None and loss.requires_grad:
-                loss.register_hook(self._arm_shadow_merge)
             return loss
         return {"pred": _nchw(joint_pred), "pred_05x": _nchw(pred_05x), "pred_10x": _nchw(pred_10x),
                 "attn_05x": _nchw(attn_05x)}
-
-    # -- gradients of the 0.5x pass ------------------------------------------------------
-    # Both passes use every parameter, so autograd would add the two contributions with one
-    # `add` kernel per parameter (955 launches per step).  Instead the 0.5x pass runs on detached
-    # aliases (same storage, separate autograd leaves) and ONE multi-tensor add merges their
-    # gradients into the parameters' at the end of backward.
-    def _shadow_parameters(self):
-        cur = getattr(self, "_shadow", None)
-        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
-        if cur is None or len(cur[0]) != len(named) or any(
-                s.data_ptr() != p.data_ptr() or s.shape != p.shape for (_, p), s in zip(named, cur[0].values())):
-            cur = ({n: p.detach().requires_grad_(True) for n, p in named}, [p for _, p in named])
-            object.__setattr__(self, "_shadow", cur)
-        return cur[0]
-
-    def _arm_shadow_merge(self, grad):
-        from torch.autograd import Variable
-        Variable._execution_engine.queue_callback(self._merge_shadow_grads)
-        return None
-
-    def _merge_shadow_grads(self):
-        shadows, params = self._shadow
-        getattr(ops.backend(), "flush_backward", lambda: None)()    # deferred weight-gradient reduces first
-        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
-        if main is not None:
-            for st in getattr(ops.backend(), "side_streams", lambda: [])():
-                main.wait_stream(st)             # the 0.5x pass's gradients were produced there
-        dst, src = [], []
-        for p, s in zip(params, shadows.values()):
-            if s.grad is None:
-                continue
-            if p.grad is None:
-                p.grad = s.grad
-            else:
-                dst.append(p.grad)
-                src.append(s.grad)
-            s.grad = None
-        if dst:
-            torch._foreach_add_(dst, src)
 
     def forward(self, inputs):
         ops.backend().begin_step(inputs["images"].device)

@@ -29,8 +29,8 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         res = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True, private_input=True)
-        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True, private_input=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=res, relu=True)
 
 
 class ResNetTrunk(nn.Module):

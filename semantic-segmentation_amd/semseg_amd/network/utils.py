@@ -32,7 +32,8 @@ class AttnHead(nn.Sequential):
         x = conv_bn(self.conv0, self.bn0, x, relu=True)
         if hasattr(self, "conv1"):
             x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        return B.sigmoid(self.conv2(x, out_f32=True))      # [B,H,W,1] fp32
+        y = self.conv2(x, out_f32=True)                    # [B,H,W,1] fp32 (a list for a list)
+        return [B.sigmoid(t) for t in y] if isinstance(y, (list, tuple)) else B.sigmoid(y)
 
 
 def make_attn_head(in_ch, out_ch):

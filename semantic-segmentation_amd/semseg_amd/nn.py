@@ -12,6 +12,7 @@ class Conv2d(nn.Conv2d):
     """nn.Conv2d (groups=1, square kernel/stride/padding/dilation) on NHWC input."""
 
     def forward(self, x, out_f32=False):
+        """x: a tensor, or a list of tensors (independent problems through the same filter)."""
         assert self.groups == 1 and self.padding_mode == "zeros"
         return ops.backend().conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0],
                                     self.dilation[0], out_f32)
@@ -51,21 +52,15 @@ def BNReLU(ch):
     return nn.Sequential(Norm2d(ch), nn.ReLU())
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, post=None, private_input=False, block=None):
+def conv_bn(conv, bn, x, residual=None, relu=False, post=None):
     """conv -> norm (+ residual add, ReLU, Dropout2d mask) as one backend call, so
     the backend may fuse the batch statistics into the conv epilogue.
-    private_input / block: what the caller knows about the dataflow around this call (see
-    ops.HipBackend.conv_bn_act); they enable backward fusions and never change results."""
-    assert conv.groups == 1 and conv.padding_mode == "zeros"
-    if private_input or block is not None:
-        return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post, private_input=private_input, block=block)
+    `x` may be a LIST of independent problems (scale passes, resolution branches); `conv`, `bn`,
+    `residual`, `relu`, `post` are then one value for all of them or lists of the same length,
+    and a list is returned (ops.BackendBase)."""
+    for c in (conv if isinstance(conv, (list, tuple)) else (conv,)):
+        assert c.groups == 1 and c.padding_mode == "zeros"
     return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post)
-
-
-def residual_link():
-    """Per-call hand-over object of a residual block for the backend (None where unsupported)."""
-    f = getattr(ops.backend(), "residual_link", None)
-    return f() if f is not None else None
 
 
 def initialize_weights(*models):

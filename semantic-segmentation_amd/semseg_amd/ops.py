@@ -7,15 +7,86 @@ libsemseg_hip.so); it is created on first use and raises if the library is
 missing.  `_set_backend_for_tests` exists so the CPU test-suite can check the
 module wiring against the reference with the oracle's operators; product code
 never calls it.
-"""
-import os
 
+Multi-problem calls.  The hot ops (conv, conv+BN, BasicBlock, fuse sum, bilinear)
+accept a LIST of independent problems wherever they accept a tensor -- the resolution
+branches of a HighResolutionModule times the scale passes of MscaleOCR -- and return a
+list.  `BackendBase` maps such a call over the single-problem primitives; the HIP
+backend overrides them with grouped launches (one launch per kernel instantiation for
+the whole list, csrc/group.h).
+"""
 import torch
 
 _BACKEND = None
 
 
-class HipBackend:
+def _is_list(v):
+    return isinstance(v, (list, tuple))
+
+
+def _lst(v, n):
+    return list(v) if _is_list(v) else [v] * n
+
+
+class BackendBase:
+    """List-aware front of the operator surface over single-problem primitives
+    (`_conv2d`, `_conv_bn_act`, `_batch_norm_act`, `_sum_act`, `_bilinear`)."""
+
+    def group(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False, want_stats=False):
+        if not _is_list(x):
+            return self._conv2d(x, weight, bias, stride, padding, dilation, out_f32)
+        n = len(x)
+        return [self._conv2d(xi, w, b, stride, padding, dilation, out_f32)
+                for xi, w, b in zip(x, _lst(weight, n), _lst(bias, n))]
+
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+        if not _is_list(x):
+            return self._conv_bn_act(conv, bn, x, residual, relu, post)
+        n = len(x)
+        return [self._conv_bn_act(c, b, xi, r, rl, po) for c, b, xi, r, rl, po in
+                zip(_lst(conv, n), _lst(bn, n), x, _lst(residual, n), _lst(relu, n), _lst(post, n))]
+
+    def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
+        if not _is_list(x):
+            return self._batch_norm_act(x, bn, residual, relu, post)
+        n = len(x)
+        return [self._batch_norm_act(xi, b, r, rl, po) for xi, b, r, rl, po in
+                zip(x, _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n))]
+
+    def basic_block(self, blocks, xs):
+        """conv3x3-BN-ReLU-conv3x3-BN-(+x)-ReLU (network/hrnetv2.py:37-66, no downsample branch)
+        of blocks[i] on xs[i]."""
+        mid = [self._conv_bn_act(b.conv1, b.bn1, x, None, True, None) for b, x in zip(blocks, xs)]
+        return [self._conv_bn_act(b.conv2, b.bn2, m, x, True, None) for b, m, x in zip(blocks, mid, xs)]
+
+    def sum_act(self, tensors, relu=True):
+        if tensors and _is_list(tensors[0]):
+            return [self._sum_act(t, relu) for t in tensors]
+        return self._sum_act(tensors, relu)
+
+    def bilinear(self, x, size, out_f32=False):
+        if not _is_list(x):
+            return self._bilinear(x, size, out_f32)
+        sizes = size if _is_list(size[0]) or hasattr(size[0], "__len__") else [size] * len(x)
+        return [self._bilinear(xi, s, out_f32) for xi, s in zip(x, sizes)]
+
+    @staticmethod
+    def parallel(thunks, level=1):
+        """Independent sub-graphs, issued one after the other (thunks[1:] first, thunks[0] last:
+        the reference runs the low-scale pass before the 1.0x pass, and BatchNorm running
+        statistics are updated in issue order)."""
+        outs = [None] * len(thunks)
+        for i in range(1, len(thunks)):
+            outs[i] = thunks[i]()
+        outs[0] = thunks[0]()
+        return outs
+
+
+class HipBackend(BackendBase):
     name = "hip"
 
     def __init__(self):
@@ -27,131 +98,111 @@ class HipBackend:
     def begin_step(self, device=None):
         self.hb.begin_step(device)
 
-    # -- independent sub-graphs on concurrent HIP streams ------------------
-    # The two scale passes of MscaleOCR and the 2-4 resolution branches of every
-    # HighResolutionModule are independent chains of small kernels (B=1: most
-    # launches cannot fill 256 CUs).  Each chain gets its own stream; fork/join
-    # are events, so a captured hipGraph keeps them as parallel branches.
-    # autograd replays every op's backward on the stream of its forward, so the
-    # backward pass is concurrent in the same way.
-    # bit 0: the two scale passes, bit 1: the HRNet branches (SSA_CONCURRENCY=0 disables both).
-    # Measured on MI355X, 1024x1024 crop, hipGraph replay: sequential 108.2 ms/step,
-    # scale passes concurrent 77.1, scale passes + branches 101.8 (the per-module
-    # fork/join events cost more than the overlap buys at this size; at 256x256 the
-    # branches alone give 70.3 -> 60.1) -- hence the default of 1.
-    concurrency = int(os.environ.get("SSA_CONCURRENCY", "1"))
-    # The 0.5x pass runs on detached aliases of the parameters and its gradients are added to the
-    # 1.0x pass's by ONE multi-tensor add at the end of backward, instead of autograd's 955
-    # per-parameter `add` launches (MscaleOCR._shadow_parameters).  Off under torch.distributed:
-    # DDP's per-parameter hooks must see the complete gradient.
-    shadow_lo_pass = os.environ.get("SSA_SHADOW", "1") != "0"
-
-    def use_shadow_pass(self):
-        from .parallel import sync_world
-        return self.shadow_lo_pass and not sync_world()
-
-    def side_streams(self):
-        return list(self._streams.values())
-    _streams = {}
-    _side_handles = set()
-
-    @staticmethod
-    def _sequential(thunks):
-        outs = [None] * len(thunks)          # same issue order as the concurrent path
-        for i in range(1, len(thunks)):
-            outs[i] = thunks[i]()
-        outs[0] = thunks[0]()
-        return outs
-
-    def parallel(self, thunks, level=1):
-        if not (self.concurrency & level) or len(thunks) < 2 or not torch.cuda.is_available():
-            return self._sequential(thunks)
-        main = torch.cuda.current_stream()
-        if main.cuda_stream in self._side_handles:
-            # nested fork (a fork from an already forked stream): hipStreamEndCapture
-            # segfaults on such graphs (ROCm 7.2), so only the root stream forks
-            return self._sequential(thunks)
-        side = []
-        for i in range(1, len(thunks)):
-            key = (main.cuda_stream, level, i)     # nested forks never share a stream
-            st = self._streams.get(key)
-            if st is None:
-                st = self._streams[key] = torch.cuda.Stream()
-                self._side_handles.add(st.cuda_stream)
-            st.wait_stream(main)                 # fork: everything enqueued on `main` so far
-            side.append(st)
-        outs = [None] * len(thunks)
-        for i in range(1, len(thunks)):
-            with torch.cuda.stream(side[i - 1]):
-                outs[i] = thunks[i]()
-        outs[0] = thunks[0]()
-        for i, st in enumerate(side):
-            main.wait_stream(st)                 # join
-            _record_stream(outs[i + 1], main)
-        return outs
+    def group(self):
+        return self.hb.group()
 
     def image_to_nhwc(self, images, out_hw=None):
         return self.hb.image_to_nhwc(images, out_hw)
 
+    # -- convolution -----------------------------------------------------------------
     def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False, want_stats=False):
-        return self.hb.Conv2dFn.apply(x, weight, bias, stride, padding, dilation, out_f32, want_stats)
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        n = len(xs)
+        ws, bs = _lst(weight, n), _lst(bias, n)
+        spec = tuple((stride, padding, dilation, bool(out_f32), bool(want_stats)) for _ in range(n))
+        flat = []
+        for xi, w, b in zip(xs, ws, bs):
+            flat += [xi, w, b]
+        ys = self.hb.ConvGroupFn.apply(spec, *flat)
+        return list(ys) if multi else ys[0]
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, private_input=False, block=None):
-        """conv -> BatchNorm (+residual, ReLU, mask).  In training the conv epilogue
-        accumulates the batch statistics where the kernel supports it, and the
-        normalisation picks them up instead of re-reading the conv output.
-        private_input: `x` is the output of a BatchNorm+ReLU layer and this conv is its ONLY
-        consumer; block: the residual_link() of the residual block this call belongs to (its conv1
-        call has residual=None and the block input as `x`, its last call has the block input as
-        `residual`).  Both only matter under SSA_FUSE_BWD (hip_backend.py)."""
-        hb = self.hb
-        if hb._FUSE_BWD and torch.is_grad_enabled():
-            if private_input:
-                hb._NEXT_CONV_IN_LINK[0] = getattr(x, "_ssa_bn_link", None)
-            if block is not None:
-                if residual is None:
-                    hb._NEXT_CONV_RES_LINK[0] = block
-                else:
-                    hb._NEXT_BN_RES_LINK[0] = block
-        y = self.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], conv.dilation[0], False,
-                        bool(bn.training))
-        return self.batch_norm_act(y, bn, residual, relu, post)
-
-    def residual_link(self):
-        """Hand-over object for one residual block (None unless SSA_FUSE_BWD)."""
-        return self.hb.ResLink() if (self.hb._FUSE_BWD and torch.is_grad_enabled()) else None
+    def _bn_meta(self, bn, relu):
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        # training: the running statistics are updated by end_forward() (deferred, one launch, in
+        # issue order: the passes over one layer are problems of the same grouped launch)
+        return self.hb.BnMeta(0.1 if bn.momentum is None else bn.momentum, bn.eps, bool(bn.training), bool(relu),
+                              getattr(bn, "sync", False), self.hb._BN_UPDATES.slot(bn) if track else None,
+                              None if bn.training else bn.running_mean, None if bn.training else bn.running_var)
 
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
-        track = bn.training and bn.track_running_stats and bn.running_mean is not None
-        link = None
-        if self.hb._FUSE_BWD and bn.training and relu and residual is None and post is None and \
-                torch.is_grad_enabled():
-            link = self.hb._NEXT_BN_OUT_LINK[0] = self.hb.BnLink()
-        # training: the running statistics are updated by end_forward() (deferred, in
-        # issue order) because passes over the same layer run on concurrent streams
-        z = self.hb.BatchNormActFn.apply(
-            x, bn.weight, bn.bias, residual, post,
-            None if bn.training else bn.running_mean, None if bn.training else bn.running_var, None,
-            0.1 if bn.momentum is None else bn.momentum, bn.eps, bn.training, relu,
-            getattr(bn, "sync", False), self.hb._BN_UPDATES.slot(bn) if track else None)
-        if link is not None and link.x is not None:
-            z._ssa_bn_link = link          # picked up by the conv that consumes z alone (private_input=True)
-        return z
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        n = len(xs)
+        zs = self._bn_group(xs, _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n))
+        return zs if multi else zs[0]
+
+    def _bn_group(self, xs, bns, ress, relus, posts):
+        metas = tuple(self._bn_meta(b, r) for b, r in zip(bns, relus))
+        flat = []
+        for xi, b, r, po in zip(xs, bns, ress, posts):
+            flat += [xi, b.weight, b.bias, r, po]
+        return list(self.hb.BnActGroupFn.apply(metas, *flat))
+
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+        """conv -> BatchNorm (+residual, ReLU, mask).  In training the conv epilogue accumulates
+        the batch statistics, and the normalisation picks them up instead of re-reading the
+        conv output.  Lists = independent problems (grouped launches)."""
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        zs = self._conv_bn_group(_lst(conv, len(xs)), _lst(bn, len(xs)), xs, residual, relu, post)
+        return zs if multi else zs[0]
+
+    def _conv_bn_group(self, convs, bns, xs, residual=None, relu=False, post=None):
+        n = len(xs)
+        spec = tuple((c.stride[0], c.padding[0], c.dilation[0], False, bool(b.training)) for c, b in zip(convs, bns))
+        flat = []
+        for xi, c in zip(xs, convs):
+            flat += [xi, c.weight, c.bias]
+        ys = self.hb.ConvGroupFn.apply(spec, *flat)
+        return self._bn_group(list(ys), bns, _lst(residual, n), _lst(relu, n), _lst(post, n))
+
+    def basic_block(self, blocks, xs):
+        ok = torch.is_grad_enabled() and all(
+            b.bn1.training and b.bn2.training and b.conv1.bias is None and b.conv2.bias is None and
+            b.conv1.stride[0] == 1 and b.conv1.kernel_size[0] == 3 and b.conv1.padding[0] == 1 and
+            b.conv1.dilation[0] == 1 and b.conv1.in_channels == b.conv2.out_channels and
+            b.conv1.weight.requires_grad for b in blocks)
+        if not ok:
+            mid = self._conv_bn_group([b.conv1 for b in blocks], [b.bn1 for b in blocks], list(xs), relu=True)
+            return self._conv_bn_group([b.conv2 for b in blocks], [b.bn2 for b in blocks], mid, residual=list(xs), relu=True)
+        metas = tuple((self._bn_meta(b.bn1, True), self._bn_meta(b.bn2, True)) for b in blocks)
+        flat = []
+        for b, x in zip(blocks, xs):
+            flat += [x, b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias]
+        return list(self.hb.BasicBlockGroupFn.apply(metas, *flat))
 
     def end_forward(self):
         self.hb.end_forward()
 
     def flush_backward(self):
         """Deferred backward work whose results another end-of-backward callback is about to read."""
-        self.hb.flush_wgrad_reduces()
+        self.hb.flush_wgrads()
 
     def sum_act(self, tensors, relu=True):
-        return self.hb.SumActFn.apply(relu, *tensors)
+        multi = bool(tensors) and _is_list(tensors[0])
+        probs = [list(t) for t in tensors] if multi else [list(tensors)]
+        flat = [t for p in probs for t in p]
+        zs = self.hb.SumActGroupFn.apply(bool(relu), tuple(len(p) for p in probs), *flat)
+        return list(zs) if multi else zs[0]
 
     def bilinear(self, x, size, out_f32=False):
-        if tuple(x.shape[1:3]) == tuple(size) and (x.dtype == torch.float32) == bool(out_f32 or x.dtype == torch.float32):
-            return x
-        return self.hb.BilinearFn.apply(x, int(size[0]), int(size[1]), bool(out_f32))
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        sizes = [tuple(s) for s in size] if (multi and hasattr(size[0], "__len__")) else [tuple(size)] * len(xs)
+        outs = [None] * len(xs)
+        todo, spec = [], []
+        for i, (t, s) in enumerate(zip(xs, sizes)):
+            if tuple(t.shape[1:3]) == s and (t.dtype == torch.float32) == bool(out_f32 or t.dtype == torch.float32):
+                outs[i] = t
+            else:
+                todo.append(i)
+                spec.append((int(s[0]), int(s[1]), bool(out_f32)))
+        if todo:
+            ys = self.hb.BilinearGroupFn.apply(tuple(spec), *[xs[i] for i in todo])
+            for i, y in zip(todo, ys):
+                outs[i] = y
+        return outs if multi else outs[0]
 
     def max_pool3x3s2(self, x):
         return self.hb.MaxPool3x3s2Fn.apply(x)
@@ -185,20 +236,6 @@ class HipBackend:
 
     def bce_rmi(self, logits, labels, do_rmi, weight_lambda=0.5):
         return self.hb.BceRmiFn.apply(logits, labels, bool(do_rmi), weight_lambda)
-
-
-def _record_stream(obj, stream):
-    """Tell the caching allocator that tensors produced on a side stream are
-    consumed on `stream` (so their memory is not recycled under that use)."""
-    if torch.is_tensor(obj):
-        if obj.is_cuda:
-            obj.record_stream(stream)
-    elif isinstance(obj, dict):
-        for v in obj.values():
-            _record_stream(v, stream)
-    elif isinstance(obj, (list, tuple)):
-        for v in obj:
-            _record_stream(v, stream)
 
 
 def backend():

@@ -1,20 +1,26 @@
 """Data-parallel training over RCCL/xGMI: one process per GPU.
 
 `DistributedDataParallel` stands in for apex.parallel.DistributedDataParallel
-(network/__init__.py:37-39 of the reference): gradients are averaged over ranks
-with bucketed all-reduces that are launched from autograd hooks while backward
-is still running (reverse-registration order, >= `message_size` elements per
-bucket, as apex's default of 1e7).  `backend='nccl'` is RCCL on ROCm.
-SyncBN lives in semseg_amd.nn.SyncBatchNorm.
+(network/__init__.py:37-39 of the reference): gradients are averaged over ranks.
+On the HIP path the parameter gradients of a step live in the backend's gradient arena
+(hip_backend._GradArena: a few contiguous fp32 chunks in backward order), so the exchange
+is ONE in-place all-reduce (mean) per chunk, enqueued with direct RCCL calls on the compute
+stream at the end of backward -- no flattening copy, no per-parameter hooks, and the same
+captured hipGraph as the single-GPU step.  Gradients that reach a parameter through autograd
+(conv biases; every parameter under the CPU test backend) are collected by hooks and exchanged
+as one flat bucket in an end-of-backward callback.
+SyncBN lives in semseg_amd.nn.SyncBatchNorm; its exchange is `allreduce_bn_sums`.
+`backend='nccl'` is RCCL on ROCm.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
 from torch import nn
 
 # SSA_FORCE_DIST=1: treat a world of ONE rank like a distributed job (SyncBN exchanges and the
-# DDP hooks run, over a 1-rank RCCL communicator).  Lets a one-GPU box exercise the c10d code
+# gradient exchange run, over a 1-rank RCCL communicator).  Lets a one-GPU box exercise the code
 # path -- in particular inside hipGraph capture -- that the multi-GPU runs take.
 _FORCE = os.environ.get("SSA_FORCE_DIST", "0") == "1"
 
@@ -27,21 +33,26 @@ def sync_world(enabled=True, group=None):
     return 0
 
 
-def allreduce_bn_sums(sums, local_count, group=None):
-    """SyncBN exchange (apex.parallel.SyncBatchNorm, config.py:216-222): SUM the
-    per-channel fp64 partial sums over ranks in place and return the global
-    sample count.  Every rank runs the same crop size, so count = local * world.
-    With (sum x, sum x^2) this makes the statistics those of the concatenated
-    global batch; with (sum dy, sum dy*xhat) likewise for the backward."""
-    world = sync_world(True, group)
-    if not world:
-        return float(local_count)
+def _all_reduce_(t, average=False, group=None):
     from . import rccl
-    if rccl.ENABLED and group is None and sums.is_cuda:
-        rccl.comm().all_reduce_sum_(sums)        # one RCCL call on the stream the BN kernels run on
+    if rccl.usable(t, group):
+        rccl.comm().all_reduce_(t, average)      # one RCCL call on the stream the kernels run on
     else:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-    return float(local_count) * world
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            t.div_(dist.get_world_size(group))
+    return t
+
+
+def allreduce_bn_sums(sums, group=None):
+    """SyncBN exchange (apex.parallel.SyncBatchNorm, config.py:216-222): SUM the per-channel fp64
+    partial sums over ranks in place.  Every rank runs the same crop size, so the caller's global
+    count is local * world.  With (sum x, sum x^2) this makes the statistics those of the
+    concatenated global batch; with (sum dy, sum dy*xhat) likewise for the backward.  `sums` may
+    span the partial sums of every problem of a grouped BatchNorm level (one collective)."""
+    if sync_world(True, group):
+        _all_reduce_(sums, False, group)
+    return sums
 
 
 class DistributedDataParallel(nn.Module):
@@ -50,66 +61,47 @@ class DistributedDataParallel(nn.Module):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        self.delay_allreduce = delay_allreduce
         self.active = self.world > 1 or (_FORCE and dist.is_initialized())
-        params = [p for p in module.parameters() if p.requires_grad]
+        self._hooked = []
+        self._callback_queued = False
         if self.active:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=self.group)
-        # buckets in reverse parameter order: the order backward produces grads
-        self.buckets, cur, n = [], [], 0
-        for p in reversed(params):
-            cur.append(p)
-            n += p.numel()
-            if n >= message_size:
-                self.buckets.append(cur)
-                cur, n = [], 0
-        if cur:
-            self.buckets.append(cur)
-        self._bucket_of = {}
-        for bi, b in enumerate(self.buckets):
-            for p in b:
-                self._bucket_of[p] = bi
-        self._pending = [0] * len(self.buckets)
-        self._inflight = []
-        self._callback_queued = False
-        if self.active:
-            for p in params:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+            for p in module.parameters():
+                if p.requires_grad:
+                    p.register_post_accumulate_grad_hook(self._on_grad)
+            from . import hip_backend
+            ref = weakref.ref(self)
+            hip_backend.set_grad_sink(lambda chunks: ref() is not None and ref()._reduce_arena(chunks))
 
     def forward(self, *args, **kwargs):
-        self._pending = [len(b) for b in self.buckets]
-        self._inflight = []
+        self._hooked = []
         self._callback_queued = False
         return self.module(*args, **kwargs)
 
-    # -- autograd-thread side
+    # -- gradients accumulated by the kernels in the backend's arena
+    def _reduce_arena(self, chunks):
+        for buf, used in chunks:
+            if used:
+                _all_reduce_(buf[:used], True, self.group)
+
+    # -- gradients that arrive through autograd (autograd thread)
     def _on_grad(self, p):
+        self._hooked.append(p)
         if not self._callback_queued:
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
             self._callback_queued = True
-        bi = self._bucket_of[p]
-        self._pending[bi] -= 1
-        if self._pending[bi] == 0 and not self.delay_allreduce:
-            self._launch(bi)
-
-    def _launch(self, bi):
-        ps = self.buckets[bi]
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._inflight.append((bi, flat, work))
 
     def _finalize(self):
-        launched = {bi for bi, _, _ in self._inflight}
-        for bi in range(len(self.buckets)):
-            if bi not in launched and all(p.grad is not None for p in self.buckets[bi]):
-                self._launch(bi)
-        for bi, flat, work in self._inflight:
-            work.wait()
-            flat.div_(self.world)
-            off = 0
-            for p in self.buckets[bi]:      # the averaged gradients stay where they are: views of the bucket
-                n = p.numel()
-                p.grad = flat[off:off + n].view_as(p)
-                off += n
-        self._inflight = []
+        ps, self._hooked = self._hooked, []
+        self._callback_queued = False
+        ps = [p for p in ps if p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        _all_reduce_(flat, True, self.group)
+        off = 0
+        for p in ps:                     # the averaged gradients stay where they are: views of the bucket
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n

@@ -1,18 +1,15 @@
-"""Direct RCCL collectives on the compute stream (opt-in: SSA_RCCL_DIRECT=1).
+"""Direct RCCL collectives on the compute stream.
 
-The SyncBN exchange of this path is 1,264 all-reduces of <= 2*720+1 fp64 values per
-training step.  Through torch.distributed each costs a c10d dispatch, a
-stream switch to c10d's communication stream and two event fences; here the same
-`ncclAllReduce` is enqueued directly on the stream the BatchNorm kernels run on --
-one library call, no stream switch, and a plain kernel node when the step is captured
-in a hipGraph.  The communicator is RCCL's own (the librccl.so torch already loaded),
-bootstrapped over the existing torch.distributed process group; `backend="nccl"`
-process groups keep carrying the gradient buckets (they overlap with backward on
-c10d's stream).
-
-Not exercised on hardware yet: a one-rank communicator can be tested on a one-GPU box
-(tests/test_rccl_direct_gpu.py, opt-in), the multi-GPU behaviour only by the driver's
-multi-GPU runs."""
+The SyncBN exchange of this path is one all-reduce of a few thousand fp64 values per grouped
+BatchNorm level (~300 per training step), the gradient exchange one in-place
+all-reduce per gradient-arena chunk.  Through torch.distributed each costs a c10d dispatch, a
+stream switch to c10d's communication stream and two event fences -- and c10d's watchdog thread
+queries events while the step is being captured in a hipGraph, which aborts the capture
+(measured on MI355X, profiles/r02_notes.md).  Here the same `ncclAllReduce` is enqueued
+directly on the stream the kernels run on: one library call, no stream switch, a plain kernel
+node in the captured graph.  The communicator is RCCL's own (the librccl.so torch already
+loaded), bootstrapped over the existing torch.distributed process group.
+SSA_RCCL_DIRECT=0 falls back to torch.distributed collectives (eager steps only)."""
 import ctypes
 import glob
 import os
@@ -20,9 +17,9 @@ import os
 import torch
 import torch.distributed as dist
 
-ENABLED = os.environ.get("SSA_RCCL_DIRECT", "0") == "1"
+ENABLED = os.environ.get("SSA_RCCL_DIRECT", "1") != "0"
 
-NCCL_FLOAT32, NCCL_FLOAT64, NCCL_SUM = 7, 8, 0      # rccl.h: ncclDataType_t / ncclRedOp_t
+NCCL_FLOAT32, NCCL_FLOAT64, NCCL_SUM, NCCL_AVG = 7, 8, 0, 4      # rccl.h: ncclDataType_t / ncclRedOp_t
 
 
 class _UniqueId(ctypes.Structure):
@@ -63,6 +60,7 @@ class DirectComm:
         dist.broadcast_object_list(box, src=0, group=group)
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
         self.comm = ctypes.c_void_p()
+        self.calls = 0                  # collectives issued (bench.py reports them per step)
         self.device = torch.cuda.current_device()
         self._check(self.lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank),
                     "ncclCommInitRank")
@@ -71,13 +69,17 @@ class DirectComm:
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
 
-    def all_reduce_sum_(self, t):
-        """In-place sum over ranks of a dense fp32 / fp64 tensor, enqueued on the current stream."""
+    def all_reduce_(self, t, average=False):
+        """In-place sum (or mean) over ranks of a dense fp32 / fp64 tensor, enqueued on the current stream."""
         dt = {torch.float32: NCCL_FLOAT32, torch.float64: NCCL_FLOAT64}[t.dtype]
         assert t.is_contiguous() and t.is_cuda
-        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, NCCL_SUM, self.comm,
-                                           torch.cuda.current_stream().cuda_stream), "ncclAllReduce")
+        self.calls += 1
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, NCCL_AVG if average else NCCL_SUM,
+                                           self.comm, torch.cuda.current_stream().cuda_stream), "ncclAllReduce")
         return t
+
+    def all_reduce_sum_(self, t):
+        return self.all_reduce_(t, False)
 
     def destroy(self):
         if self.comm:
@@ -86,6 +88,11 @@ class DirectComm:
 
 
 _COMM = None
+
+
+def usable(t, group=None):
+    """Direct RCCL carries this tensor: enabled, default group on the nccl (= RCCL) backend, device memory."""
+    return ENABLED and group is None and t.is_cuda and dist.get_backend() == "nccl"
 
 
 def comm():

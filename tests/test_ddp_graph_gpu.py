@@ -1,7 +1,9 @@
-"""The N > 1 code path of bench.py (SyncBN exchanges + DDP gradient buckets over RCCL) inside a
-captured hipGraph, exercised on ONE GPU with a one-rank RCCL communicator (SSA_FORCE_DIST=1):
-~1,270 c10d collectives are captured into the step graph.  What this cannot show is the
-inter-GPU behaviour of those graph nodes -- only the driver's multi-GPU runs can."""
+"""The N > 1 code path of bench.py (SyncBN exchanges + gradient-arena all-reduce) inside the captured
+hipGraph, exercised on ONE GPU with a one-rank RCCL communicator (SSA_FORCE_DIST=1): the program
+the multi-GPU runs execute -- direct RCCL calls on the compute stream as graph nodes.  What this
+cannot show is the inter-GPU behaviour of those nodes; only the driver's multi-GPU runs can.
+(torch.distributed's own collectives cannot be captured here: c10d's watchdog thread queries
+events during capture and aborts it -- measured in round 2, profiles/r02_call_a.log.)"""
 import json
 import os
 import subprocess
@@ -13,29 +15,29 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# not yet run on hardware (round-1 GPU budget): opt-in until it has
-unverified = pytest.mark.skipif(os.environ.get("SSA_TEST_UNVERIFIED", "0") != "1",
-                                reason="not yet run on hardware (round-1 GPU budget); set SSA_TEST_UNVERIFIED=1")
 
-
-def _bench(extra_env):
-    env = dict(os.environ, SSA_FORCE_DIST="1", **extra_env)
+def _bench(extra_env, extra_args=()):
+    env = dict(os.environ, **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--crop", "256", "--steps", "4", "--warmup",
-                        "1", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, env=env,
-                       timeout=300)
+                        "1", "--no-cpu-baseline", "--no-roofline"] + list(extra_args), capture_output=True, text=True,
+                       env=env, timeout=400)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
-@unverified
-def test_forced_dist_step_captures_with_rccl():
-    eager = _bench({"SSA_DDP_GRAPH": "0"})
-    graph = _bench({"SSA_DDP_GRAPH": "1"})
+def test_forced_dist_step_is_the_single_gpu_program():
+    plain = _bench({"SSA_FORCE_DIST": "0"})
+    dist1 = _bench({"SSA_FORCE_DIST": "1"})
+    eager = _bench({"SSA_FORCE_DIST": "1"}, ["--no-graph"])
+    assert plain["config"]["hipgraph"] is True and dist1["config"]["hipgraph"] is True
     assert eager["config"]["hipgraph"] is False
-    assert graph["config"]["hipgraph"] is True, graph["config"].get("hipgraph_error")
-    le, lg = eager["config"]["loss"], graph["config"]["loss"]
-    print("forced-dist world=1: eager %.2f ms/step loss %.4f | graph %.2f ms/step loss %.4f" % (
-        eager["ms_per_step"], le, graph["ms_per_step"], lg))
-    assert lg == lg and abs(lg - le) <= 0.05 * abs(le)
+    lp, ld, le = plain["config"]["loss"], dist1["config"]["loss"], eager["config"]["loss"]
+    print("world=1: plain %.2f ms/step loss %.4f | forced-dist graph %.2f ms/step loss %.4f | forced-dist eager "
+          "%.2f ms/step loss %.4f" % (plain["ms_per_step"], lp, dist1["ms_per_step"], ld, eager["ms_per_step"], le))
+    # one rank: SyncBN over the world == BatchNorm, mean gradient == gradient -> the same training
+    # trajectory (same seeds, same number of steps) up to the order of fp64 atomics
+    assert ld == ld and abs(ld - lp) <= 0.02 * abs(lp)
+    assert abs(le - lp) <= 0.02 * abs(lp)
+    assert dist1["config"]["collectives_per_step"] < 700

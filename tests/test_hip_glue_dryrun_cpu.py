@@ -17,7 +17,8 @@ import ctypes
 import pytest
 import torch
 
-HOST_ONLY = ("ssa_version", "ssa_bn_stat_replicas", "ssa_conv2d_igemm_tile")
+HOST_ONLY = ("ssa_version", "ssa_bn_stat_replicas", "ssa_conv2d_igemm_tile", "ssa_group_begin", "ssa_group_end",
+             "ssa_group_abort", "ssa_launch_count", "ssa_profile_note")
 
 
 class DryLib:
@@ -102,7 +103,7 @@ def test_train_step_and_eval_glue(name, crit, dry):
     assert not missing, missing[:5]
     for n, p in net.named_parameters():
         assert p.grad.shape == p.shape and p.grad.dtype == torch.float32, n
-    assert dry.calls["ssa_conv2d_wgrad"] + dry.calls["ssa_conv2d_wgrad_head"] > 0
+    assert dry.calls["ssa_conv2d_wgrad"] + dry.calls["ssa_conv2d_wgrad_head"] + dry.calls["ssa_conv2d_wgrad_tile"] > 0
     assert dry.calls["ssa_bn_update_running_batched"] == 1          # one deferred running-stat update per step
     assert dry.calls["ssa_pack_filters_batched"] <= 1
     # second step: the filter cache is warm, nothing is re-packed one by one
@@ -141,76 +142,47 @@ def test_fused_sgd_step_glue_and_filter_cache_refresh(dry):
     assert all("momentum_buffer" in opt.state[p] for p in net.parameters())
 
 
-def test_deferred_wgrad_reduce_glue(dry, monkeypatch):
-    """SSA_DEFER_WGRAD_REDUCE: no per-layer reduce, one batched call per backward, issued before the
-    shadow-gradient merge reads the weight gradients; every parameter still gets its gradient."""
-    from semseg_amd import hip_backend
-    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
-    inputs = _batch()
-    net(inputs).backward()                   # baseline: one reduce per conv weight gradient + the OCR products
-    baseline = dry.calls["ssa_conv2d_wgrad_reduce"]
-    dry.calls.clear()
-    monkeypatch.setattr(hip_backend, "_DEFER_WGRAD_REDUCE", True)
-    order = []
-    real_flush = hip_backend.flush_wgrad_reduces
-    monkeypatch.setattr(hip_backend, "flush_wgrad_reduces",
-                        lambda *a, **k: (order.append(("flush", len(hip_backend._PENDING_REDUCES))), real_flush(*a, **k))[1])
-    import torch as _t
-    real_add = _t._foreach_add_
-    monkeypatch.setattr(_t, "_foreach_add_", lambda *a, **k: (order.append(("merge", 0)), real_add(*a, **k))[1])
-    for step in range(2):
-        net.zero_grad(set_to_none=True)
-        net(inputs).backward()
-        flushed = [n for k, n in order if k == "flush" and n > 0]
-        assert len(flushed) == step + 1
-        # what is still reduced layer by layer (the OCR matrix products) + the batch == the baseline
-        assert dry.calls["ssa_conv2d_wgrad_reduce"] // (step + 1) + flushed[-1] == baseline
-        assert flushed[-1] > 600
-        assert dry.calls["ssa_conv2d_wgrad_reduce_batched"] == step + 1
-        assert not hip_backend._PENDING_REDUCES
-        assert all(p.grad is not None for p in net.parameters())
-    # the flush that found work came before the merge of the 0.5x pass's gradients
-    first_work = next(i for i, (k, n) in enumerate(order) if k == "flush" and n > 0)
-    first_merge = next(i for i, (k, n) in enumerate(order) if k == "merge")
-    assert first_work < first_merge, order[:6]
-
-
-def test_backward_fusion_glue(dry, monkeypatch):
-    """SSA_FUSE_BWD: every conv1 -> bn1 -> relu -> conv2 of a basic block hands bn1's backward sums over
-    from conv2's data-gradient epilogue (no bn_bwd_reduce for those layers), every block without a
-    downsample branch adds the identity gradient in conv1's data-gradient epilogue; all parameters
-    still get gradients, and nothing is left in the hand-over slots."""
+def test_lockstep_grouping_and_gradient_arena_glue(dry):
+    """The HRNet-OCR-MScale step in lockstep: every BasicBlock level is ONE autograd node for all
+    (branch, pass) problems, whose backward takes bn1's sums from conv2's data-gradient epilogue
+    (mode 2) and adds the identity gradient in conv1's (mode 1); weight gradients are queued and
+    reduced ONCE per parameter (both scale passes' splits behind one another) into the gradient
+    arena, which an end-of-backward callback publishes as .grad -- no autograd accumulation."""
     from semseg_amd import hip_backend
     net = _build("ocrnet.HRNet_Mscale", "rmi").train()
     inputs = _batch(2, 128, 128)
-    net(inputs).backward()
-    base_reduce = dry.calls["ssa_bn_bwd_reduce"]
-    base_tile = dry.calls["ssa_conv2d_tile"]
-    assert dry.calls["ssa_conv2d_tile_aux"] == 0
-    dry.calls.clear()
-    monkeypatch.setattr(hip_backend, "_FUSE_BWD", True)
-    net.zero_grad(set_to_none=True)
-    net(inputs).backward()
-    aux = dry.calls["ssa_conv2d_tile_aux"]
+    import torch as _t
+    adds = []
+    real_add = _t._foreach_add_
+    _t._foreach_add_ = lambda *a, **k: (adds.append(len(a[0])), real_add(*a, **k))[1]
+    try:
+        net(inputs).backward()
+    finally:
+        _t._foreach_add_ = real_add
     n_basic = sum(1 for m in net.modules() if type(m).__name__ == "BasicBlock")
     assert n_basic == 104
-    # per scale pass: one mode-2 launch per basic block (conv2's dgrad) + one mode-1 launch per basic
-    # block (conv1's dgrad; none of HRNet's basic blocks has a downsample branch) + layer1's conv2s
-    assert aux >= 2 * 2 * n_basic, aux
-    assert dry.calls["ssa_conv2d_tile"] + aux == base_tile
-    assert base_reduce - dry.calls["ssa_bn_bwd_reduce"] >= 2 * n_basic          # the fused layers skip the reduce pass
-    assert dry.calls["ssa_sum_act"] >= 0
-    assert all(p.grad is not None for p in net.parameters())
-    for slot in (hip_backend._NEXT_BN_OUT_LINK, hip_backend._NEXT_CONV_IN_LINK, hip_backend._NEXT_CONV_RES_LINK,
-                 hip_backend._NEXT_BN_RES_LINK):
-        assert slot[0] is None
-    # eval / no-grad passes create no links
+    # per scale pass one mode-2 and one mode-1 launch per basic block
+    assert dry.calls["ssa_conv2d_tile_aux"] == 2 * 2 * n_basic, dry.calls["ssa_conv2d_tile_aux"]
+    n_conv_w = sum(1 for m in net.modules() if isinstance(m, torch.nn.Conv2d))
+    # one reduce per conv parameter (not per pass) + the OCR matrix products (activations as filters)
+    assert n_conv_w <= dry.calls["ssa_conv2d_wgrad_reduce"] <= n_conv_w + 16, (dry.calls["ssa_conv2d_wgrad_reduce"], n_conv_w)
+    assert not hip_backend._WGRAD_Q and not hip_backend._GRADS.slots and not hip_backend._GRADS.armed
+    assert not adds, "gradients were accumulated by torch"
+    for n, p in net.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.dtype == torch.float32, n
+    # a second backward without zero_grad accumulates into the existing .grad (one multi-tensor add)
+    _t._foreach_add_ = lambda *a, **k: (adds.append(len(a[0])), real_add(*a, **k))[1]
+    try:
+        net(inputs).backward()
+    finally:
+        _t._foreach_add_ = real_add
+    assert len(adds) == 1 and adds[0] > 900
+    # eval / no-grad passes leave nothing queued
     net.eval()
     with torch.no_grad():
         out = net({"images": inputs["images"]})
     assert tuple(out["pred"].shape) == (2, 19, 128, 128)
-    for slot in (hip_backend._NEXT_BN_OUT_LINK, hip_backend._NEXT_CONV_IN_LINK):
-        assert slot[0] is None
+    assert not hip_backend._WGRAD_Q
 
 
 def _dist_worker(rank, world, port, q):
@@ -230,7 +202,6 @@ def _dist_worker(rank, world, port, q):
     _lib._LIB = d
     hip_backend._s = lambda: None
     be = ops.HipBackend()
-    be.concurrency = 0
     ops._set_backend_for_tests(be)
     cfg.MODEL.BNFUNC = snn.SyncBatchNorm
     cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
@@ -238,7 +209,6 @@ def _dist_worker(rank, world, port, q):
     n_bn = sum(1 for m in net.modules() if isinstance(m, snn.SyncBatchNorm))
     ddp = DistributedDataParallel(net)
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
-    assert not be.use_shadow_pass()
     calls = []
     real = dist.all_reduce
     dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
@@ -247,16 +217,15 @@ def _dist_worker(rank, world, port, q):
         ddp({"images": torch.randn(1, 3, 64, 64), "gts": torch.randint(0, 19, (1, 64, 64))}).backward()
         opt.step()
     ok = all(p.grad is not None and p.grad.shape == p.shape for p in net.parameters())
-    q.put((rank, ok, n_bn, len(calls), len(ddp.buckets), sum(p.numel() for p in net.parameters())))
+    q.put((rank, ok, n_bn, len(calls), sum(calls), sum(p.numel() for p in net.parameters())))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
 def test_two_rank_syncbn_ddp_glue():
-    """The N > 1 host path (SyncBatchNorm exchanges inside the BN Functions, DDP hooks and buckets)
-    on the real glue with two gloo ranks: 2 exchanges per SyncBN layer and scale pass and step
-    (forward + backward), one all-reduce per gradient bucket."""
+    """The N > 1 host path (SyncBatchNorm exchanges inside the grouped BN Functions, gradient-arena
+    all-reduce) on the real glue with two gloo ranks."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as sk:
@@ -271,10 +240,10 @@ def test_two_rank_syncbn_ddp_glue():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    for rank, ok, n_bn, n_calls, n_buckets, n_params in got:
+    for rank, ok, n_bn, n_calls, n_elems, n_params in got:
         assert ok
         assert n_bn == 316
-        # per step: (forward + backward) x 2 scale passes x 316 layers -- minus the two layers of the
-        # attention head in the 1.0x pass, whose output two_scale_forward does not use (no backward) --
-        # plus the gradient buckets
-        assert n_calls == 2 * (2 * 2 * n_bn - 2 + n_buckets), (n_calls, n_buckets)
+        # lockstep: ONE SyncBN exchange per grouped BatchNorm level (forward and backward) instead of
+        # one per (layer, pass) = 2 * 2 * 316 = 1,264; plus the gradient arena chunks and the bias bucket
+        assert n_calls // 2 < 700, n_calls
+        assert n_elems // 2 >= n_params

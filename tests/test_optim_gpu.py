@@ -10,17 +10,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 # Run on an MI355X in round 1: the first parametrisation (profiles/r01_optim_gpu_test.log: parameters
-# bit-identical to torch.optim.SGD after step 1, within 7.2e-7 after four steps).  The rest has not
-# run on hardware yet (GPU budget) and is opt-in until it has: SSA_TEST_UNVERIFIED=1.
-unverified = pytest.mark.skipif(os.environ.get("SSA_TEST_UNVERIFIED", "0") != "1",
-                                reason="not yet run on hardware (round-1 GPU budget); set SSA_TEST_UNVERIFIED=1")
 
 SIZES = (1, 3, 7, 19, 4095, 4096, 4097, 720 * 512 * 9, 100003) + tuple(range(5, 5 + 120))   # > 96 tensors: 3 launches
 
 
 @pytest.mark.parametrize("momentum,wd,nesterov", [(0.9, 1e-4, False),
-                                                  pytest.param(0.0, 1e-4, False, marks=unverified),
-                                                  pytest.param(0.9, 0.0, True, marks=unverified)])
+                                                  (0.0, 1e-4, False),
+                                                  (0.9, 0.0, True)])
 def test_fused_sgd_matches_oracle_and_torch(momentum, wd, nesterov):
     from semseg_amd.loss.optimizer import FusedSGD
     from oracle.optim import sgd_step
@@ -64,7 +60,6 @@ def test_fused_sgd_matches_oracle_and_torch(momentum, wd, nesterov):
                                        opt_r.state[q]["momentum_buffer"].cpu().numpy(), rtol=2e-6, atol=2e-6)
 
 
-@unverified
 def test_fused_sgd_step_refreshes_packed_filters():
     """A conv after FusedSGD.step() must see the updated weights: the bf16 operand cache of the HIP
     backend is keyed on the parameter's version counter, which the raw-pointer update has to bump."""
@@ -85,7 +80,6 @@ def test_fused_sgd_step_refreshes_packed_filters():
     assert float(y0.abs().max()) > 0.1 and float(y1.abs().max()) == 0.0
 
 
-@unverified
 def test_fused_sgd_lr_from_device_scalar():
     """sync_lr() is what a captured step relies on: the kernel must read the device scalar."""
     from semseg_amd.loss.optimizer import FusedSGD

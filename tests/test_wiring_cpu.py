@@ -89,29 +89,6 @@ def test_train_step_wiring(oracle_ops):
             assert torch.allclose(v, osd[k], rtol=1e-9, atol=1e-12), k
 
 
-def test_shadow_parameter_gradient_merge(oracle_ops):
-    """The 0.5x pass on detached parameter aliases + one merge at the end of backward
-    (MscaleOCR._shadow_parameters) gives exactly the gradients autograd's own accumulation gives."""
-    from semseg_amd import ops
-    gold = torch.load(os.path.join(G, "mscale_golden.pt"), map_location="cpu", weights_only=False)
-    img = gold["images"].double()
-    grads = []
-    for shadow in (False, True):
-        ops.backend().shadow = shadow
-        try:
-            net, _ = _net(True)
-            net.double()
-            loss = net({"images": img, "gts": gold["gts"]})
-            loss.backward()
-            grads.append((float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters()}))
-        finally:
-            ops.backend().shadow = False
-    assert grads[0][0] == grads[1][0]
-    for n, g in grads[0][1].items():
-        assert torch.allclose(g, grads[1][1][n], rtol=1e-12, atol=1e-14), n
-    assert all(s.grad is None for s in net._shadow[0].values())     # merged and released
-
-
 def test_eval_wiring(oracle_ops):
     gold = torch.load(os.path.join(G, "mscale_golden.pt"), map_location="cpu", weights_only=False)
     net, cfg = _net(False)

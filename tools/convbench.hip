@@ -255,13 +255,13 @@ int main(int argc, char** argv) {
         };
         int rc = 0;
         float us = timeit([&] { rc |= ssa_conv2d_wgrad(&d, dx, ddy, c.Cout, c.Cout, ns_o, part, st);
-                                rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, st); });
+                                rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, 0, st); });
         char nm[40]; snprintf(nm, sizeof nm, "wgrad old s%d", ns_o);
         if (rc) printf("%-22s wgrad old failed rc=%d\n", c.name, rc); else checkw(nm, us);
         CK(hipMemsetAsync(dwo, 0, nw * 4, st));
         rc = 0;
         us = timeit([&] { rc |= ssa_conv2d_wgrad_tile(&d, dx, ddy, c.Cout, c.Cout, ns_t, part, st);
-                          rc |= ssa_conv2d_wgrad_reduce(part, ns_t, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, st); });
+                          rc |= ssa_conv2d_wgrad_reduce(part, ns_t, c.Cout, c.Cout, c.Cin, c.Cin, 3, 3, dwo, 0, st); });
         snprintf(nm, sizeof nm, "wgrad tile s%d", ns_t);
         if (rc) printf("%-22s wgrad tile failed rc=%d\n", c.name, rc); else checkw(nm, us);
         CK(hipFree(ddy)); CK(hipFree(dwr)); CK(hipFree(dwo)); CK(hipFree(part)); CK(hipFree(derr2));
@@ -282,11 +282,11 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(ddy, hdy.data(), hdy.size() * 2, hipMemcpyHostToDevice));
         int rc = 0;
         float us_old = timeit([&] { rc |= ssa_conv2d_wgrad(&d, dx, ddy, c.Cout, c.Cout, ns_o, part, st);
-                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_old, st); });
+                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_o, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_old, 0, st); });
         if (rc) printf("%-22s wgrad old failed rc=%d\n", c.name, rc);
         rc = 0;
         float us_new = timeit([&] { rc |= ssa_conv2d_wgrad_head(&d, dx, ddy, c.Cout, c.Cout, ns_h, part, st);
-                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_h, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_new, st); });
+                                    rc |= ssa_conv2d_wgrad_reduce(part, ns_h, c.Cout, c.Cout, c.Cin, c.Cin, c.K, c.K, dw_new, 0, st); });
         CK(hipMemsetAsync(derr2, 0, 8, st));
         hipLaunchKernelGGL(cmp_f32, dim3((nw + 255) / 256), dim3(256), 0, st, dw_new, dw_old, nw, derr2);
         float he[2]; CK(hipMemcpyAsync(he, derr2, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
