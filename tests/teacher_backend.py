@@ -1,0 +1,317 @@
+"""TEST-ONLY: teacher-forced op-by-op comparison of the HIP path at the network's REAL shapes.
+
+The network code runs on this backend with CPU tensors.  Every call of the public operator surface
+  1. runs the oracle's operator with the product's storage rounding (tests/bf16_emu_backend.py) on the
+     teacher's inputs -> the teacher's output, which is what the network continues with;
+  2. runs the HIP operator (through the C ABI) on THE SAME inputs, uploaded (bf16 tensors are exactly
+     representable, fp32 stay fp32), with GPU mirrors of the layer's parameters;
+  3. compares the two outputs at the one-rounding tolerance of the op-level tests;
+and in the backward pass every op receives the TEACHER's output gradient on both sides and its input
+gradients and parameter gradients are compared the same way.  No error accumulates from op to op, so a
+1 % error of any kernel at any shape the network really uses fails that op -- which the end-to-end
+tests (chaotic random-weight network, bf16 noise floor of ~10 %) cannot see.
+"""
+import torch
+
+from bf16_emu_backend import Bf16EmuBackend
+from semseg_amd.ops import BackendBase, _is_list, _lst
+
+BF16_TOL = (1e-2, 4e-3)        # one bf16 rounding of the output (tests/util.py)
+FUSED_TOL = (2e-2, 6e-3)       # conv+BN / residual block: a 1-ulp flip of the bf16 intermediate, amplified by 1/std
+F32_TOL = (2e-3, 5e-4)         # fp32 outputs from bf16 operands
+GRAD_TOL = (2e-2, 6e-3)        # data gradients (bf16, through BN)
+PARAM_TOL = (1e-2, 4e-3)       # parameter gradients (fp32 sums of bf16 products)
+LOSS_TOL = (1e-4, 1e-4)
+
+
+class Record:
+    def __init__(self):
+        self.rows = []          # (index, op, what, shape, max_err/max_ref, mean_err/mean_ref, tol, ok)
+        self.n_ops = 0
+
+    def add(self, idx, op, what, got, ref, tol):
+        got = got.detach().float().cpu()
+        ref = ref.detach().float().cpu()
+        assert got.shape == ref.shape, (op, what, got.shape, ref.shape)
+        finite = bool(torch.isfinite(got).all())
+        err = (got - ref).abs()
+        scale = float(ref.abs().max())
+        mref = float(ref.abs().mean())
+        rmax = float(err.max()) / (scale + 1e-30)
+        rmean = float(err.mean()) / (mref + 1e-30)
+        if what.startswith("d") and rmax > tol[0]:
+            # gradients through a ReLU mask recomputed from bf16 data: an element whose pre-activation is
+            # within rounding of zero may fall on the other side of the mask than the teacher's and then
+            # differs by its full magnitude; up to 1e-4 of the elements may (tests/util.py:check_close_robust)
+            if float((err > tol[0] * scale).float().mean()) <= 1e-4:
+                rmax = tol[0]
+        ok = finite and (scale == 0.0 and float(err.max()) == 0.0 or (rmax <= tol[0] and rmean <= tol[1]))
+        self.rows.append((idx, op, what, tuple(ref.shape), rmax, rmean, tol, ok))
+
+    def failures(self):
+        return [r for r in self.rows if not r[7]]
+
+    def summary(self, k=12):
+        lines = ["%d ops, %d comparisons, %d failures" % (self.n_ops, len(self.rows), len(self.failures()))]
+        for r in sorted(self.rows, key=lambda r: -(r[4] / r[6][0]))[:k]:
+            lines.append("  op %4d %-14s %-18s %-22s max %.4f (tol %.4f) mean %.4f (tol %.4f) %s" % (
+                r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], "" if r[7] else "FAIL"))
+        return "\n".join(lines)
+
+
+def _hip_dtype(t):
+    d = getattr(t, "_hip_dtype", None)
+    if d is not None:
+        return d
+    # class logits ([..,19]) and attention maps ([..,1]) are fp32 on the HIP path, activations bf16
+    return torch.float32 if (t.dim() == 4 and t.shape[-1] in (1, 19)) or t.dim() == 0 else torch.bfloat16
+
+
+class _TeachFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tb, name, ref_fn, hip_fn, params, tols, *tensors):
+        idx = tb.rec.n_ops
+        tb.rec.n_ops += 1
+        ref_in, hip_in = [], []
+        for t in tensors:
+            if t is None:
+                ref_in.append(None)
+                hip_in.append(None)
+                continue
+            fp = t.is_floating_point()
+            ref_in.append(t.detach().requires_grad_(fp and t.requires_grad))
+            h = t.detach().to(tb.device)
+            if fp and tb.cast:
+                h = h.to(_hip_dtype(t))
+            hip_in.append(h.contiguous().requires_grad_(fp and t.requires_grad))
+        with torch.enable_grad():
+            ref_out = list(ref_fn(ref_in))
+            hip_out = list(hip_fn(hip_in))
+        assert len(ref_out) == len(hip_out), name
+        for k, (r, h) in enumerate(zip(ref_out, hip_out)):
+            tol = F32_TOL if (tols[0] is BF16_TOL and h.dtype == torch.float32) else tols[0]
+            tb.rec.add(idx, name, "out%d" % k, h, r, tol)
+        ctx.pack = (tb, idx, name, ref_in, ref_out, hip_in, hip_out, params, tols)
+        tb._last_dtypes = [h.dtype for h in hip_out]
+        return tuple(r.detach() for r in ref_out)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        tb, idx, name, ref_in, ref_out, hip_in, hip_out, params, tols = ctx.pack
+        sel = [k for k, d in enumerate(dys) if d is not None and ref_out[k].requires_grad]
+        grads = [None] * (6 + len(ref_in))
+        if not sel:
+            return tuple(grads)
+        r_ins = [k for k, t in enumerate(ref_in) if t is not None and t.requires_grad]
+        cpu_params = [p for p, _ in params if p.requires_grad]
+        hip_params = [q for p, q in params if p.requires_grad]
+        rg = torch.autograd.grad([ref_out[k] for k in sel], [ref_in[k] for k in r_ins] + cpu_params,
+                                 [dys[k] for k in sel], allow_unused=True)
+        for q in hip_params:
+            q.grad = None
+        hg = torch.autograd.grad([hip_out[k] for k in sel], [hip_in[k] for k in r_ins] + hip_params,
+                                 [dys[k].to(tb.device).to(hip_out[k].dtype) for k in sel], allow_unused=True)
+        if tb.device != "cpu":
+            torch.cuda.synchronize()
+        for j, k in enumerate(r_ins):
+            if rg[j] is None:
+                continue
+            assert hg[j] is not None, (name, "input %d got no gradient on the HIP side" % k)
+            tol = F32_TOL if (name == "bilinear" and hip_in[k].dtype == torch.float32) else tols[1]
+            tb.rec.add(idx, name, "din%d" % k, hg[j], rg[j], tol)
+            grads[6 + k] = rg[j]
+        for j, (p, q) in enumerate(zip(cpu_params, hip_params)):
+            r = rg[len(r_ins) + j]
+            h = hg[len(r_ins) + j]
+            if h is None:
+                h = q.grad                   # published by the gradient arena at the end of the inner backward
+            if r is None:
+                continue
+            assert h is not None, (name, "parameter got no gradient on the HIP side", tuple(p.shape))
+            tb.rec.add(idx, name, "dparam%s" % (tuple(p.shape),), h, r, PARAM_TOL)
+        return tuple(grads)
+
+
+class TeacherBackend(BackendBase):
+    name = "teacher-forced"
+    act_dtype = torch.float32
+
+    def __init__(self, cpu_net, hip_net, device="cuda"):
+        """device='cpu': self-test of this harness -- the 'HIP' side is a second emulation backend on
+        CPU mirrors (tests/test_teacher_cpu.py), every comparison must then come out exact."""
+        from semseg_amd import ops
+        self.emu = Bf16EmuBackend()
+        self.device = device
+        self.cast = device != "cpu"
+        self.hip = ops.HipBackend() if device != "cpu" else Bf16EmuBackend()
+        self.rec = Record()
+        self._anchor = torch.zeros((), requires_grad=True)
+        self.mod = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_modules(), hip_net.named_modules())}
+        self.par = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_parameters(), hip_net.named_parameters())}
+
+    # -- plumbing
+    def _pp(self, *ps):
+        return [(p, self.par[id(p)]) for p in ps if p is not None]
+
+    def _mod_params(self, mods):
+        out = []
+        for m in mods:
+            out += self._pp(*[p for p in m.parameters(recurse=False)])
+        seen, uniq = set(), []
+        for p, q in out:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append((p, q))
+        return uniq
+
+    def _teach(self, name, ref_fn, hip_fn, tensors, params=(), tols=(BF16_TOL, GRAD_TOL)):
+        # the anchor keeps every op on the autograd graph (the first conv's input needs no gradient,
+        # and the layer parameters are not inputs of the teacher node)
+        outs = _TeachFn.apply(self, name, lambda t: ref_fn(t[:-1]), lambda t: hip_fn(t[:-1]), list(params), tols,
+                              *(list(tensors) + [self._anchor]))
+        for o, d in zip(outs, self._last_dtypes):
+            o._hip_dtype = d
+        return list(outs)
+
+    def begin_step(self, device=None):
+        self.hip.begin_step(torch.device(self.device))
+
+    def end_forward(self):
+        self.hip.end_forward()
+
+    def image_to_nhwc(self, images, out_hw=None):
+        ref = self.emu.image_to_nhwc(images, out_hw)
+        got = self.hip.image_to_nhwc(images.to(self.device), out_hw)
+        self.rec.add(self.rec.n_ops, "image_to_nhwc", "out0", got, ref, BF16_TOL)
+        self.rec.n_ops += 1
+        ref._hip_dtype = torch.bfloat16
+        return ref
+
+    # -- list-aware public surface
+    def conv2d(self, x, weight, bias, stride, padding, dilation, out_f32=False, want_stats=False):
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        n = len(xs)
+        ws, bs = _lst(weight, n), _lst(bias, n)
+        hw = [self.par[id(w)] for w in ws]
+        hb_ = [None if b is None else self.par[id(b)] for b in bs]
+        outs = self._teach(
+            "conv2d",
+            lambda t: self.emu.conv2d(t, ws, bs, stride, padding, dilation, out_f32),
+            lambda t: self.hip.conv2d(t, hw, hb_, stride, padding, dilation, out_f32),
+            xs, self._pp(*(ws + bs)), (F32_TOL if out_f32 else BF16_TOL, GRAD_TOL))
+        return outs if multi else outs[0]
+
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        n = len(xs)
+        convs, bns, ress, relus, posts = _lst(conv, n), _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n)
+        hconvs, hbns = [self.mod[id(c)] for c in convs], [self.mod[id(b)] for b in bns]
+        hposts = [None if p is None else p.to(self.device) for p in posts]
+        outs = self._teach(
+            "conv_bn_act",
+            lambda t: self.emu.conv_bn_act(convs, bns, t[:n], t[n:], relus, posts),
+            lambda t: self.hip.conv_bn_act(hconvs, hbns, t[:n], t[n:], relus, hposts),
+            xs + ress, self._mod_params(convs + bns), (FUSED_TOL, GRAD_TOL))
+        return outs if multi else outs[0]
+
+    def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        n = len(xs)
+        bns, ress, relus, posts = _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n)
+        hbns = [self.mod[id(b)] for b in bns]
+        hposts = [None if p is None else p.to(self.device) for p in posts]
+        outs = self._teach(
+            "batch_norm_act",
+            lambda t: self.emu.batch_norm_act(t[:n], bns, t[n:], relus, posts),
+            lambda t: self.hip.batch_norm_act(t[:n], hbns, t[n:], relus, hposts),
+            xs + ress, self._mod_params(bns), (BF16_TOL, GRAD_TOL))
+        return outs if multi else outs[0]
+
+    def basic_block(self, blocks, xs):
+        hblocks = [self.mod[id(b)] for b in blocks]
+        mods = []
+        for b in blocks:
+            mods += [b.conv1, b.bn1, b.conv2, b.bn2]
+        return self._teach("basic_block", lambda t: self.emu.basic_block(blocks, t),
+                           lambda t: self.hip.basic_block(hblocks, t), list(xs), self._mod_params(mods),
+                           (FUSED_TOL, (3e-2, 1e-2)))
+
+    def sum_act(self, tensors, relu=True):
+        multi = bool(tensors) and _is_list(tensors[0])
+        probs = [list(t) for t in tensors] if multi else [list(tensors)]
+        counts = [len(p) for p in probs]
+
+        def split(t):
+            out, off = [], 0
+            for c in counts:
+                out.append(t[off:off + c])
+                off += c
+            return out
+        outs = self._teach("sum_act", lambda t: self.emu.sum_act(split(t), relu), lambda t: self.hip.sum_act(split(t), relu),
+                           [t for p in probs for t in p])
+        return outs if multi else outs[0]
+
+    def bilinear(self, x, size, out_f32=False):
+        multi = _is_list(x)
+        xs = list(x) if multi else [x]
+        sizes = [tuple(s) for s in size] if (multi and hasattr(size[0], "__len__")) else [tuple(size)] * len(xs)
+        todo = [i for i, (t, s) in enumerate(zip(xs, sizes)) if tuple(t.shape[1:3]) != s]
+        outs = list(xs)
+        if todo:
+            f32 = [out_f32 or _hip_dtype(xs[i]) == torch.float32 for i in todo]
+            ys = self._teach("bilinear", lambda t: self.emu.bilinear(t, [sizes[i] for i in todo], out_f32),
+                             lambda t: self.hip.bilinear(t, [sizes[i] for i in todo], out_f32), [xs[i] for i in todo],
+                             (), (BF16_TOL, GRAD_TOL))
+            for i, y, f in zip(todo, ys, f32):
+                outs[i] = y
+        return outs if multi else outs[0]
+
+    # -- single-problem ops
+    def _one(self, name, fn_name, tensors, tols=(BF16_TOL, GRAD_TOL), extra=()):
+        return self._teach(name, lambda t: [getattr(self.emu, fn_name)(*t, *extra)],
+                           lambda t: [getattr(self.hip, fn_name)(*t, *extra)], tensors, (), tols)[0]
+
+    def max_pool3x3s2(self, x):
+        return self._one("max_pool3x3s2", "max_pool3x3s2", [x])
+
+    def global_avg_pool(self, x):
+        return self._one("global_avg_pool", "global_avg_pool", [x])
+
+    def cat(self, tensors):
+        y = torch.cat(tensors, dim=3)
+        y._hip_dtype = _hip_dtype(tensors[0])
+        return y
+
+    def to_act(self, x):
+        y = self.emu.to_act(x)
+        y._hip_dtype = torch.bfloat16
+        return y
+
+    def ocr_gather(self, feats, logits):
+        y = self._one("ocr_gather", "ocr_gather", [feats, logits], ((1e-2, 4e-3), (2e-2, 8e-3)))
+        y._hip_dtype = torch.float32
+        return y
+
+    def ocr_attention(self, q, k, v, scale):
+        for t in (k, v):
+            if not hasattr(t, "_hip_dtype"):
+                t._hip_dtype = torch.bfloat16
+        return self._one("ocr_attention", "ocr_attention", [q, k, v], ((2e-2, 8e-3), (3e-2, 1.5e-2)), (scale,))
+
+    def sigmoid(self, x):
+        return self._one("sigmoid", "sigmoid", [x], ((1e-5, 1e-5), (1e-4, 1e-4)))
+
+    def bcast_mul(self, a, x):
+        return self._one("bcast_mul", "bcast_mul", [a, x], ((1e-5, 1e-5), (1e-4, 1e-4)))
+
+    def attn_blend(self, lo, a, hi):
+        return self._one("attn_blend", "attn_blend", [lo, a, hi], ((1e-5, 1e-5), (1e-4, 1e-4)))
+
+    def cross_entropy(self, logits, labels, ignore_index):
+        return self._one("cross_entropy", "cross_entropy", [logits, labels], ((1e-5, 1e-5), (1e-4, 1e-4)), (ignore_index,))
+
+    def bce_rmi(self, logits, labels, do_rmi, weight_lambda=0.5):
+        return self._one("bce_rmi", "bce_rmi", [logits, labels], (LOSS_TOL, (2e-3, 1e-3)), (do_rmi, weight_lambda))

@@ -13,7 +13,7 @@ weights, same inputs).  With
     e_hip[i] = |hip_i - oracle_i| / |oracle_i|   (L2 over the tensor, op i of ~1400)
     e_emu[i] = |emu_i - oracle_i| / |oracle_i|
 the tests assert
-  * op by op (eval):  e_hip[i] <= 1.5 * e_emu[i] + 5e-3 for EVERY op output -- a
+  * op by op (eval):  e_hip[i] <= 1.5 * e_emu[i] + 5e-3 for EVERY tensor the operator surface returns -- a
     wrong kernel at any of the network's real shapes shows up as a jump at its
     index that the emulation does not have;
   * outputs (eval):   same rule for pred / pred_05x / pred_10x / attn_05x, and
@@ -127,7 +127,7 @@ def test_eval_op_by_op(setup):
                sd, images, gts, False)
     hip = _run(traced(ops.HipBackend(), lambda i, n, y: hip_err.append(_rel(y.detach().float().cpu(), ref_log[i]))),
                sd, images, gts, False, device="cuda")
-    assert len(ref_log) == len(emu_err) == len(hip_err) > 1000
+    assert len(ref_log) == len(emu_err) == len(hip_err) > 400        # tensors returned by the (grouped) public ops
     worst = max(range(len(hip_err)), key=lambda i: hip_err[i] - 1.5 * emu_err[i])
     print("ops traced %d; largest excess at op %d (%s %s): hip %.4f emu %.4f" % (
         len(hip_err), worst, names[worst], tuple(ref_log[worst].shape), hip_err[worst], emu_err[worst]))

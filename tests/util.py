@@ -31,6 +31,19 @@ def check_close(name, got, ref, rel_max=1e-2, rel_mean=4e-3):
     assert mean_err <= rel_mean * mean_ref + 1e-30, "%s: mean err %.4g > %.4g" % (name, mean_err, rel_mean * mean_ref)
 
 
+def check_close_robust(name, got, ref, rel_max=1e-2, rel_mean=4e-3, outliers=1e-4):
+    """check_close for gradients that pass through a ReLU mask recomputed from bf16 data: where the
+    pre-activation is within rounding of zero the mask may fall on the other side than the oracle's, and
+    such an element's gradient differs by its full magnitude.  At most `outliers` of the elements may
+    exceed the max-error bound (a wrong tile edge or channel block is orders of magnitude more)."""
+    assert torch.isfinite(got.detach().float()).all(), name + ": non-finite output"
+    mx, scale, mean_err, mean_ref = report(name, got, ref)
+    err = (got.detach().float().cpu() - ref.detach().float().cpu()).abs()
+    frac = float((err > rel_max * scale).float().mean())
+    assert frac <= outliers, "%s: %.3g of the elements exceed %.4g" % (name, frac, rel_max * scale)
+    assert mean_err <= rel_mean * mean_ref + 1e-30, "%s: mean err %.4g > %.4g" % (name, mean_err, rel_mean * mean_ref)
+
+
 def nhwc(t):
     """NCHW -> NHWC contiguous"""
     return t.permute(0, 2, 3, 1).contiguous()
