@@ -15,10 +15,14 @@ time, so `train.py`, `config.py` and `scripts/*.yml` run unchanged:
         -> semseg_amd.nn.SyncBatchNorm / semseg_amd.parallel.DistributedDataParallel /
            a bf16 no-op amp shim     (config.py:218-220, network/__init__.py:37-39, train.py:381,504)
 
-After the reference's `assert_and_infer_cfg(args)` has run, call
-`sync_config()` so our cfg mirrors the fields the hot path reads.
+Configuration: the model factories (`--arch` targets), `get_loss` and `get_optimizer` registered by
+`install()` re-read the reference's global `cfg` every time they are called (`sync_config()`), so the
+values `assert_and_infer_cfg(args)` and `datasets.setup_loaders(args)` (NUM_CLASSES, train.py:338-341)
+put there are the ones the modules are built with -- train.py needs no extra call.
 """
 import contextlib
+import functools
+import inspect
 import sys
 import types
 
@@ -51,6 +55,17 @@ def install(replace_apex=True):
         sys.modules["apex"] = apex
         sys.modules["apex.parallel"] = par
         sys.modules["apex.amp"] = apex.amp
+    for mod in (ocrnet, deepv3, mscale, mscale2):
+        for fname, fn in list(vars(mod).items()):
+            if inspect.isfunction(fn) and fn.__module__ == mod.__name__ and not fname.startswith("_") and \
+                    "num_classes" in inspect.signature(fn).parameters and not getattr(fn, "_ssa_synced", False):
+                setattr(mod, fname, _synced(fn))
+    for mod, names in ((criteria, ("get_loss",)), (optimizer, ("get_optimizer",))):
+        for fname in names:
+            fn = getattr(mod, fname)
+            if not getattr(fn, "_ssa_synced", False):
+                setattr(mod, fname, _synced(fn))
+    loss.get_loss, loss.get_optimizer = criteria.get_loss, optimizer.get_optimizer
     for name, mod in (("network.ocrnet", ocrnet), ("network.hrnetv2", hrnetv2),
                       ("network.ocr_utils", ocr_utils), ("network.utils", nutils),
                       ("network.mynn", mynn), ("network.deepv3", deepv3), ("network.mscale", mscale),
@@ -58,6 +73,17 @@ def install(replace_apex=True):
                       ("loss.utils", criteria), ("loss.rmi", criteria), ("loss.optimizer", optimizer)):
         sys.modules[name] = mod
     return network, loss
+
+
+def _synced(fn):
+    """fn with our cfg refreshed from the reference's first (when the reference's config is loaded)."""
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        if "config" in sys.modules and hasattr(sys.modules["config"], "assert_and_infer_cfg"):
+            sync_config()
+        return fn(*a, **k)
+    wrapper._ssa_synced = True
+    return wrapper
 
 
 def sync_config():
