@@ -449,41 +449,43 @@ struct ConvWgradTr {
 // Workgroup (co, k-chunk of 64): 64 k-columns x 4 split lanes; each thread sums
 // every 4th split (coalesced 256-byte rows), the 4 lanes meet in LDS, and the
 // chunk is written to its OIHW positions.  k = (kh,kw,ci) -> (ci,kh,kw).
+// One workgroup per output channel co: sums the splits of partial[.][co][k] for every k (coalesced:
+// consecutive threads read consecutive k), transposes k = (kh,kw,ci) -> (ci,kh,kw) through LDS and
+// writes -- or adds to -- the channel's contiguous run of the OIHW gradient with unit stride.
 struct WgradReduceK {
   struct Args { const float* partial; float* dw; int nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, accumulate; };
   static constexpr int NT = 256;
-  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
-    __shared__ float sh[4][64];
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
+    extern __shared__ float sh[];                 // [Cin * taps] in OIHW order
     const float* __restrict__ partial = a.partial;
-    float* __restrict__ dw = a.dw;
-    const int nsplit = a.nsplit, cout_pad = a.cout_pad, Cin_pad = a.Cin_pad, Cin = a.Cin;
+    const int nsplit = a.nsplit, Cin_pad = a.Cin_pad, Cin = a.Cin;
     const int co = bx;
     const int taps = a.KH * a.KW;
     const int Kflat = taps * Cin_pad;
-    const int kk = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int k = by * 64 + kk;
-    const long split_stride = (long)cout_pad * Kflat;
-    float s0 = 0.f, s1 = 0.f;
-    if (k < Kflat) {
-      const float* src = partial + (long)co * Kflat + k;
-      int sp = sl;
-      for (; sp + 4 < nsplit; sp += 8) {
+    const long split_stride = (long)a.cout_pad * Kflat;
+    const float* src0 = partial + (long)co * Kflat;
+    for (int k = threadIdx.x; k < Kflat; k += NT) {
+      const float* src = src0 + k;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int sp = 0;
+      for (; sp + 3 < nsplit; sp += 4) {
         s0 += src[(long)sp * split_stride];
-        s1 += src[(long)(sp + 4) * split_stride];
+        s1 += src[(long)(sp + 1) * split_stride];
+        s2 += src[(long)(sp + 2) * split_stride];
+        s3 += src[(long)(sp + 3) * split_stride];
       }
-      if (sp < nsplit) s0 += src[(long)sp * split_stride];
-    }
-    sh[sl][kk] = s0 + s1;
-    __syncthreads();
-    if (sl == 0 && k < Kflat) {
-      const float v = (sh[0][kk] + sh[1][kk]) + (sh[2][kk] + sh[3][kk]);
+      for (; sp < nsplit; ++sp) s0 += src[(long)sp * split_stride];
       const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
-      if (ci < Cin) {
-        float* dst = dw + ((long)co * Cin + ci) * taps + tap;
-        // accumulate: dw is the layer's slice of the step's gradient arena (cleared once per step);
-        // one reduce job per layer and launch, so the read-modify-write has no concurrent writer
-        *dst = a.accumulate ? *dst + v : v;
-      }
+      if (ci < Cin) sh[ci * taps + tap] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    float* __restrict__ dst = a.dw + (long)co * Cin * taps;
+    // accumulate: dw is the layer's slice of the step's gradient arena (cleared once per step);
+    // one reduce job per layer and launch, so the read-modify-write has no concurrent writer
+    if (a.accumulate) {
+      for (int i = threadIdx.x; i < Cin * taps; i += NT) dst[i] += sh[i];
+    } else {
+      for (int i = threadIdx.x; i < Cin * taps; i += NT) dst[i] = sh[i];
     }
   }
 };
@@ -617,6 +619,16 @@ constexpr TileChoice kFwdTiles[] = {
     {3, 256, 32, 0.55f},  {4, 64, 64, 0.50f},  {5, 128, 64, 0.75f}};
 
 int choose_fwd_tile(long M, int N) {
+  // Inside a group bracket the launch gets its parallelism from all the problems of the level: pick the
+  // tile for efficiency (largest N block that N fills), not to spread ONE problem over 256 CUs -- and
+  // problems of one level then share kernel instantiations.  SSA_GROUP_UNIFY=0 keeps the cost model.
+  static const bool unify = !(getenv("SSA_GROUP_UNIFY") && atoi(getenv("SSA_GROUP_UNIFY")) == 0);
+  if (unify && ssa::group_state().depth > 0 && M >= 256) {
+    if (N > 96) return 0;       // 128 x 128
+    if (N > 64) return 2;       // 128 x 96
+    if (N > 32) return 5;       // 128 x 64
+    return 3;                   // 256 x 32
+  }
   int best = 0;
   double best_cost = 1e300;
   for (const TileChoice& t : kFwdTiles) {
@@ -788,9 +800,10 @@ int ssa_conv2d_wgrad(const ssa_conv_desc* dp, const void* x, const void* dy, int
 int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad, int Cout, int Cin_pad,
                             int Cin, int KH, int KW, float* dw_oihw, int accumulate, void* stream) {
   if (!partial || !dw_oihw || Cout > cout_pad || Cin > Cin_pad || nsplit < 1) return SSA_EINVAL;
-  const int Kflat = KH * KW * Cin_pad;
+  const size_t lds = (size_t)Cin * KH * KW * sizeof(float);
+  if (lds > 160 * 1024) return SSA_EUNSUPPORTED;
   WgradReduceK::Args a{partial, dw_oihw, nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, accumulate};
-  return ssa::submit<WgradReduceK>(a, Cout, (Kflat + 63) / 64, 0, (hipStream_t)stream);
+  return ssa::submit<WgradReduceK>(a, Cout, 1, lds, (hipStream_t)stream);
 }
 
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job, void* stream) {

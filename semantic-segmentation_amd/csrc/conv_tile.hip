@@ -38,6 +38,7 @@
 // instantiation become one launch.
 #include "common.h"
 #include "group.h"
+#include <stdlib.h>
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -327,10 +328,14 @@ int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const 
 
 // tile shape by image width: TW = 32 where the image is at least 32 wide.
 // big: two MFMA row blocks per wave (256 pixels per workgroup) where LDS allows.
+// grouped launches: 32-pixel-wide tiles down to 16-pixel-wide images (half the lanes of such a tile idle,
+// but the 0.5x pass of the 192/384-channel branches then shares the launch of the 1.0x pass)
+static thread_local bool g_wide_tiles = false;
+
 template <int CK, int KS, int NB, int TPC, bool BIG_OK, bool NARROW_OK = true>
 int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
                   double* stats, hipStream_t s, bool want_big, const AuxArgs& ax) {
-  if (d.W >= 32 || !NARROW_OK) {
+  if (d.W >= 32 || !NARROW_OK || (g_wide_tiles && d.W >= 16)) {
     if constexpr (BIG_OK) {
       if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s, ax);
     }
@@ -358,9 +363,17 @@ int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const 
   // >= 512 tiles, where both n-blocks in one workgroup save the second halo read.
   // cfg >= 0 (benchmark knob): bit 0 = 128-pixel tile, bit 1 = one n-block per workgroup.
   const long tiles128 = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
-  const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && tiles128 >= 512) ? 0 : 2)) : d.cfg;
+  // Inside a group bracket (group.h) the problems of a depth level share launches only if they share
+  // the kernel instantiation, and the launch gets its parallelism from all of them: the variant is
+  // then chosen by the channel count alone (48 channels: both n-blocks per workgroup whatever the tile
+  // count), so that the 1.0x and the 0.5x pass of a layer -- and the 192- and 384-channel branches --
+  // leave as ONE launch.  SSA_GROUP_UNIFY=0 keeps the per-problem choice.
+  static const bool unify = !(getenv("SSA_GROUP_UNIFY") && atoi(getenv("SSA_GROUP_UNIFY")) == 0);
+  const bool grouped = unify && ssa::group_state().depth > 0 && d.cfg < 0;
+  const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && (tiles128 >= 512 || grouped)) ? 0 : 2)) : d.cfg;
   const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
   const bool split_n = (cfg & 2) != 0;
+  g_wide_tiles = grouped;
   switch (d.Cin) {
     case 48:
       if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);

@@ -413,6 +413,15 @@ int ssa_ce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
+  {   // the [NT][C] fp32 tile exceeds the default 64 KB of dynamic LDS from 65 classes (Mapillary) on
+    static size_t allowed = 64 * 1024;
+    const size_t need = (size_t)NT * C * sizeof(float);
+    if (need > allowed) {
+      e = hipFuncSetAttribute((const void*)pixel_loss_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+      if (e != hipSuccess) return (int)e;
+      allowed = need;
+    }
+  }
   hipLaunchKernelGGL(pixel_loss_kernel<0>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
                      s, logits, ld, labels, P, C, ignore_index, acc, dlogits);
   SSA_LAUNCH_CHECK();
@@ -425,6 +434,15 @@ int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int 
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
+  {   // the [NT][C] fp32 tile exceeds the default 64 KB of dynamic LDS from 65 classes (Mapillary) on
+    static size_t allowed = 64 * 1024;
+    const size_t need = (size_t)NT * C * sizeof(float);
+    if (need > allowed) {
+      e = hipFuncSetAttribute((const void*)pixel_loss_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+      if (e != hipSuccess) return (int)e;
+      allowed = need;
+    }
+  }
   hipLaunchKernelGGL(pixel_loss_kernel<1>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
                      s, logits, ld, labels, P, C, 0, acc, dlogits);
   SSA_LAUNCH_CHECK();

@@ -54,6 +54,7 @@ class DistributedSampler(Sampler):
         self.epoch = epoch
 
     def set_num_samples(self):
-        n = len(self.dataset)
-        self.num_samples = int(math.ceil(n / self.num_replicas)) if self.pad else n // self.num_replicas
+        """datasets/sampler.py:108-110: after build_epoch() changed the dataset -- always the ceiling,
+        whatever `pad` was at construction (the reference's own behaviour)."""
+        self.num_samples = int(math.ceil(len(self.dataset) * 1.0 / self.num_replicas))
         self.total_size = self.num_samples * self.num_replicas

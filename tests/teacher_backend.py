@@ -17,10 +17,14 @@ from bf16_emu_backend import Bf16EmuBackend
 from semseg_amd.ops import BackendBase, _is_list, _lst
 
 BF16_TOL = (1e-2, 4e-3)        # one bf16 rounding of the output (tests/util.py)
-FUSED_TOL = (2e-2, 6e-3)       # conv+BN / residual block: a 1-ulp flip of the bf16 intermediate, amplified by 1/std
+FUSED_TOL = (3e-2, 6e-3)       # conv+BN / residual block: a 1-ulp flip of the bf16 intermediate, amplified by gamma/std
 F32_TOL = (2e-3, 5e-4)         # fp32 outputs from bf16 operands
 GRAD_TOL = (2e-2, 6e-3)        # data gradients (bf16, through BN)
-PARAM_TOL = (1e-2, 4e-3)       # parameter gradients (fp32 sums of bf16 products)
+# parameter gradients (fp32 sums of bf16 products): the MEAN bound is the one-rounding bound; the max bound
+# allows for single ReLU-mask flips (an element within rounding of the threshold), each of which moves a
+# BatchNorm parameter gradient -- or the 9*C weight-gradient entries its pixel touches -- by one full term
+# of a sum over as few as ~1,300 pixels (the 384-channel branch): measured up to 3.3 % of max|ref|
+PARAM_TOL = (5e-2, 4e-3)
 LOSS_TOL = (1e-4, 1e-4)
 
 
@@ -53,7 +57,8 @@ class Record:
 
     def summary(self, k=12):
         lines = ["%d ops, %d comparisons, %d failures" % (self.n_ops, len(self.rows), len(self.failures()))]
-        for r in sorted(self.rows, key=lambda r: -(r[4] / r[6][0]))[:k]:
+        worst = sorted(self.rows, key=lambda r: -max(r[4] / r[6][0], r[5] / r[6][1]))[:k]
+        for r in self.failures()[:40] + [w for w in worst if w[7]]:
             lines.append("  op %4d %-14s %-18s %-22s max %.4f (tol %.4f) mean %.4f (tol %.4f) %s" % (
                 r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], "" if r[7] else "FAIL"))
         return "\n".join(lines)
@@ -209,11 +214,15 @@ class TeacherBackend(BackendBase):
         convs, bns, ress, relus, posts = _lst(conv, n), _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n)
         hconvs, hbns = [self.mod[id(c)] for c in convs], [self.mod[id(b)] for b in bns]
         hposts = [None if p is None else p.to(self.device) for p in posts]
+        # a conv bias in front of a training-mode BatchNorm has an identically zero gradient (the
+        # normalisation removes it): both sides compute rounding noise there, nothing to compare
+        params = [(p, q) for p, q in self._mod_params(convs + bns)
+                  if not any(p is c.bias and b.training for c, b in zip(convs, bns))]
         outs = self._teach(
             "conv_bn_act",
             lambda t: self.emu.conv_bn_act(convs, bns, t[:n], t[n:], relus, posts),
             lambda t: self.hip.conv_bn_act(hconvs, hbns, t[:n], t[n:], relus, hposts),
-            xs + ress, self._mod_params(convs + bns), (FUSED_TOL, GRAD_TOL))
+            xs + ress, params, (FUSED_TOL, GRAD_TOL))
         return outs if multi else outs[0]
 
     def batch_norm_act(self, x, bn, residual=None, relu=False, post=None):

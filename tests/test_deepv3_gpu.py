@@ -81,7 +81,7 @@ def test_deepv3_eval_op_by_op(setup):
                gts, False)
     hip = _run(traced(ops.HipBackend(), lambda i, n, y: hip_err.append(_rel(y.detach().float().cpu(), ref_log[i]))),
                sd, images, gts, False, device="cuda")
-    assert len(ref_log) == len(emu_err) == len(hip_err) > 100
+    assert len(ref_log) == len(emu_err) == len(hip_err) > 50       # tensors returned by the (list-aware) public ops
     bad = [(i, names[i], tuple(ref_log[i].shape), hip_err[i], emu_err[i]) for i in range(len(hip_err))
            if not hip_err[i] <= 1.5 * emu_err[i] + 5e-3]
     worst = max(range(len(hip_err)), key=lambda i: hip_err[i] - 1.5 * emu_err[i])
