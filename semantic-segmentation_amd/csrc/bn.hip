@@ -23,22 +23,34 @@ constexpr int NT = 256;
 __host__ __device__ inline int active_threads(int VC) { return (NT / VC) * VC; }
 
 // Accumulate per-channel sums for this block into fp64 global sums.
-// v0/v1 hold 8 channels each (this thread's channel group cg).
+// v0/v1 hold 8 channels each (this thread's channel group cg).  The threads' partials meet in LDS
+// without atomics: every thread stores its 16 values transposed ([value][thread]: conflict free), then
+// thread c < 2C sums the RP = NA / VC threads that own channel c's group and issues ONE fp64 atomic.
+// (The previous LDS-atomic version serialised RP-way on every channel: with 4 pixel rows per thread
+// the epilogue cost more than the streaming.)
 __device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v1, int cg, int C,
                                                  bool active, double* gsums, float* sh, int bx, int nrep = 1) {
   gsums += (long)(bx % nrep) * 2 * C;   // [nrep][2][C]: spread the same-address atomics
-  // sh: [2*C] floats
-  for (int i = threadIdx.x; i < 2 * C; i += NT) sh[i] = 0.f;
-  __syncthreads();
-  if (active) {
+  // sh: [16][NT + 1] floats (odd row stride: the 8 channels of a group fall in 8 banks)
+  constexpr int LDR = NT + 1;
+  const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sh[cg * 8 + j], v0[j]);
-      atomicAdd(&sh[C + cg * 8 + j], v1[j]);
-    }
+  for (int j = 0; j < 8; ++j) {
+    sh[j * LDR + t] = active ? v0[j] : 0.f;
+    sh[(8 + j) * LDR + t] = active ? v1[j] : 0.f;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&gsums[i], (double)sh[i]);
+  const int VC = C >> 3, RP = active_threads(VC) / VC;
+  for (int i = t; i < 2 * C; i += NT) {
+    const int which = i / C, c = i - which * C;
+    const int g = c >> 3, j = c & 7;
+    const float* src = sh + (which * 8 + j) * LDR + g;
+    float a0 = 0.f, a1 = 0.f;
+    int r = 0;
+    for (; r + 1 < RP; r += 2) { a0 += src[r * VC]; a1 += src[(r + 1) * VC]; }
+    if (r < RP) a0 += src[r * VC];
+    atomicAdd(&gsums[i], (double)(a0 + a1));
+  }
 }
 
 __device__ __forceinline__ void bn_stats_body(const bf16_t* __restrict__ x, long P, int C,
@@ -504,7 +516,7 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 Grid plan_grid(long P, int C, int rows_per_thread = -1, long max_blocks = 16384) {
-  static const int apply_rows = env_int("SSA_BN_ROWS_APPLY", 2);
+  static const int apply_rows = env_int("SSA_BN_ROWS_APPLY", 8);   // grouped launches: 2 -> 8 rows, -1.2 ms/step
   if (rows_per_thread < 0) rows_per_thread = apply_rows;
   const int VC = C >> 3;
   const int RP = active_threads(VC) / VC;
@@ -520,7 +532,7 @@ Grid plan_grid(long P, int C, int rows_per_thread = -1, long max_blocks = 16384)
   return {(int)blocks, ppb};
 }
 Grid plan_reduce_grid(long P, int C) {
-  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 4), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
+  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 16), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
   return plan_grid(P, C, rows, cap);
 }
 
@@ -539,7 +551,7 @@ int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_su
   }
   const Grid g = plan_reduce_grid(P, C);
   BnStatsK::Args a{(const bf16_t*)x, sums, P, g.ppb, C, ld};
-  return ssa::submit<BnStatsK>(a, g.blocks, 1, 2 * C * sizeof(float), s);
+  return ssa::submit<BnStatsK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s);
 }
 
 int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
@@ -607,7 +619,7 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
   const Grid g = plan_reduce_grid(P, C);
   BnBwdReduceK::Args a{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums, mask_scale,
                        mask_shift, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep};
-  return ssa::submit<BnBwdReduceK>(a, g.blocks, 1, 2 * C * sizeof(float), s);
+  return ssa::submit<BnBwdReduceK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s);
 }
 
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
@@ -644,7 +656,7 @@ int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out, double* sc
   if (e != hipSuccess) return (int)e;
   const Grid g = plan_reduce_grid(P, C);
   ColsumK::Args a{(const bf16_t*)x, scratch2c, P, g.ppb, C, ld};
-  if (int rc = ssa::submit<ColsumK>(a, g.blocks, 1, 2 * C * sizeof(float), s)) return rc;
+  if (int rc = ssa::submit<ColsumK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s)) return rc;
   hipLaunchKernelGGL(d2f_kernel, dim3((C + 127) / 128), dim3(128), 0, s, scratch2c, out, C);
   SSA_LAUNCH_CHECK();
   return SSA_OK;

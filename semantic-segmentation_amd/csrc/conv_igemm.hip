@@ -619,16 +619,8 @@ constexpr TileChoice kFwdTiles[] = {
     {3, 256, 32, 0.55f},  {4, 64, 64, 0.50f},  {5, 128, 64, 0.75f}};
 
 int choose_fwd_tile(long M, int N) {
-  // Inside a group bracket the launch gets its parallelism from all the problems of the level: pick the
-  // tile for efficiency (largest N block that N fills), not to spread ONE problem over 256 CUs -- and
-  // problems of one level then share kernel instantiations.  SSA_GROUP_UNIFY=0 keeps the cost model.
-  static const bool unify = !(getenv("SSA_GROUP_UNIFY") && atoi(getenv("SSA_GROUP_UNIFY")) == 0);
-  if (unify && ssa::group_state().depth > 0 && M >= 256) {
-    if (N > 96) return 0;       // 128 x 128
-    if (N > 64) return 2;       // 128 x 96
-    if (N > 32) return 5;       // 128 x 64
-    return 3;                   // 256 x 32
-  }
+  // (Measured and rejected, profiles/r02_notes.md: inside group brackets, picking the largest tile that N
+  // fills instead of this cost model -- the stride-2 / 1x1 fuse convs got slower, 3.0 -> 4.2 ms per step.)
   int best = 0;
   double best_cost = 1e300;
   for (const TileChoice& t : kFwdTiles) {

@@ -231,6 +231,107 @@ int launch_bilinear(const void* src, int B, int Hs, int Ws, int C, int lds, void
   return ssa::submit<K>(a, grid_for(nthreads), 1, 0, s);
 }
 
+// ---- few-channel tensors (class logits [.., 19], attention maps [.., 1]; fp32 on this path): one
+// thread per PIXEL.  The source indices / weights are computed once per pixel instead of once per
+// element (and with 32-bit index arithmetic); the forward stages the 256-pixel block of outputs in LDS
+// ([pixel][C], odd C = conflict free) and writes it with unit stride.
+constexpr int kPxMaxC = 32;
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
+                                                     OutT* __restrict__ y, int Ho, int Wo, float sh, float sw,
+                                                     const int bx, const int gx) {
+  extern __shared__ float tile[];               // [256][C]
+  const int npix = B * Ho * Wo;
+  const int tid = threadIdx.x;
+  for (int p0 = bx * 256; p0 < npix; p0 += gx * 256) {
+    const int p = p0 + tid;
+    if (p < npix) {
+      const int ox = p % Wo;
+      const int t = p / Wo;
+      const int oy = t % Ho, b = t / Ho;
+      const Src ys = src_index(oy, sh, Hi), xs = src_index(ox, sw, Wi);
+      const InT* r0 = x + ((long)(b * Hi + ys.i0) * Wi) * ldx;
+      const InT* r1 = x + ((long)(b * Hi + ys.i1) * Wi) * ldx;
+      const InT* p00 = r0 + (long)xs.i0 * ldx;
+      const InT* p01 = r0 + (long)xs.i1 * ldx;
+      const InT* p10 = r1 + (long)xs.i0 * ldx;
+      const InT* p11 = r1 + (long)xs.i1 * ldx;
+      const float w00 = ys.l0 * xs.l0, w01 = ys.l0 * xs.l1, w10 = ys.l1 * xs.l0, w11 = ys.l1 * xs.l1;
+      for (int c = 0; c < C; ++c) {
+        // same association as the element-wise kernel: l0y*(l0x*a + l1x*b) + l1y*(l0x*c + l1x*d)
+        const float o = ys.l0 * (xs.l0 * ld_as_f32(p00 + c) + xs.l1 * ld_as_f32(p01 + c)) +
+                        ys.l1 * (xs.l0 * ld_as_f32(p10 + c) + xs.l1 * ld_as_f32(p11 + c));
+        tile[tid * C + c] = o;
+      }
+      (void)w00; (void)w01; (void)w10; (void)w11;
+    }
+    __syncthreads();
+    const int nval = min(256, npix - p0) * C;
+    OutT* dst = y + (long)p0 * C;
+    for (int i = tid; i < nval; i += 256) st_from_f32(dst + i, tile[i]);
+    __syncthreads();
+  }
+}
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ void bilinear_bwd_px_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
+                                                     OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw,
+                                                     const int bx, const int gx) {
+  const int npix = B * Hi * Wi;
+  for (int p = bx * 256 + threadIdx.x; p < npix; p += gx * 256) {
+    const int ix = p % Wi;
+    const int t = p / Wi;
+    const int iy = t % Hi, b = t / Hi;
+    int ylo, yhi, xlo, xhi;
+    cand_range(iy, sh, Ho, &ylo, &yhi);
+    cand_range(ix, sw, Wo, &xlo, &xhi);
+    float acc[kPxMaxC];
+#pragma unroll
+    for (int c = 0; c < kPxMaxC; ++c) acc[c] = 0.f;
+    const InT* base = dy + (long)b * Ho * Wo * lddy;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = weight_for(oy, sh, Hi, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = weight_for(ox, sw, Wi, ix);
+        if (wx == 0.f) continue;
+        const float w = wy * wx;
+        const InT* g = base + ((long)oy * Wo + ox) * lddy;
+#pragma unroll
+        for (int c = 0; c < kPxMaxC; ++c)
+          if (c < C) acc[c] += w * ld_as_f32(g + c);
+      }
+    }
+    OutT* dst = dx + (long)p * lddx;
+#pragma unroll
+    for (int c = 0; c < kPxMaxC; ++c)
+      if (c < C) st_from_f32(dst + c, acc[c]);
+  }
+}
+
+template <typename InT, typename OutT, bool BWD>
+struct BilinearPxK {
+  struct Args { const InT* src; OutT* dst; int B, Hs, Ws, C, lds, Hd, Wd, ldd; float sh, sw; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    if constexpr (!BWD) bilinear_fwd_px_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.sh, a.sw, bx, gx);
+    else bilinear_bwd_px_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+  }
+};
+template <typename InT, typename OutT, bool BWD>
+int launch_bilinear_px(const void* src, int B, int Hs, int Ws, int C, int lds, void* dst, int Hd, int Wd, int ldd,
+                       float sh, float sw, hipStream_t s) {
+  typedef BilinearPxK<InT, OutT, BWD> K;
+  typename K::Args a{(const InT*)src, (OutT*)dst, B, Hs, Ws, C, lds, Hd, Wd, ldd, sh, sw};
+  const long npix = (long)B * Hd * Wd;
+  return ssa::submit<K>(a, grid_for(npix), 1, BWD ? 0 : (size_t)256 * C * sizeof(float), s);
+}
+// few channels, dense destination, 32-bit pixel counts
+static bool px_ok(int B, int Hs, int Ws, int Hd, int Wd, int C, int ldd) {
+  return C <= kPxMaxC && ldd == C && (long)B * Hs * Ws < (1L << 30) && (long)B * Hd * Wd < (1L << 30);
+}
+
 }  // namespace
 
 extern "C" {
@@ -243,6 +344,10 @@ int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C, 
   const long n = (long)B * Ho * Wo * C;
   if (in_dtype == 0 && out_dtype == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
     return launch_bilinear<bf16_t, bf16_t, true, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n / 8, s);
+  if (px_ok(B, Hi, Wi, Ho, Wo, C, ldy)) {
+    if (in_dtype == 1 && out_dtype == 1) return launch_bilinear_px<float, float, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
+    if (in_dtype == 0 && out_dtype == 1) return launch_bilinear_px<bf16_t, float, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
+  }
   if (in_dtype == 0 && out_dtype == 0)
     return launch_bilinear<bf16_t, bf16_t, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
   if (in_dtype == 0 && out_dtype == 1)
@@ -262,6 +367,10 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
   const long n = (long)B * Hi * Wi * C;
   if (dy_dtype == 0 && dx_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0)
     return launch_bilinear<bf16_t, bf16_t, true, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n / 8, s);
+  if (px_ok(B, Ho, Wo, Hi, Wi, C, lddx)) {
+    if (dy_dtype == 1 && dx_dtype == 1) return launch_bilinear_px<float, float, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
+    if (dy_dtype == 1 && dx_dtype == 0) return launch_bilinear_px<float, bf16_t, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
+  }
   if (dy_dtype == 1 && dx_dtype == 1)
     return launch_bilinear<float, float, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
   if (dy_dtype == 1 && dx_dtype == 0)

@@ -23,8 +23,11 @@ GRAD_TOL = (2e-2, 6e-3)        # data gradients (bf16, through BN)
 # parameter gradients (fp32 sums of bf16 products): the MEAN bound is the one-rounding bound; the max bound
 # allows for single ReLU-mask flips (an element within rounding of the threshold), each of which moves a
 # BatchNorm parameter gradient -- or the 9*C weight-gradient entries its pixel touches -- by one full term
-# of a sum over as few as ~1,300 pixels (the 384-channel branch): measured up to 3.3 % of max|ref|
-PARAM_TOL = (5e-2, 4e-3)
+# of a sum over as few as ~1,300 pixels (the 384-channel branch): measured up to 3.3 % of max|ref|.
+# Mean: TWO independent bf16 roundings meet here -- the teacher's reference gradient is itself rounded
+# to bf16 (the emulation rounds the gradient of a bf16-stored weight), the HIP side's dy is bf16 --
+# measured 0.2 % typical, 0.5 % in the tail of the 2,250 comparisons of a step.
+PARAM_TOL = (5e-2, 8e-3)
 LOSS_TOL = (1e-4, 1e-4)
 
 

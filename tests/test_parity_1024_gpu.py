@@ -5,7 +5,7 @@
    teacher-forced (tests/teacher_backend.py): each HIP op gets the oracle's bf16-rounded input at its
    real 1024^2-crop shape and must match the oracle's output to ONE-ROUNDING tolerance (bf16 outputs
    1e-2 max / 4e-3 mean relative, fp32 outputs 2e-3 / 5e-4, fused conv+BN / residual blocks 3e-2 / 6e-3,
-   parameter gradients 5e-2 max / 4e-3 mean -- the mean is the one-rounding bound, the max allows single
+   parameter gradients 5e-2 max / 8e-3 mean -- the mean is two bf16 roundings, the max allows single
    ReLU-mask flips, tests/teacher_backend.py).  No error accumulates, so a 1 % error of any kernel at any real
    shape fails.  The launched kernel instantiations are recorded and the shape-dependent dispatch
    classes (head halo GEMM, head weight gradient, 256-pixel/two-n-block 48-channel tile, grouped
