@@ -477,6 +477,13 @@ int ssa_sgd_momentum_step(void* const* params, const void* const* grads, void* c
                           const int64_t* numel, int n_tensors, float lr, const float* lr_dev,
                           float momentum, float weight_decay, int nesterov, void* stream);
 
+/* fp32 elementwise out = a (+ | * | /) b (op 0 | 1 | 2) and its backward (da, db optional): the
+ * attention normalisation and the attention-weighted sum over scales of the attention-to-scale
+ * heads, network/attnscale.py:153-166,330-352.                                   */
+int ssa_ewise_f32(int op, const float* a, const float* b, float* out, long n, void* stream);
+int ssa_ewise_bwd_f32(int op, const float* a, const float* b, const float* dout, float* da,
+                      float* db, long n, void* stream);
+
 /* axpy on fp32: y = alpha*x + (accumulate? y : 0) */
 int ssa_axpy_f32(const float* x, float alpha, float* y, long n, int accumulate,
                  void* stream);

@@ -148,6 +148,29 @@ __global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __r
     y[i] = accumulate ? y[i] + alpha * x[i] : alpha * x[i];
 }
 
+// fp32 elementwise add / mul / div of two same-shape tensors and their backward: the attention
+// normalisation and the weighted sum over scales of network/attnscale.py:153-166,330-352.
+__global__ void ewise_fwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                 float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = a[i], y = b[i];
+    out[i] = op == 0 ? x + y : (op == 1 ? x * y : x / y);
+  }
+}
+__global__ void ewise_bwd_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                 const float* __restrict__ dout, float* __restrict__ da,
+                                 float* __restrict__ db, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = dout[i];
+    float ga, gb;
+    if (op == 0) { ga = g; gb = g; }
+    else if (op == 1) { ga = g * b[i]; gb = g * a[i]; }
+    else { const float r = 1.f / b[i]; ga = g * r; gb = -g * a[i] * r * r; }
+    if (da) da[i] = ga;
+    if (db) db[i] = gb;
+  }
+}
+
 inline int grid_for(long n, int per_block = 256, int cap = 4096) {
   long b = (n + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -226,6 +249,21 @@ int ssa_attn_blend_bwd(const float* a, const float* hi, const float* djoint, flo
   if (!a || !hi || !djoint || !da || P <= 0 || C <= 0) return SSA_EINVAL;
   hipLaunchKernelGGL(attn_blend_bwd_kernel, dim3(grid_for(P, 4)), dim3(256), 0, (hipStream_t)stream,
                      a, hi, djoint, da, dhi, P, C, accumulate_da);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_ewise_f32(int op, const float* a, const float* b, float* out, long n, void* stream) {
+  if (!a || !b || !out || n <= 0 || op < 0 || op > 2) return SSA_EINVAL;
+  hipLaunchKernelGGL(ewise_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, out, n);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_ewise_bwd_f32(int op, const float* a, const float* b, const float* dout, float* da, float* db, long n,
+                      void* stream) {
+  if (!a || !b || !dout || n <= 0 || op < 0 || op > 2) return SSA_EINVAL;
+  hipLaunchKernelGGL(ewise_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, dout, da, db, n);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

@@ -72,6 +72,8 @@ __device__ __forceinline__ void bilinear_fwd_s_body(const InT* __restrict__ x, i
   }
 }
 
+constexpr int kMaxCand = 12;      // candidate columns whose weights the gather kernels keep in registers
+
 // candidate output range that can reference input index i
 __device__ __forceinline__ void cand_range(int i, float scale, int out_size, int* lo, int* hi) {
   const float inv = 1.f / scale;
@@ -107,17 +109,37 @@ __device__ __forceinline__ void bilinear_bwd_v8_body(const bf16_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const bf16_t* base = dy + (long)b * Ho * Wo * lddy + cg * 8;
+    // column weights once per element, not once per (row, column): up to kMaxCand candidates stay in
+    // registers (x4 upsampling has 11), wider ranges recompute
+    float wxs[kMaxCand];
+    const int nx = xhi - xlo + 1;
+    const bool hoisted = nx <= kMaxCand;
+#pragma unroll
+    for (int k = 0; k < kMaxCand; ++k) wxs[k] = (hoisted && k < nx) ? weight_for(xlo + k, sw, Wi, ix) : 0.f;
     for (int oy = ylo; oy <= yhi; ++oy) {
       const float wy = weight_for(oy, sh, Hi, iy);
       if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float wx = weight_for(ox, sw, Wi, ix);
-        if (wx == 0.f) continue;
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(base + ((long)oy * Wo + ox) * lddy), g);
-        const float w = wy * wx;
+      const bf16_t* row = base + (long)oy * Wo * lddy;
+      if (hoisted) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+        for (int k = 0; k < kMaxCand; ++k) {
+          if (wxs[k] == 0.f) continue;
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(row + (long)(xlo + k) * lddy), g);
+          const float w = wy * wxs[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+        }
+      } else {
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = weight_for(ox, sw, Wi, ix);
+          if (wx == 0.f) continue;
+          float g[8];
+          unpack8(*reinterpret_cast<const uint4*>(row + (long)ox * lddy), g);
+          const float w = wy * wx;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+        }
       }
     }
     *reinterpret_cast<uint4*>(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + cg * 8) = pack8(acc);
@@ -139,13 +161,25 @@ __device__ __forceinline__ void bilinear_bwd_s_body(const InT* __restrict__ dy, 
     cand_range(ix, sw, Wo, &xlo, &xhi);
     float acc = 0.f;
     const InT* base = dy + (long)b * Ho * Wo * lddy + c;
+    float wxs[kMaxCand];
+    const int nx = xhi - xlo + 1;
+    const bool hoisted = nx <= kMaxCand;
+#pragma unroll
+    for (int k = 0; k < kMaxCand; ++k) wxs[k] = (hoisted && k < nx) ? weight_for(xlo + k, sw, Wi, ix) : 0.f;
     for (int oy = ylo; oy <= yhi; ++oy) {
       const float wy = weight_for(oy, sh, Hi, iy);
       if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float wx = weight_for(ox, sw, Wi, ix);
-        if (wx == 0.f) continue;
-        acc += wy * wx * ld_as_f32(base + ((long)oy * Wo + ox) * lddy);
+      const InT* row = base + (long)oy * Wo * lddy;
+      if (hoisted) {
+#pragma unroll
+        for (int k = 0; k < kMaxCand; ++k)
+          if (wxs[k] != 0.f) acc += wy * wxs[k] * ld_as_f32(row + (long)(xlo + k) * lddy);
+      } else {
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = weight_for(ox, sw, Wi, ix);
+          if (wx == 0.f) continue;
+          acc += wy * wx * ld_as_f32(row + (long)ox * lddy);
+        }
       }
     }
     st_from_f32(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + c, acc);
@@ -235,7 +269,7 @@ int launch_bilinear(const void* src, int B, int Hs, int Ws, int C, int lds, void
 // thread per PIXEL.  The source indices / weights are computed once per pixel instead of once per
 // element (and with 32-bit index arithmetic); the forward stages the 256-pixel block of outputs in LDS
 // ([pixel][C], odd C = conflict free) and writes it with unit stride.
-constexpr int kPxMaxC = 32;
+constexpr int kPxMaxC = 32;      // LDS tile [256][C] stays below 32 KB
 
 template <typename InT, typename OutT>
 __device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
@@ -275,57 +309,20 @@ __device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, 
 }
 
 template <typename InT, typename OutT>
-__device__ __forceinline__ void bilinear_bwd_px_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
-                                                     OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw,
-                                                     const int bx, const int gx) {
-  const int npix = B * Hi * Wi;
-  for (int p = bx * 256 + threadIdx.x; p < npix; p += gx * 256) {
-    const int ix = p % Wi;
-    const int t = p / Wi;
-    const int iy = t % Hi, b = t / Hi;
-    int ylo, yhi, xlo, xhi;
-    cand_range(iy, sh, Ho, &ylo, &yhi);
-    cand_range(ix, sw, Wo, &xlo, &xhi);
-    float acc[kPxMaxC];
-#pragma unroll
-    for (int c = 0; c < kPxMaxC; ++c) acc[c] = 0.f;
-    const InT* base = dy + (long)b * Ho * Wo * lddy;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      const float wy = weight_for(oy, sh, Hi, iy);
-      if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float wx = weight_for(ox, sw, Wi, ix);
-        if (wx == 0.f) continue;
-        const float w = wy * wx;
-        const InT* g = base + ((long)oy * Wo + ox) * lddy;
-#pragma unroll
-        for (int c = 0; c < kPxMaxC; ++c)
-          if (c < C) acc[c] += w * ld_as_f32(g + c);
-      }
-    }
-    OutT* dst = dx + (long)p * lddx;
-#pragma unroll
-    for (int c = 0; c < kPxMaxC; ++c)
-      if (c < C) st_from_f32(dst + c, acc[c]);
-  }
-}
-
-template <typename InT, typename OutT, bool BWD>
 struct BilinearPxK {
   struct Args { const InT* src; OutT* dst; int B, Hs, Ws, C, lds, Hd, Wd, ldd; float sh, sw; };
   static constexpr int NT = 256;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
-    if constexpr (!BWD) bilinear_fwd_px_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.sh, a.sw, bx, gx);
-    else bilinear_bwd_px_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.ldd, a.sh, a.sw, bx, gx);
+    bilinear_fwd_px_body<InT, OutT>(a.src, a.B, a.Hs, a.Ws, a.C, a.lds, a.dst, a.Hd, a.Wd, a.sh, a.sw, bx, gx);
   }
 };
-template <typename InT, typename OutT, bool BWD>
+template <typename InT, typename OutT>
 int launch_bilinear_px(const void* src, int B, int Hs, int Ws, int C, int lds, void* dst, int Hd, int Wd, int ldd,
                        float sh, float sw, hipStream_t s) {
-  typedef BilinearPxK<InT, OutT, BWD> K;
+  typedef BilinearPxK<InT, OutT> K;
   typename K::Args a{(const InT*)src, (OutT*)dst, B, Hs, Ws, C, lds, Hd, Wd, ldd, sh, sw};
   const long npix = (long)B * Hd * Wd;
-  return ssa::submit<K>(a, grid_for(npix), 1, BWD ? 0 : (size_t)256 * C * sizeof(float), s);
+  return ssa::submit<K>(a, grid_for(npix), 1, (size_t)256 * C * sizeof(float), s);
 }
 // few channels, dense destination, 32-bit pixel counts
 static bool px_ok(int B, int Hs, int Ws, int Hd, int Wd, int C, int ldd) {
@@ -345,8 +342,8 @@ int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C, 
   if (in_dtype == 0 && out_dtype == 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0)
     return launch_bilinear<bf16_t, bf16_t, true, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n / 8, s);
   if (px_ok(B, Hi, Wi, Ho, Wo, C, ldy)) {
-    if (in_dtype == 1 && out_dtype == 1) return launch_bilinear_px<float, float, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
-    if (in_dtype == 0 && out_dtype == 1) return launch_bilinear_px<bf16_t, float, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
+    if (in_dtype == 1 && out_dtype == 1) return launch_bilinear_px<float, float>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
+    if (in_dtype == 0 && out_dtype == 1) return launch_bilinear_px<bf16_t, float>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, s);
   }
   if (in_dtype == 0 && out_dtype == 0)
     return launch_bilinear<bf16_t, bf16_t, false, false>(x, B, Hi, Wi, C, ldx, y, Ho, Wo, ldy, sh, sw, n, s);
@@ -367,10 +364,8 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
   const long n = (long)B * Hi * Wi * C;
   if (dy_dtype == 0 && dx_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0)
     return launch_bilinear<bf16_t, bf16_t, true, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n / 8, s);
-  if (px_ok(B, Ho, Wo, Hi, Wi, C, lddx)) {
-    if (dy_dtype == 1 && dx_dtype == 1) return launch_bilinear_px<float, float, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
-    if (dy_dtype == 1 && dx_dtype == 0) return launch_bilinear_px<float, bf16_t, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
-  }
+  // (a per-pixel gather for the few-channel fp32 tensors was measured 4x SLOWER than the per-element
+  // kernel -- lanes = pixels read with a 76-byte stride -- and is not used; profiles/r02_notes.md)
   if (dy_dtype == 1 && dx_dtype == 1)
     return launch_bilinear<float, float, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
   if (dy_dtype == 1 && dx_dtype == 0)

@@ -5,7 +5,7 @@
 registers this package's modules under the names the reference resolves at run
 time, so `train.py`, `config.py` and `scripts/*.yml` run unchanged:
 
-  network.ocrnet / network.deepv3 / network.mscale / network.mscale2 / network.hrnetv2 /
+  network.ocrnet / network.deepv3 / network.mscale / network.mscale2 / network.attnscale / network.hrnetv2 /
   network.ocr_utils / network.utils / network.mynn
         -> semseg_amd.network.*      (importlib target of --arch, network/__init__.py:45-54)
   loss.utils (get_loss, CrossEntropyLoss2d), loss.rmi (RMILoss), loss.optimizer (get_optimizer,
@@ -43,7 +43,7 @@ def _amp_shim():
 
 def install(replace_apex=True):
     from . import nn as snn, parallel, network, loss
-    from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn, deepv3, mscale, mscale2
+    from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn, deepv3, mscale, mscale2, attnscale
     from .loss import criteria, optimizer
     if replace_apex:
         apex = types.ModuleType("apex")
@@ -55,7 +55,7 @@ def install(replace_apex=True):
         sys.modules["apex"] = apex
         sys.modules["apex.parallel"] = par
         sys.modules["apex.amp"] = apex.amp
-    for mod in (ocrnet, deepv3, mscale, mscale2):
+    for mod in (ocrnet, deepv3, mscale, mscale2, attnscale):
         for fname, fn in list(vars(mod).items()):
             if inspect.isfunction(fn) and fn.__module__ == mod.__name__ and not fname.startswith("_") and \
                     "num_classes" in inspect.signature(fn).parameters and not getattr(fn, "_ssa_synced", False):
@@ -69,7 +69,7 @@ def install(replace_apex=True):
     for name, mod in (("network.ocrnet", ocrnet), ("network.hrnetv2", hrnetv2),
                       ("network.ocr_utils", ocr_utils), ("network.utils", nutils),
                       ("network.mynn", mynn), ("network.deepv3", deepv3), ("network.mscale", mscale),
-                      ("network.mscale2", mscale2),
+                      ("network.mscale2", mscale2), ("network.attnscale", attnscale),
                       ("loss.utils", criteria), ("loss.rmi", criteria), ("loss.optimizer", optimizer)):
         sys.modules[name] = mod
     return network, loss

@@ -1469,6 +1469,32 @@ class BcastMulFn(torch.autograd.Function):
         return da, dx
 
 
+class EwiseFn(torch.autograd.Function):
+    """fp32 out = a (+|*|/) b for two same-shape tensors (attention-to-scale heads)."""
+    OPS = {"add": 0, "mul": 1, "div": 2}
+
+    @staticmethod
+    def forward(ctx, op, a, b):
+        a = a.float().contiguous()
+        b = b.float().contiguous()
+        assert a.shape == b.shape, (a.shape, b.shape)
+        out = torch.empty_like(a)
+        check(lib().ssa_ewise_f32(EwiseFn.OPS[op], _p(a), _p(b), _p(out), a.numel(), _s()), "ssa_ewise_f32")
+        ctx.op = op
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        check(lib().ssa_ewise_bwd_f32(EwiseFn.OPS[ctx.op], _p(a), _p(b), _p(dout), _p(da), _p(db), a.numel(), _s()),
+              "ssa_ewise_bwd_f32")
+        return None, da, db
+
+
 class AttnBlendFn(torch.autograd.Function):
     """joint = lo + (1 - a) * hi"""
 

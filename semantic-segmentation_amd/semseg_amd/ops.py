@@ -231,6 +231,13 @@ class HipBackend(BackendBase):
     def attn_blend(self, lo, a, hi):
         return self.hb.AttnBlendFn.apply(lo, a, hi)
 
+    def ewise(self, op, a, b):
+        """fp32 a (+|*|/) b, same shapes ('add', 'mul', 'div')."""
+        return self.hb.EwiseFn.apply(op, a, b)
+
+    def relu(self, x):
+        return self.sum_act([x], relu=True)
+
     def cross_entropy(self, logits, labels, ignore_index):
         return self.hb.CrossEntropyFn.apply(logits, labels, ignore_index)
 

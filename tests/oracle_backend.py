@@ -97,6 +97,12 @@ class OracleBackend(BackendBase):
     def attn_blend(self, lo, a, hi):
         return lo + (1 - a) * hi
 
+    def ewise(self, op, a, b):
+        return a + b if op == "add" else (a * b if op == "mul" else a / b)
+
+    def relu(self, x):
+        return self.sum_act([x], relu=True)
+
     def cross_entropy(self, logits, labels, ignore_index):
         return O.cross_entropy(_to_nchw(logits), labels, ignore_index)
 

@@ -322,6 +322,13 @@ class TeacherBackend(BackendBase):
     def attn_blend(self, lo, a, hi):
         return self._one("attn_blend", "attn_blend", [lo, a, hi], ((1e-5, 1e-5), (1e-4, 1e-4)))
 
+    def ewise(self, op, a, b):
+        return self._teach("ewise", lambda t: [self.emu.ewise(op, *t)], lambda t: [self.hip.ewise(op, *t)], [a, b], (),
+                           ((1e-5, 1e-5), (1e-4, 1e-4)))[0]
+
+    def relu(self, x):
+        return self.sum_act([x], relu=True)
+
     def cross_entropy(self, logits, labels, ignore_index):
         return self._one("cross_entropy", "cross_entropy", [logits, labels], ((1e-5, 1e-5), (1e-4, 1e-4)), (ignore_index,))
 

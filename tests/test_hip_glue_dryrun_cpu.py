@@ -90,6 +90,27 @@ ARCHS = [("ocrnet.HRNet_Mscale", "rmi"), ("ocrnet.HRNet", "ce"), ("deepv3.DeepV3
          ("mscale.MscaleV3Plus.fuse2b", "ce"), ("mscale2.DeepV3R50", "ce"), ("ocrnet.OCRNetASPP", "ce")]
 
 
+@pytest.mark.parametrize("name", ["attnscale.DeepV3R50", "attnscale.DeepV3R50B", "attnscale.DeepV3R50BP"])
+def test_attnscale_glue(name, dry):
+    """The attention-to-scale heads on the HIP glue: train step (all parameters get gradients) and the
+    eval tuple (prediction, attention) of the reference's contract."""
+    from semseg_amd.config import cfg
+    cfg.MODEL.N_SCALES = [0.5, 1.0, 2.0] if name != "attnscale.DeepV3R50B" else [0.5, 1.0]
+    cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
+    net = _build(name, "ce").train()
+    inputs = _batch()
+    out = net(inputs)
+    loss = out["pred"] if isinstance(out, dict) else out
+    assert loss.dim() == 0 and loss.requires_grad
+    loss.backward()
+    missing = [n for n, p in net.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    net.eval()
+    with torch.no_grad():
+        pred, attn = net({"images": inputs["images"]})["pred"]
+    assert tuple(pred.shape) == (2, 19, 64, 96) and pred.dtype == torch.float32 and attn.shape[1] == 1
+
+
 @pytest.mark.parametrize("name,crit", ARCHS)
 def test_train_step_and_eval_glue(name, crit, dry):
     from semseg_amd.config import cfg
