@@ -132,6 +132,26 @@ struct ConvTile {
     a_off[mi] = (ty * HW_ + tx) * PSB + (lane >> 5) * 16;
   }
 
+  // fused-epilogue tile (data-gradient variants): its global loads are issued HERE, before the halo /
+  // MFMA phase, and land in registers while that runs (after the MFMA loop they cost a full, exposed
+  // memory latency: measured +4-5 us per launch)
+  constexpr int AUX_IT = AUX ? (4 * MI * 32 * NB * 4 + 255) / 256 : 1;
+  uint4 auxv[AUX_IT];
+  if constexpr (AUX) {
+    constexpr int CPR_ = NB * 4;
+    const bf16_t* ab = aux + (long)b * H * W * ldaux;
+#pragma unroll
+    for (int i = 0; i < AUX_IT; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx / CPR_, cp = idx - row * CPR_;
+      const int ty = row / TW, tx = row - ty * TW;
+      const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
+      auxv[i] = make_uint4(0, 0, 0, 0);
+      if (idx < 4 * MI * 32 * CPR_ && oy < H && ox < W && n + 8 <= Cout)
+        auxv[i] = *reinterpret_cast<const uint4*>(ab + ((long)oy * W + ox) * ldaux + n);
+    }
+  }
+
   f32x16_t acc[MI][NB];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -201,15 +221,11 @@ struct ConvTile {
   float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 waves][2][NB*32]
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem + (size_t)BM * LDC * 2 + (size_t)4 * 2 * NB * 32 * sizeof(float));
   if constexpr (AUX) {
-    // the aux tile (same pixels, same channels as the output tile) -> LDS, zero outside the image
-    const bf16_t* ab = aux + (long)b * H * W * ldaux;
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
-      const int row = idx / CPR, cp = idx - row * CPR;
-      const int ty = row / TW, tx = row - ty * TW;
-      const int oy = y0 + ty, ox = x0 + tx, n = nb0 * 32 + cp * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (oy < H && ox < W && n + 8 <= Cout) v = *reinterpret_cast<const uint4*>(ab + ((long)oy * W + ox) * ldaux + n);
-      *reinterpret_cast<uint4*>(Xs + row * LDC + cp * 8) = v;
+    // the aux tile (same pixels, same channels as the output tile; zero outside the image): registers -> LDS
+#pragma unroll
+    for (int i = 0; i < AUX_IT; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BM * CPR) *reinterpret_cast<uint4*>(Xs + (idx / CPR) * LDC + (idx % CPR) * 8) = auxv[i];
     }
     __syncthreads();
   }

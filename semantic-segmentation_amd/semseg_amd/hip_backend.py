@@ -1178,6 +1178,47 @@ class SumActGroupFn(torch.autograd.Function):
         return tuple(out)
 
 
+class FanOutGroupFn(torch.autograd.Function):
+    """Tensors with several consumers (a branch output feeds every row of the fuse layers,
+    network/hrnetv2.py:236-252): forward hands out counts[i] aliases of tensor i, backward sums the
+    consumers' gradients of ALL tensors with one grouped launch -- where autograd's own accumulation
+    issues counts[i] - 1 separate adds per tensor (~125 launches per step)."""
+
+    @staticmethod
+    def forward(ctx, counts, *ts):
+        ctx.counts = counts
+        return tuple(t.view_as(t) for t, c in zip(ts, counts) for _ in range(c))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        out, off, jobs = [None], 0, []
+        for c in ctx.counts:
+            part = [g for g in gs[off:off + c] if g is not None]
+            off += c
+            if not part:
+                out.append(None)
+            elif len(part) == 1:
+                out.append(part[0])
+            else:
+                part = [g if g.dtype == ACT_DTYPE else g.to(ACT_DTYPE) for g in part]
+                jobs.append((len(out), [g.contiguous() for g in part]))
+                out.append(None)
+        while jobs:
+            nxt = []
+            with group():
+                for pos, part in jobs:
+                    head, rest = part[:4], part[4:]
+                    z = torch.empty_like(head[0])
+                    args = [_p(t) for t in head] + [None] * (4 - len(head))
+                    check(lib().ssa_sum_act(args[0], args[1], args[2], args[3], _p(z), z.numel(), 0, _s()), "ssa_sum_act")
+                    if rest:
+                        nxt.append((pos, [z] + rest))
+                    else:
+                        out[pos] = z
+            jobs = nxt
+        return tuple(out)
+
+
 class SumActFn:
     @staticmethod
     def apply(relu, *ts):

@@ -164,14 +164,19 @@ class HighResolutionModule(nn.Module):
             return ys if multi else [y[0] for y in ys]
         # ---- fuse layers (network/hrnetv2.py:236-252), level by level over all (i, j, pass)
         rows = self.fuse_layers
+        # every branch output feeds every row: one handle per consumer (their gradients are summed by ONE
+        # grouped launch in the backward pass, ops.fan_out)
+        handles = B.fan_out([ys[i][p] for i, p in jobs], [len(rows)] * len(jobs))
+        use = {(i, p): handles[k] for k, (i, p) in enumerate(jobs)}       # use[(j, p)][i]: row i's handle
         term = {}
         up = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j > i for p in range(P)]
         if up:
-            ts = conv_bn([rows[i][j][0] for i, j, p in up], [rows[i][j][1] for i, j, p in up], [ys[j][p] for i, j, p in up])
+            ts = conv_bn([rows[i][j][0] for i, j, p in up], [rows[i][j][1] for i, j, p in up],
+                         [use[(j, p)][i] for i, j, p in up])
             ts = B.bilinear(ts, [tuple(ys[i][p].shape[1:3]) for i, j, p in up])
             term.update(zip(up, ts))
         down = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j < i for p in range(P)]
-        state = {k: ys[k[1]][k[2]] for k in down}
+        state = {k: use[(k[1], k[2])][k[0]] for k in down}
         step = 0
         while True:
             sel = [k for k in down if step < len(rows[k[0]][k[1]])]
@@ -186,7 +191,7 @@ class HighResolutionModule(nn.Module):
         sums = []
         for i in range(len(rows)):
             for p in range(P):
-                sums.append([ys[i][p] if j == i else term[(i, j, p)] for j in range(nb)])
+                sums.append([use[(i, p)][i] if j == i else term[(i, j, p)] for j in range(nb)])
         outs = B.sum_act(sums, relu=True)
         outs = [[outs[i * P + p] for p in range(P)] for i in range(len(rows))]
         return outs if multi else [o[0] for o in outs]

@@ -74,6 +74,11 @@ class BackendBase:
         sizes = size if _is_list(size[0]) or hasattr(size[0], "__len__") else [size] * len(x)
         return [self._bilinear(xi, s, out_f32) for xi, s in zip(x, sizes)]
 
+    def fan_out(self, tensors, counts):
+        """tensors[i] is about to be consumed counts[i] times: returns counts[i] handles per tensor (the
+        HIP backend sums their gradients with one grouped launch instead of autograd's adds)."""
+        return [[t] * c for t, c in zip(tensors, counts)]
+
     @staticmethod
     def parallel(thunks, level=1):
         """Independent sub-graphs, issued one after the other (thunks[1:] first, thunks[0] last:
@@ -171,6 +176,17 @@ class HipBackend(BackendBase):
         for b, x in zip(blocks, xs):
             flat += [x, b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias]
         return list(self.hb.BasicBlockGroupFn.apply(metas, *flat))
+
+    def fan_out(self, tensors, counts):
+        if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors) or max(counts) < 2 or \
+                any(t.dtype != self.act_dtype or t.numel() % 8 for t in tensors):
+            return BackendBase.fan_out(self, tensors, counts)
+        flat = self.hb.FanOutGroupFn.apply(tuple(counts), *tensors)
+        out, off = [], 0
+        for c in counts:
+            out.append(list(flat[off:off + c]))
+            off += c
+        return out
 
     def end_forward(self):
         self.hb.end_forward()

@@ -13,8 +13,13 @@ import sys
 
 
 def short(name):
+    """Kernel family: the functor a grouped / single launch wrapper (csrc/group.h) was instantiated with
+    -- 'ConvTile', 'BnBwdApplyK', ... (the names bench.py's roofline block uses) -- or the plain kernel name."""
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
+    m = re.match(r"ssa::k_(?:grouped|single)<(\w+)", name)
+    if m:
+        return m.group(1)
     m = re.match(r"([^(]+)", name)
     n = (m.group(1) if m else name).strip()
     return re.sub(r"<.*", "", n)          # template arguments folded: one row per kernel family
@@ -43,8 +48,16 @@ def main():
         wr = wkib * 1024 / wn if wn else 0.0
         out[k] = {"launches": n, "avg_us": ns / n / 1e3, "read_bytes_per_launch": rd,
                   "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sha = None
+    try:
+        import bench
+        sha = bench.source_sha()          # bench.py refuses this file once the kernel sources change
+    except Exception as e:                # noqa: BLE001
+        print("source_sha unavailable:", e)
     json.dump({"note": "read = 2 x FETCH_SIZE x 1024 (gfx950 correction), write = WRITE_SIZE x 1024; per launch averages",
-               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+               "source_sha": sha, "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print("%-34s %8s %9s %12s %12s" % ("kernel family", "launches", "avg_us", "read MB", "write MB"))
     for k, v in list(out.items())[:22]:
         print("%-34s %8d %9.2f %12.3f %12.3f" % (k[:34], v["launches"], v["avg_us"], v["read_bytes_per_launch"] / 1e6,
