@@ -456,6 +456,18 @@ int ssa_image_u8_crop_flip_normalize(const unsigned char* img_hwc, int H, int W,
 int ssa_label_u8_crop_flip(const unsigned char* lab_hw, int H, int W, int x0, int y0, int cw,
                            int ch, int flip, int64_t* out, void* stream);
 
+/* The scale step of the input pipeline on the device:
+ * `img.resize((w, h), Image.BICUBIC)` of transforms/joint_transforms.py:433-471 (RandomSizeAndCrop ->
+ * scale_and_crop; also the Scale / ResizeHeight transforms) is Pillow's two-pass 8-bit resampling
+ * (libImaging/Resample.c): a horizontal pass into an 8-bit image, then a vertical pass over it.  One
+ * call = one pass over an interleaved uint8 [Hs][Ws][C] device image along axis 1 (x: n_out output
+ * columns) or 0 (y: n_out output rows); bounds [n_out][2] = (first source index, tap count) and coefs
+ * [n_out][ksize] = 22-bit fixed-point taps are DEVICE arrays the host derives exactly as
+ * precompute_coeffs / normalize_coeffs_8bpc do (semseg_amd/datasets/transforms.py).  Integer
+ * arithmetic: bit-identical to Pillow.                                                          */
+int ssa_resample_u8(const unsigned char* src, int Hs, int Ws, int C, int axis, unsigned char* dst,
+                    int n_out, const int* bounds, const int* coefs, int ksize, void* stream);
+
 /* Evaluation tail on the device (utils/trnval_utils.py:173-196 + utils/misc.py:50-67
  * fast_hist): pred[p] = first argmax_c logits[p,c] (uint8, optional) and
  * hist[gt*C + pred] += 1 for 0 <= gt < C (int64 [C*C], ACCUMULATED: clear it once per

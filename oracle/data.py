@@ -86,3 +86,88 @@ def crop_flip_normalize(img_u8, labels_u8, window, flip, mean, std):
     m = np.asarray(mean, dtype=np.float32)[:, None, None]
     s = np.asarray(std, dtype=np.float32)[:, None, None]
     return (t - m) / s, np.ascontiguousarray(lab).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# S2': the IMAGE half of the scale step, `img.resize((w, h), Image.BICUBIC)`
+# (transforms/joint_transforms.py:433-471 RandomSizeAndCrop -> scale_and_crop, and the Scale /
+# ResizeHeight transforms): Pillow 8-bit two-pass resampling, libImaging/Resample.c
+# (precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc),
+# restated scalar by scalar.  Pinned against Pillow itself in tests/test_data_cpu.py.
+# ---------------------------------------------------------------------------------------------
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic_filter(x):
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size, out_size):
+    """-> (ksize, bounds [(xmin, xmax)], integer coefficients [out_size][ksize]) of Resample.c for the
+    whole-image box (in0 = 0, in1 = in_size) and the bicubic filter (support 2.0)."""
+    scale = float(in_size) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds, kk = [], []
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws, ww = [], 0.0
+        for x in range(xmax):
+            w = _bicubic_filter((x + xmin - center + 0.5) * ss)
+            ws.append(w)
+            ww += w
+        if ww != 0.0:
+            ws = [w / ww for w in ws]
+        ws += [0.0] * (ksize - xmax)
+        kk.append([int(-0.5 + w * (1 << PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << PRECISION_BITS)) for w in ws])
+        bounds.append((xmin, xmax))
+    return ksize, bounds, kk
+
+
+def _clip8(v):
+    v >>= PRECISION_BITS               # arithmetic shift, as the C `in >> PRECISION_BITS` on int
+    return 0 if v < 0 else (255 if v > 255 else v)
+
+
+def resize_bicubic_u8(img, size):
+    """img: numpy uint8 [H][W][C]; size = (Hd, Wd).  Horizontal pass into an 8-bit image, then the
+    vertical pass over it (ImagingResampleInner)."""
+    import numpy as np
+    hs, ws, ch = img.shape
+    hd, wd = size
+    src = img.astype(np.int64)
+    if wd != ws:
+        _, bounds, kk = pil_bicubic_coeffs(ws, wd)
+        tmp = np.empty((hs, wd, ch), dtype=np.int64)
+        for xx, ((xmin, xmax), k) in enumerate(zip(bounds, kk)):
+            acc = np.full((hs, ch), 1 << (PRECISION_BITS - 1), dtype=np.int64)
+            for x in range(xmax):
+                acc += src[:, xmin + x, :] * k[x]
+            tmp[:, xx, :] = np.clip(acc >> PRECISION_BITS, 0, 255)
+        src = tmp
+    if hd != hs:
+        _, bounds, kk = pil_bicubic_coeffs(hs, hd)
+        out = np.empty((hd, src.shape[1], ch), dtype=np.int64)
+        for yy, ((ymin, ymax), k) in enumerate(zip(bounds, kk)):
+            acc = np.full((src.shape[1], ch), 1 << (PRECISION_BITS - 1), dtype=np.int64)
+            for y in range(ymax):
+                acc += src[ymin + y, :, :] * k[y]
+            out[yy] = np.clip(acc >> PRECISION_BITS, 0, 255)
+        src = out
+    return src.astype(np.uint8)

@@ -50,6 +50,35 @@ bool window_ok(int H, int W, int x0, int y0, int cw, int ch) {
   return H > 0 && W > 0 && cw > 0 && ch > 0 && x0 >= 0 && y0 >= 0 && (long)x0 + cw <= W && (long)y0 + ch <= H;
 }
 
+// One pass of Pillow's 8-bit resampling (libImaging/Resample.c ImagingResampleHorizontal_8bpc /
+// Vertical_8bpc) over an interleaved uint8 [H][W][C] image: out = clip8((2^21 + sum_k in * kk) >> 22)
+// with the per-output (first tap, tap count) bounds and the 22-bit fixed-point coefficients the host
+// derived exactly as precompute_coeffs + normalize_coeffs_8bpc do.  Integer arithmetic: bit-identical
+// to `img.resize(size, Image.BICUBIC)` (transforms/joint_transforms.py:433-471) pass by pass.
+__global__ __launch_bounds__(256) void resample_u8_kernel(
+    const unsigned char* __restrict__ src, int Hs, int Ws, int C, int axis, unsigned char* __restrict__ dst,
+    int Hd, int Wd, const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize) {
+  const long n = (long)Hd * Wd * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long t = i / C;
+    const int x = (int)(t % Wd), y = (int)(t / Wd);
+    const int o = axis ? x : y;
+    const int first = bounds[2 * o], cnt = bounds[2 * o + 1];
+    const int* k = coefs + (long)o * ksize;
+    int ss = 1 << 21;
+    if (axis) {
+      const unsigned char* p = src + ((long)y * Ws + first) * C + c;
+      for (int j = 0; j < cnt; ++j) ss += (int)p[(long)j * C] * k[j];
+    } else {
+      const unsigned char* p = src + ((long)first * Ws + x) * C + c;
+      for (int j = 0; j < cnt; ++j) ss += (int)p[(long)j * Ws * C] * k[j];
+    }
+    ss >>= 22;
+    dst[i] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -80,6 +109,20 @@ int ssa_label_u8_crop_flip(const unsigned char* lab_hw, int H, int W, int x0, in
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(label_crop_flip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lab_hw, W, x0, y0,
                      cw, ch, flip ? 1 : 0, (long*)out);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_resample_u8(const unsigned char* src, int Hs, int Ws, int C, int axis, unsigned char* dst, int n_out,
+                    const int* bounds, const int* coefs, int ksize, void* stream) {
+  if (!src || !dst || !bounds || !coefs || Hs <= 0 || Ws <= 0 || C <= 0 || n_out <= 0 || ksize <= 0 ||
+      (axis != 0 && axis != 1))
+    return SSA_EINVAL;
+  const int Hd = axis ? Hs : n_out, Wd = axis ? n_out : Ws;
+  const long n = (long)Hd * Wd * C;
+  const int blocks = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+  hipLaunchKernelGGL(resample_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, C, axis, dst,
+                     Hd, Wd, bounds, coefs, ksize);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

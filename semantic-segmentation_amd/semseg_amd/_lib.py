@@ -123,6 +123,7 @@ _SIGS = {
                             c_double, _P, c_int, _P], c_int),
     "ssa_image_u8_crop_flip_normalize": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P],
                                          c_int),
+    "ssa_resample_u8": ([_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P], c_int),
     "ssa_label_u8_crop_flip": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_confusion_matrix": ([_P, c_int, _P, c_long, c_int, _P, _P, _P], c_int),
     "ssa_sgd_momentum_step": ([_P, _P, _P, _P, c_int, c_float, _P, c_float, c_float, c_int, _P], c_int),

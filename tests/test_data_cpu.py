@@ -98,3 +98,43 @@ def test_oracle_pipeline_tail_matches_pil_and_torch():
         im, lab = crop_flip_normalize(g["img"].numpy(), g["lab"].numpy(), c["window"], c["flip"], g["mean"], g["std"])
         assert np.array_equal(im, c["image"].numpy()), c["window"]
         assert np.array_equal(lab, c["labels"].numpy()), c["window"]
+
+
+BICUBIC_CASES = [(37, 53, 74, 106), (64, 96, 48, 72), (50, 70, 100, 35), (33, 45, 67, 91), (128, 256, 205, 410),
+                 (20, 20, 20, 31), (97, 131, 49, 66)]
+
+
+def test_bicubic_oracle_is_pillow_bit_for_bit():
+    """oracle.data.resize_bicubic_u8 (restatement of libImaging/Resample.c) against Pillow itself --
+    `img.resize((w, h), Image.BICUBIC)`, the image half of the reference's scale step
+    (transforms/joint_transforms.py:433-471) -- on up-, down- and mixed scalings."""
+    import numpy as np
+    from PIL import Image
+    from oracle.data import resize_bicubic_u8
+    rng = np.random.default_rng(0)
+    for h, w, hd, wd in BICUBIC_CASES:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.array(Image.fromarray(img, "RGB").resize((wd, hd), Image.BICUBIC))
+        assert np.array_equal(resize_bicubic_u8(img, (hd, wd)), ref), (h, w, hd, wd)
+
+
+def test_bicubic_tap_tables_of_the_product_are_the_oracles():
+    import numpy as np
+    from oracle.data import pil_bicubic_coeffs
+    from semseg_amd.datasets.transforms import bicubic_tables
+    for n_src, n_dst in [(53, 106), (96, 72), (70, 35), (45, 91), (256, 410), (20, 31), (131, 66), (2048, 1843),
+                         (1024, 2049), (1024, 512), (7, 3), (3, 7), (2048, 1024), (1024, 717)]:
+        k, b, c = pil_bicubic_coeffs(n_src, n_dst)
+        k2, b2, c2 = bicubic_tables(n_dst, n_src)
+        assert k == k2 and np.array_equal(np.array(b), b2) and np.array_equal(np.array(c), c2), (n_src, n_dst)
+
+
+def test_device_prefetcher_passes_batches_through_in_order():
+    import torch
+    from semseg_amd.datasets.transforms import DevicePrefetcher
+    batches = [(torch.full((2, 3), float(i)), torch.full((2,), i), "name%d" % i, 0.5) for i in range(5)]
+    got = list(DevicePrefetcher(batches, device="cpu"))
+    assert len(got) == 5 and len(DevicePrefetcher(batches, device="cpu")) == 5
+    for i, (img, gts, name, scale) in enumerate(got):
+        assert float(img[0, 0]) == i and int(gts[0]) == i and name == "name%d" % i and scale == 0.5
+    assert list(DevicePrefetcher([], device="cpu")) == []

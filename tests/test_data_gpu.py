@@ -90,3 +90,27 @@ def test_pipeline_tail_on_device_is_bit_exact():
         assert torch.equal(got[..., :3].view(torch.int16), want.contiguous().view(torch.int16)), window
         assert int(got[..., 3:].abs().max()) == 0
         assert torch.equal(gts[0].cpu(), torch.from_numpy(want_lab)), window
+
+
+def test_bicubic_scale_step_on_device_is_bit_exact():
+    """ssa_resample_u8 (two passes) against the oracle (pinned to Pillow in tests/test_data_cpu.py): the
+    image half of RandomSizeAndCrop's scale step, incl. a full-size 1024x2048 frame scaled by 0.9 and 1.7."""
+    import numpy as np
+    from oracle.data import resize_bicubic_u8
+    from semseg_amd.datasets.transforms import resize_image_bicubic
+    rng = np.random.default_rng(1)
+    cases = [(37, 53, 74, 106), (64, 96, 48, 72), (50, 70, 100, 35), (33, 45, 67, 91), (97, 131, 49, 66),
+             (1024, 2048, 921, 1843), (512, 1024, 870, 1740)]
+    for h, w, hd, wd in cases:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = resize_image_bicubic(torch.from_numpy(img).cuda(), (hd, wd)).cpu().numpy()
+        assert got.shape == (hd, wd, 3)
+        assert np.array_equal(got, resize_bicubic_u8(img, (hd, wd))), (h, w, hd, wd)
+
+
+def test_device_prefetcher_overlaps_and_preserves_batches():
+    from semseg_amd.datasets.transforms import DevicePrefetcher
+    batches = [(torch.randn(1, 3, 256, 256), torch.randint(0, 19, (1, 256, 256)), "n%d" % i, 0.0) for i in range(4)]
+    for i, (img, gts, name, _) in enumerate(DevicePrefetcher(batches)):
+        assert img.is_cuda and gts.is_cuda and name == "n%d" % i
+        assert torch.equal(img.cpu(), batches[i][0]) and torch.equal(gts.cpu(), batches[i][1])
