@@ -53,7 +53,9 @@ class Record:
             if float((err > tol[0] * scale).float().mean()) <= 1e-4:
                 rmax = tol[0]
         ok = finite and (scale == 0.0 and float(err.max()) == 0.0 or (rmax <= tol[0] and rmean <= tol[1]))
-        self.rows.append((idx, op, what, tuple(ref.shape), rmax, rmean, tol, ok))
+        cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
+        ratio = float(got.norm() / (ref.norm() + 1e-30))
+        self.rows.append((idx, op, what, tuple(ref.shape), rmax, rmean, tol, ok, cos, ratio))
 
     def failures(self):
         return [r for r in self.rows if not r[7]]
@@ -62,8 +64,8 @@ class Record:
         lines = ["%d ops, %d comparisons, %d failures" % (self.n_ops, len(self.rows), len(self.failures()))]
         worst = sorted(self.rows, key=lambda r: -max(r[4] / r[6][0], r[5] / r[6][1]))[:k]
         for r in self.failures()[:40] + [w for w in worst if w[7]]:
-            lines.append("  op %4d %-14s %-18s %-22s max %.4f (tol %.4f) mean %.4f (tol %.4f) %s" % (
-                r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], "" if r[7] else "FAIL"))
+            lines.append("  op %4d %-14s %-18s %-22s max %.4f (tol %.4f) mean %.4f (tol %.4f) cos %.4f |got|/|ref| %.3f %s" % (
+                r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], r[8], r[9], "" if r[7] else "FAIL"))
         return "\n".join(lines)
 
 

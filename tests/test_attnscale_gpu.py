@@ -25,6 +25,8 @@ def test_attnscale_teacher_forced(name, scales, training):
     for k in sd:                               # as tests/test_deepv3_gpu.py: tame the B=2 image-pooling BN
         if k.endswith("aspp.img_conv.1.weight"):
             sd[k].mul_(0.05)
+        if k.startswith("scale_attn") and k.endswith("6.weight"):
+            sd[k].mul_(0.05)                   # keep the sigmoid attention away from exact 0 (0/0 in the normalisation)
     images, gts = _synth(2, 128, 192, seed=17)
     if not training:                           # eval: BN running statistics calibrated on this batch first
         from oracle_backend import OracleBackend
@@ -55,6 +57,10 @@ def test_attnscale_teacher_forced(name, scales, training):
         cfg.MODEL.N_SCALES = None
         cfg.LOSS.SUPERVISED_MSCALE_WT = 0
     print(tb.rec.summary(6))
+    for r in tb.rec.rows:                      # one layer through every scale pass
+        if r[2] in ("dparam(19, 256, 1, 1)", "dparam(48, 256, 1, 1)"):
+            print("   layer trace: op %d %s %s max %.4f mean %.4f cos %.4f ratio %.3f ok=%s" % (
+                r[0], r[1], r[2], r[4], r[5], r[8], r[9], r[7]))
     assert tb.rec.n_ops > 60
     assert any(r[1] == "ewise" for r in tb.rec.rows)
     assert not tb.rec.failures(), tb.rec.summary(30)
