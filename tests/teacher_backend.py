@@ -11,6 +11,8 @@ gradients and parameter gradients are compared the same way.  No error accumulat
 1 % error of any kernel at any shape the network really uses fails that op -- which the end-to-end
 tests (chaotic random-weight network, bf16 noise floor of ~10 %) cannot see.
 """
+import threading
+
 import torch
 
 from bf16_emu_backend import Bf16EmuBackend
@@ -49,8 +51,12 @@ class Record:
         if what.startswith("d") and rmax > tol[0]:
             # gradients through a ReLU mask recomputed from bf16 data: an element whose pre-activation is
             # within rounding of zero may fall on the other side of the mask than the teacher's and then
-            # differs by its full magnitude; up to 1e-4 of the elements may (tests/util.py:check_close_robust)
-            if float((err > tol[0] * scale).float().mean()) <= 1e-4:
+            # differs by its full magnitude; up to 1e-4 of the elements may (tests/util.py:check_close_robust).
+            # For a DATA gradient one flipped (pixel, channel) of the output moves every input channel under
+            # the filter footprint -- 2048 elements = 0.13 % of layer4's 768-pixel input per flip -- so the
+            # allowance there is 0.5 % of the elements; the mean bound still holds for all of them.
+            frac = 5e-3 if what.startswith("din") else 1e-4
+            if float((err > tol[0] * scale).float().mean()) <= frac:
                 rmax = tol[0]
         ok = finite and (scale == 0.0 and float(err.max()) == 0.0 or (rmax <= tol[0] and rmean <= tol[1]))
         cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
@@ -75,6 +81,27 @@ def _hip_dtype(t):
         return d
     # class logits ([..,19]) and attention maps ([..,1]) are fp32 on the HIP path, activations bf16
     return torch.float32 if (t.dim() == 4 and t.shape[-1] in (1, 19)) or t.dim() == 0 else torch.bfloat16
+
+
+def _isolated(fn):
+    """Run the device-side inner backward from a helper thread.  Called re-entrantly from this node, the
+    engine's owner thread would keep executing OTHER ready nodes of the outer (CPU) graph while the device
+    thread works -- e.g. the same layer's node of another scale pass, whose own inner backward then
+    re-publishes that layer's parameter gradients before this node has read them.  A helper thread makes
+    the inner call a plain top-level backward; this thread just waits for it."""
+    box = {}
+
+    def work():
+        try:
+            box["v"] = fn()
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the calling thread
+            box["e"] = e
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    if "e" in box:
+        raise box["e"]
+    return box["v"]
 
 
 class _TeachFn(torch.autograd.Function):
@@ -119,8 +146,9 @@ class _TeachFn(torch.autograd.Function):
                                  [dys[k] for k in sel], allow_unused=True)
         for q in hip_params:
             q.grad = None
-        hg = torch.autograd.grad([hip_out[k] for k in sel], [hip_in[k] for k in r_ins] + hip_params,
-                                 [dys[k].to(tb.device).to(hip_out[k].dtype) for k in sel], allow_unused=True)
+        hdys = [dys[k].to(tb.device).to(hip_out[k].dtype) for k in sel]
+        hg = _isolated(lambda: torch.autograd.grad([hip_out[k] for k in sel], [hip_in[k] for k in r_ins] + hip_params,
+                                                   hdys, allow_unused=True))
         if tb.device != "cpu":
             torch.cuda.synchronize()
         for j, k in enumerate(r_ins):
@@ -139,6 +167,8 @@ class _TeachFn(torch.autograd.Function):
                 continue
             assert h is not None, (name, "parameter got no gradient on the HIP side", tuple(p.shape))
             tb.rec.add(idx, name, "dparam%s" % (tuple(p.shape),), h, r, PARAM_TOL)
+            if tb.debug is not None:
+                tb.debug(idx, name, p, q, r, h, hip_in, hip_out, [dys[k] for k in sel], hg[len(r_ins) + j] is None)
         return tuple(grads)
 
 
@@ -155,6 +185,7 @@ class TeacherBackend(BackendBase):
         self.cast = device != "cpu"
         self.hip = ops.HipBackend() if device != "cpu" else Bf16EmuBackend()
         self.rec = Record()
+        self.debug = None            # optional callable, see tools/debug_teacher.py
         self._anchor = torch.zeros((), requires_grad=True)
         self.mod = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_modules(), hip_net.named_modules())}
         self.par = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_parameters(), hip_net.named_parameters())}
