@@ -6,6 +6,8 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <stdlib.h>
+#include <vector>
 
 namespace ssa {
 
@@ -41,6 +43,30 @@ void profile_close(void* h, hipStream_t s, int jobs, double flops, double bytes)
   delete r;
 }
 
+// ---- side streams of a bracket (SSA_GROUP_STREAMS = total streams a bracket may use; 1 = off)
+struct SideStreams { std::vector<hipStream_t> streams; std::vector<hipEvent_t> join; hipEvent_t fork; };
+static SideStreams* side_streams() {
+  static thread_local SideStreams* ss = nullptr;
+  static thread_local bool tried = false;
+  if (tried) return ss;
+  tried = true;
+  const char* e = getenv("SSA_GROUP_STREAMS");
+  const int n = e ? atoi(e) : 1;
+  if (n <= 1) return nullptr;
+  SideStreams* t = new SideStreams;
+  if (hipEventCreateWithFlags(&t->fork, hipEventDisableTiming) != hipSuccess) { delete t; return nullptr; }
+  for (int i = 0; i < n - 1 && i < 7; ++i) {
+    hipStream_t s; hipEvent_t ev;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) break;
+    t->streams.push_back(s);
+    t->join.push_back(ev);
+  }
+  if (t->streams.empty()) { delete t; return nullptr; }
+  ss = t;
+  return ss;
+}
+
 }  // namespace ssa
 
 extern "C" {
@@ -60,8 +86,35 @@ int ssa_group_end(void* stream) {
   if (g.depth <= 0) return SSA_EINVAL;
   if (--g.depth > 0) return SSA_OK;          // nested brackets flush with the outermost one
   int rc = g.error;
+  hipStream_t main = (hipStream_t)stream;
+  int nonempty = 0;
+  for (ssa::Bucket& b : g.buckets) nonempty += !b.gx.empty();
+  ssa::SideStreams* ss = (rc == 0 && nonempty > 1 && !ssa::profiling()) ? ssa::side_streams() : nullptr;
+  if (ss) {
+    // The launches of a bracket are independent of one another by contract (the bracket reorders
+    // them by kernel instantiation already): launch k > 0 goes to a side stream forked from `stream`
+    // here and joined below -- in a captured step these are parallel branches of the hipGraph, so the
+    // 48/96/192/384-channel launches of one depth level, none of which fills 256 CUs, overlap.
+    if (hipEventRecord(ss->fork, main) != hipSuccess) ss = nullptr;
+  }
+  int k = 0, used = 0;
   for (ssa::Bucket& b : g.buckets) {
-    if (rc == 0 && !b.gx.empty()) rc = b.flush(b, (hipStream_t)stream);
+    if (rc != 0 || b.gx.empty()) continue;
+    hipStream_t s = main;
+    if (ss && k > 0) {
+      const int i = (k - 1) % (int)ss->streams.size();
+      s = ss->streams[i];
+      if (i >= used) {
+        if (hipStreamWaitEvent(s, ss->fork, 0) != hipSuccess) rc = SSA_EINVAL;
+        used = i + 1;
+      }
+    }
+    if (rc == 0) rc = b.flush(b, s);
+    ++k;
+  }
+  for (int i = 0; ss && i < used; ++i) {
+    if (hipEventRecord(ss->join[i], ss->streams[i]) != hipSuccess ||
+        hipStreamWaitEvent(main, ss->join[i], 0) != hipSuccess) rc = rc ? rc : SSA_EINVAL;
   }
   g.buckets.clear();
   g.error = 0;

@@ -57,10 +57,6 @@ def test_attnscale_teacher_forced(name, scales, training):
         cfg.MODEL.N_SCALES = None
         cfg.LOSS.SUPERVISED_MSCALE_WT = 0
     print(tb.rec.summary(6))
-    for r in tb.rec.rows:                      # one layer through every scale pass
-        if r[2] in ("dparam(19, 256, 1, 1)", "dparam(48, 256, 1, 1)"):
-            print("   layer trace: op %d %s %s max %.4f mean %.4f cos %.4f ratio %.3f ok=%s" % (
-                r[0], r[1], r[2], r[4], r[5], r[8], r[9], r[7]))
     assert tb.rec.n_ops > 60
     assert any(r[1] == "ewise" for r in tb.rec.rows)
     assert not tb.rec.failures(), tb.rec.summary(30)
