@@ -141,13 +141,31 @@ int ssa_conv2d_halo(const ssa_conv_desc* d, const void* x, const void* w_frag,
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);
 
+/* Data gradient of a 3x3, stride-2, pad-1 convolution (the fuse / transition / stem
+ * down-convs of network/hrnetv2.py:218-250, 357-371; cuDNN's backward-data behind
+ * nn.Conv2d) decomposed by OUTPUT PARITY: the pixels (2m+py, 2n+px) of dx depend on
+ * (1+py)*(1+px) of the 9 taps only, so the four classes are four dense stride-1
+ * correlations of dy with 1, 2, 2 and 4 taps -- no multiplications by the zeros of the
+ * zero-inserted form (ssa_conv2d_igemm with transposed = 1 does 4x the MFMA work).
+ * dy: [B,Ho,Wo,cout_pad] bf16 (row stride lddy), dx: [B,H,W,Cin] bf16 (lddx), every pixel
+ * written.  w_cls[c], kpad_cls[c]: operand of class c = 2*py+px packed by
+ * ssa_pack_filter(mode 4+c) -- [Cin][Kpad], k = (jy, jx, co).  Inside a group bracket the
+ * four problems share one launch.                                                        */
+int ssa_conv2d_dgrad_s2(int B, int H, int W, int Cin, int lddx, int Ho, int Wo, int cout_pad,
+                        int lddy, const void* dy, const void* const* w_cls, const int* kpad_cls,
+                        void* dx, void* stream);
+
 /* Filter packing: OIHW fp32 parameter -> bf16 [rows][Kpad] GEMM operand.
  * mode 0 (forward): rows = Cout, k = (kh,kw,ci) with ci < cin_pad.
  * mode 1 (dgrad)  : rows = Cin,  k = (kh',kw',co) with co < cout_pad, taps
  *                   flipped (kh' = KH-1-kh) -- the transposed filter.
  * mode 2 / 3      : the same two operands in MFMA-fragment order for
  *                   ssa_conv2d_tile: [n-block][k-step][lane][8], rows padded to
- *                   a multiple of 32, Kpad = KH*KW*c_pad (a multiple of 16).   */
+ *                   a multiple of 32, Kpad = KH*KW*c_pad (a multiple of 16).
+ * mode 4 + 2*py + px (3x3 only): data-gradient operand of parity class (py, px) of a
+ *                   stride-2 conv (ssa_conv2d_dgrad_s2): rows = Cin,
+ *                   k = (jy, jx, co), jy <= py, jx <= px, co < cout_pad; tap j of
+ *                   class 0 is forward tap 1, of class 1 forward tap 2 - 2j.       */
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin,
                     int KH, int KW, int cin_pad, int cout_pad, int Kpad,
                     int mode, void* stream);
@@ -183,6 +201,16 @@ typedef struct ssa_pack_job {
 } ssa_pack_job;
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job,
                              void* stream);
+/* The same repack balanced by TILE: tiles_dev = device array of int4 {job index, first output
+ * channel (multiple of 32), first input channel (multiple of ct), ct} covering every job's
+ * [Cout] x [Cin] plane with 32 x ct tiles, ct = ssa_pack_tile_channels(KH, KW) (0: filter
+ * too large for this path -> use ssa_pack_filters_batched).  Writes the data elements only:
+ * the destinations' zero padding must be in place (cleared buffers packed once by
+ * ssa_pack_filter).  max_ct_taps = the largest ct * KH * KW over the tiles (sizes the LDS
+ * tile).  One coalesced read of each OIHW tile serves either operand form.                 */
+int ssa_pack_tile_channels(int KH, int KW);
+int ssa_pack_filters_tiled(const void* jobs_dev, const void* tiles_dev, int ntiles,
+                           int max_ct_taps, void* stream);
 
 /* Halo-staged weight gradient for the 3x3 stride-1 trunk convs with
  * Cin == cout_pad in {48, 64, 96, 192, 384}: persistent workgroups keep their

@@ -24,6 +24,7 @@
 #include "group.h"
 #include "../../include/semseg_hip.h"
 #include <limits.h>
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -61,6 +62,9 @@ struct IgemmArgs {
   ssa_conv_desc d;
   const bf16_t* x; const bf16_t* w; const float* bias; void* y; double* stats;
   int tiles_n, tr_shift;
+  // strided output (parity classes of a stride-2 data gradient, ssa_conv2d_dgrad_s2): GEMM row
+  // m = (b, oy, ox) is stored at pixel b*o_HW + (oy*o_mul + o_py)*o_W + ox*o_mul + o_px; o_mul = 0: pixel m
+  int o_mul, o_py, o_px, o_W, o_HW;
 };
 
 template <int WGM, int WGN, int MI, int NI>
@@ -116,6 +120,13 @@ struct ConvIgemm {
   }
   const int tr_mask = (1 << tr_shift) - 1;
   const int nk = d.Kpad / BK;
+  const int o_mul = a.o_mul, o_py = a.o_py, o_px = a.o_px, o_W = a.o_W, o_HW = a.o_HW;
+  auto opix = [&](int m) -> long {
+    if (o_mul == 0) return m;
+    const int b = m / HoWo, rem = m - b * HoWo;
+    const int oy = rem / d.Wo, ox = rem - oy * d.Wo;
+    return (long)b * o_HW + (long)(oy * o_mul + o_py) * o_W + ox * o_mul + o_px;
+  };
 
   uint4 ra[A_IT], rb[B_IT];
   auto gload = [&](int kt) {
@@ -197,7 +208,7 @@ struct ConvIgemm {
         for (int r = 0; r < 16; ++r) {
           const int row = wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const int m = m0 + row;
-          if (m < M && n < d.Cout) y[(long)m * d.ldy + n] = acc[mi][ni][r] + bv;
+          if (m < M && n < d.Cout) y[opix(m) * d.ldy + n] = acc[mi][ni][r] + bv;
         }
       }
     return;
@@ -254,7 +265,7 @@ struct ConvIgemm {
     const int row = idx / CPR, cp = idx - row * CPR;
     const int m = m0 + row, n = n0 + cp * 8;
     if (m >= M || n >= d.Cout) continue;
-    bf16_t* dst = y + (long)m * d.ldy + n;
+    bf16_t* dst = y + opix(m) * d.ldy + n;
     const bf16_t* src = Cs + row * LDC + cp * 8;
     if (n + 8 <= d.Cout) {
       *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
@@ -497,10 +508,25 @@ struct PackJob {           // mirror of ssa_pack_job (include/semseg_hip.h)
   int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, pad_;
 };
 
+// Stride-2 data gradient by output parity (ssa_conv2d_dgrad_s2): dx[2m+p] along one axis of a 3-tap,
+// pad-1, stride-2 conv is  p = 0: w[1]*dy[m];  p = 1: w[2]*dy[m] + w[0]*dy[m+1]  -- a correlation of dy
+// with 1 + p taps; tap j of class p is forward tap s2_tap(p, j).
+__host__ __device__ __forceinline__ int s2_tap(int p, int j) { return p == 0 ? 1 : 2 - 2 * j; }
+
+// mode 0: forward operand, 1: data-gradient operand (transposed, taps flipped), 4 + 2*py + px: the
+// data-gradient operand of parity class (py, px) of a 3x3 stride-2 conv: rows = Cin, k = (jy, jx, co).
 __device__ __forceinline__ bf16_t pack_one(const float* __restrict__ w, int Cout, int Cin, int KH,
                                            int KW, int cin_pad, int cout_pad, int mode, int r, int k) {
   float v = 0.f;
-  if (mode == 0) {
+  if (mode >= 4) {
+    const int py = (mode - 4) >> 1, px = (mode - 4) & 1;
+    const int kw_n = 1 + px, ntap = (1 + py) * kw_n;
+    const int tap = k / cout_pad, co = k - tap * cout_pad;
+    if (tap < ntap && co < Cout && r < Cin) {
+      const int jy = tap / kw_n, jx = tap - jy * kw_n;
+      v = w[(((long)co * Cin + r) * KH + s2_tap(py, jy)) * KW + s2_tap(px, jx)];
+    }
+  } else if (mode == 0) {
     const int tap = k / cin_pad, ci = k - tap * cin_pad;
     if (tap < KH * KW && ci < Cin && r < Cout) {
       const int kh = tap / KW, kw = tap - kh * KW;
@@ -522,7 +548,7 @@ __device__ __forceinline__ bf16_t pack_one(const float* __restrict__ w, int Cout
 // [rows][Kpad].  mode 2/3 (MFMA-fragment order, conv_tile.hip):
 // [n-block][k-step][lane][8] with row = nb*32 + (lane&31), k = ks*16 + 8*(lane>>5) + j.
 __device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int* r, int* k) {
-  if (mode < 2) {
+  if (mode < 2 || mode >= 4) {
     *r = (int)(i / Kpad);
     *k = (int)(i - (long)*r * Kpad);
   } else {
@@ -545,6 +571,12 @@ __device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int* r, i
 __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob* __restrict__ jobs) {
   extern __shared__ float rowbuf[];
   const PackJob j = jobs[blockIdx.y];
+  if (j.mode >= 4) {                                       // parity-class operands: element-wise
+    for (int r = blockIdx.x; r < j.rows; r += gridDim.x)
+      for (int k = threadIdx.x; k < j.Kpad; k += 256)
+        j.out[(long)r * j.Kpad + k] = pack_one(j.w, j.Cout, j.Cin, j.KH, j.KW, j.cin_pad, j.cout_pad, j.mode, r, k);
+    return;
+  }
   const int taps = j.KH * j.KW;
   const int transposed = j.mode & 1;
   const int rows_real = transposed ? j.Cin : j.Cout;      // rows that carry data
@@ -588,6 +620,66 @@ __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob
   }
 }
 
+// Tiled form of the batched repack: one workgroup per (job, 32 output channels x CT input channels)
+// tile of the OIHW tensor.  The tile is read with unit stride (32 runs of CT*taps floats) into LDS
+// for BOTH operand forms -- the transposed (data-gradient) form used to gather 36-byte runs at a
+// stride of Cin*taps floats --, permuted there, and written as 16-byte pieces of 8 consecutive k
+// (fragment-major forms: lanes run over the operand row, i.e. whole 1-KiB fragment blocks; row-major
+// forms: lanes run along k).  Work is balanced by tile, not by job (the old grid gave the 3.3 M-element
+// head filters and the 20 K-element branch filters 32 workgroups each).  Zero padding (rows beyond the
+// real ones, k beyond Kdim) is never written here: the destination is cleared when it is allocated and
+// packed once in full by ssa_pack_filter.
+__global__ __launch_bounds__(256) void pack_filters_tiled_kernel(const PackJob* __restrict__ jobs,
+                                                                 const int4* __restrict__ tiles) {
+  extern __shared__ float tbuf[];
+  const int4 t = tiles[blockIdx.x];
+  const PackJob j = jobs[t.x];
+  const int taps = j.KH * j.KW;
+  const int co0 = t.y, ci0 = t.z, CT = t.w;
+  const int nco = min(32, j.Cout - co0), nci = min(CT, j.Cin - ci0);
+  const int run = nci * taps, rowlen = (CT * taps) | 1;
+  for (int idx = threadIdx.x; idx < nco * run; idx += 256) {
+    const int row = idx / run, i = idx - row * run;
+    tbuf[row * rowlen + i] = j.w[((long)(co0 + row) * j.Cin + ci0) * taps + i];
+  }
+  __syncthreads();
+  const int cls = j.mode >= 4 ? j.mode - 4 : -1;          // parity class (py, px) of a stride-2 data gradient
+  const int transposed = (j.mode & 1) || cls >= 0;
+  const int cpy = cls >> 1, cpx = cls & 1, ckw = 1 + cpx;
+  const int otaps = cls >= 0 ? (1 + cpy) * ckw : taps;     // taps of the OPERAND
+  // operand row r and the channel c that runs along k inside a tap
+  const int nr = transposed ? nci : nco, nc = transposed ? nco : nci;
+  const int r0 = transposed ? ci0 : co0, c0 = transposed ? co0 : ci0;
+  const int cpad = transposed ? j.cout_pad : j.cin_pad;
+  const int ng = (nc + 7) >> 3;                          // 8-channel groups of this tile (c0 is a multiple of 8)
+  const int ksteps = j.Kpad >> 4;
+  const int items = otaps * ng * nr;
+  const bool frag = j.mode == 2 || j.mode == 3;
+  for (int idx = threadIdx.x; idx < items; idx += 256) {
+    int rl, g, tap;
+    if (frag) { rl = idx % nr; const int q = idx / nr; g = q % ng; tap = q / ng; }
+    else { g = idx % ng; const int q = idx / ng; tap = q % otaps; rl = q / otaps; }
+    int tsrc = transposed ? (taps - 1 - tap) : tap;                  // flipped taps for the data gradient
+    if (cls >= 0) tsrc = s2_tap(cpy, tap / ckw) * j.KW + s2_tap(cpx, tap % ckw);
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cl = g * 8 + e;
+      float f = 0.f;
+      if (cl < nc) f = transposed ? tbuf[cl * rowlen + rl * taps + tsrc] : tbuf[rl * rowlen + cl * taps + tsrc];
+      v[e] = f2bf(f);
+    }
+    const int r = r0 + rl, k = tap * cpad + c0 + g * 8;
+    long o;
+    if (!frag) o = (long)r * j.Kpad + k;
+    else o = ((((long)(r >> 5) * ksteps + (k >> 4)) * 64) + (r & 31) + 32 * ((k & 15) >> 3)) * 8;
+    uint4 pk;
+    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
+    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<uint4*>(j.out + o) = pk;
+  }
+}
+
 __global__ void pack_filter_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout,
                                    int Cin, int KH, int KW, int cin_pad, int cout_pad, int Kpad,
                                    int mode, int rows) {
@@ -595,7 +687,7 @@ __global__ void pack_filter_kernel(const float* __restrict__ w, bf16_t* __restri
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int r, k;
     pack_index(i, Kpad, mode, &r, &k);
-    out[i] = pack_one(w, Cout, Cin, KH, KW, cin_pad, cout_pad, mode & 1, r, k);
+    out[i] = pack_one(w, Cout, Cin, KH, KW, cin_pad, cout_pad, mode >= 4 ? mode : (mode & 1), r, k);
   }
 }
 
@@ -634,9 +726,11 @@ int choose_fwd_tile(long M, int N) {
   return best;
 }
 
+struct OutMap { int mul, py, px, W, HW; };
+
 template <int WGM, int WGN, int MI, int NI>
 int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
-               hipStream_t s, int tr_shift, double* stats = nullptr) {
+               hipStream_t s, int tr_shift, double* stats = nullptr, const OutMap* om = nullptr) {
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
   const long M = (long)d.B * d.Ho * d.Wo;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (d.Cout + BN - 1) / BN;
@@ -646,6 +740,8 @@ int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float
   IgemmArgs a;
   a.d = d; a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
   a.tiles_n = tiles_n; a.tr_shift = tr_shift;
+  a.o_mul = om ? om->mul : 0; a.o_py = om ? om->py : 0; a.o_px = om ? om->px : 0;
+  a.o_W = om ? om->W : 0; a.o_HW = om ? om->HW : 0;
   return ssa::submit<ConvIgemm<WGM, WGN, MI, NI>>(a, tiles_m * tiles_n, 1, lds, s);
 }
 
@@ -721,6 +817,42 @@ int ssa_conv2d_igemm_stats(const ssa_conv_desc* dp, const void* x, const void* w
   }
 }
 
+int ssa_conv2d_dgrad_s2(int B, int H, int W, int Cin, int lddx, int Ho, int Wo, int cout_pad, int lddy,
+                        const void* dy, const void* const* w_cls, const int* kpad_cls, void* dx,
+                        void* stream) {
+  if (!dy || !w_cls || !kpad_cls || !dx) return SSA_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 8 || lddx % 8 || cout_pad % 8 || lddy % 8) return SSA_EINVAL;
+  if (Ho != (H - 1) / 2 + 1 || Wo != (W - 1) / 2 + 1) return SSA_EINVAL;      // 3x3, stride 2, pad 1
+  if (!aligned16(dy) || !aligned16(dx)) return SSA_EINVAL;
+  if ((long)B * H * W >= INT_MAX / 2) return SSA_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    const int Hc = (H - py + 1) / 2, Wc = (W - px + 1) / 2;      // pixels of dx with this parity
+    if (Hc <= 0 || Wc <= 0) continue;
+    if (!w_cls[cls] || !aligned16(w_cls[cls])) return SSA_EINVAL;
+    ssa_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.B = B; d.H = Ho; d.W = Wo; d.Cin = cout_pad; d.ldx = lddy;
+    d.Ho = Hc; d.Wo = Wc; d.Cout = Cin; d.ldy = lddx;
+    d.KH = 1 + py; d.KW = 1 + px; d.stride = 1; d.pad = 0; d.dil = 1; d.transposed = 0;
+    d.Kpad = kpad_cls[cls]; d.out_f32 = 0; d.cfg = -1;
+    if (d.Kpad % BK || d.Kpad < d.KH * d.KW * d.Cin) return SSA_EINVAL;
+    const OutMap om{2, py, px, W, H * W};
+    int rc;
+    switch (choose_fwd_tile((long)B * Hc * Wc, Cin)) {
+      case 0: rc = launch_fwd<2, 2, 2, 2>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+      case 1: rc = launch_fwd<4, 1, 2, 2>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+      case 2: rc = launch_fwd<4, 1, 1, 3>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+      case 3: rc = launch_fwd<4, 1, 2, 1>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+      case 4: rc = launch_fwd<2, 2, 1, 1>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+      default: rc = launch_fwd<2, 2, 2, 1>(d, dy, w_cls[cls], nullptr, dx, s, 0, nullptr, &om); break;
+    }
+    if (rc) return rc;
+  }
+  return SSA_OK;
+}
+
 int ssa_conv2d_igemm(const ssa_conv_desc* dp, const void* x, const void* w_packed,
                      const float* bias, void* y, void* stream) {
   return ssa_conv2d_igemm_stats(dp, x, w_packed, bias, y, nullptr, stream);
@@ -734,10 +866,12 @@ int ssa_conv2d_igemm_tile(const ssa_conv_desc* dp) {
 
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
                     int cin_pad, int cout_pad, int Kpad, int mode, void* stream) {
-  if (!w_oihw || !w_packed || mode < 0 || mode > 3) return SSA_EINVAL;
-  int rows = (mode & 1) == 0 ? Cout : Cin;
-  const long kneed = (long)KH * KW * ((mode & 1) == 0 ? cin_pad : cout_pad);
-  if (mode < 2) {
+  if (!w_oihw || !w_packed || mode < 0 || mode > 7) return SSA_EINVAL;
+  if (mode >= 4 && (KH != 3 || KW != 3)) return SSA_EINVAL;
+  int rows = (mode & 1) == 0 && mode < 4 ? Cout : Cin;
+  long kneed = (long)KH * KW * ((mode & 1) == 0 ? cin_pad : cout_pad);
+  if (mode >= 4) kneed = (long)(1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) * cout_pad;
+  if (mode < 2 || mode >= 4) {
     if (Kpad % BK || Kpad < kneed) return SSA_EINVAL;
   } else {
     if (Kpad != kneed || Kpad % 16) return SSA_EINVAL;
@@ -803,6 +937,26 @@ int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job
   static_assert(sizeof(PackJob) == 64, "ssa_pack_job layout");
   hipLaunchKernelGGL(pack_filters_batched_kernel, dim3(blocks_per_job, njobs), dim3(256), 48 * 1024,
                      (hipStream_t)stream, (const PackJob*)jobs_dev);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_pack_tile_channels(int KH, int KW) {
+  const int taps = KH * KW;
+  if (taps < 1) return 0;
+  int ct = (288 / taps) & ~7;
+  if (ct > 256) ct = 256;
+  if (ct < 8) ct = 8;
+  return ((size_t)32 * ((ct * taps) | 1) * sizeof(float) <= 64 * 1024) ? ct : 0;
+}
+
+int ssa_pack_filters_tiled(const void* jobs_dev, const void* tiles_dev, int ntiles, int max_ct_taps,
+                           void* stream) {
+  if (!jobs_dev || !tiles_dev || ntiles < 1 || max_ct_taps < 1) return SSA_EINVAL;
+  const size_t lds = (size_t)32 * (max_ct_taps | 1) * sizeof(float);     // the largest ct * KH * KW of the tiles
+  if (lds > 64 * 1024) return SSA_EINVAL;
+  hipLaunchKernelGGL(pack_filters_tiled_kernel, dim3(ntiles), dim3(256), lds, (hipStream_t)stream,
+                     (const PackJob*)jobs_dev, (const int4*)tiles_dev);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

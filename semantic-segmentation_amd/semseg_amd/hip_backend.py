@@ -130,12 +130,30 @@ class _Packed:
 
 
 _PACKED = {}
-_JOB_TABLE = {"key": None, "dev": None, "n": 0}
+_JOB_TABLE = {"key": None, "dev": None, "n": 0, "tiles": None, "ntiles": 0, "max_ct_taps": 0}
+_PACK_TILED = os.environ.get("SSA_PACK_TILED", "1") != "0"
 
 
 def clear_pack_cache():
     _PACKED.clear()
-    _JOB_TABLE.update(key=None, dev=None, n=0)
+    _JOB_TABLE.update(key=None, dev=None, n=0, tiles=None, ntiles=0, max_ct_taps=0)
+
+
+def _pack_tiles(jobs, device):
+    """Work list of ssa_pack_filters_tiled: every job's [Cout] x [Cin] plane in 32 x ct tiles.
+    -> (device int32 [ntiles, 4], ntiles, max ct*taps), or None when a filter is too large for that path."""
+    L = lib()
+    tiles, worst = [], 0
+    for i, j in enumerate(jobs):
+        ct = L.ssa_pack_tile_channels(j.KH, j.KW)
+        if ct <= 0:
+            return None
+        worst = max(worst, ct * j.KH * j.KW)
+        for co0 in range(0, j.Cout, 32):
+            for ci0 in range(0, j.Cin, ct):
+                tiles.append((i, co0, ci0, ct))
+    t = torch.tensor(tiles, dtype=torch.int32).reshape(-1, 4)
+    return t.to(device), len(tiles), worst
 
 
 def invalidate_packed_filters():
@@ -167,9 +185,16 @@ def refresh_packed_filters():
     if _JOB_TABLE["key"] != tkey:
         arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        _JOB_TABLE.update(key=tkey, dev=host.to(stale[0][2].device), n=len(stale))
-    check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 32, _s()),
-          "ssa_pack_filters_batched")
+        dev = stale[0][2].device
+        tl = _pack_tiles([e.job for _, e, _ in stale], dev) if _PACK_TILED else None
+        _JOB_TABLE.update(key=tkey, dev=host.to(dev), n=len(stale), tiles=tl[0] if tl else None,
+                          ntiles=tl[1] if tl else 0, max_ct_taps=tl[2] if tl else 0)
+    if _JOB_TABLE["tiles"] is not None:
+        check(lib().ssa_pack_filters_tiled(_p(_JOB_TABLE["dev"]), _p(_JOB_TABLE["tiles"]), _JOB_TABLE["ntiles"],
+                                           _JOB_TABLE["max_ct_taps"], _s()), "ssa_pack_filters_tiled")
+    else:
+        check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 32, _s()),
+              "ssa_pack_filters_batched")
     for _, e, w in stale:
         e.version = w._version
 
@@ -180,11 +205,13 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
-    if mode & 1 == 0:
+    if mode >= 4:               # parity class (py, px) of a stride-2 data gradient: (1+py)*(1+px) taps
+        rows, kdim = Cin, (1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) * cout_pad
+    elif mode & 1 == 0:
         rows, kdim = Cout, KH * KW * cin_pad
     else:
         rows, kdim = Cin, KH * KW * cout_pad
-    if mode < 2:
+    if mode < 2 or mode >= 4:
         Kpad = _roundup(kdim, 32)
     else:                       # MFMA-fragment order (conv_tile.hip): rows padded to 32, K exact
         rows, Kpad = _roundup(rows, 32), kdim
@@ -195,7 +222,7 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     if e is None or e.wref() is None or e.shape != tuple(weight.shape):
         e = _Packed()
         e.shape = tuple(weight.shape)
-        e.out = torch.empty((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)
+        e.out = torch.zeros((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)    # the tiled repack keeps the padding
         e.Kpad = Kpad
         e.wref = weakref.ref(weight)
         e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows)
@@ -508,9 +535,31 @@ def _conv_dgrad(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw, 
     if use_tile or use_halo:
         wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
         return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
+    if _DGRAD_S2 and stride == 2 and (KH, KW) == (3, 3) and pad == 1 and dil == 1 and Cin % 8 == 0 and al and \
+            lddy % 8 == 0 and (Ho, Wo) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1):
+        return _dgrad_s2(x_shape, weight, dyb, lddy, cout_pad, out_hw)
     wpt, Kpad = _packed_filter(weight, 1, 0, cout_pad)
     return _igemm(dyb, lddy, (B, Ho, Wo, cout_pad), wpt, Kpad, None, (H, W), Cin, (KH, KW), stride,
                   dil * (KH - 1) - pad, dil, stride > 1, False)
+
+
+_DGRAD_S2 = os.environ.get("SSA_DGRAD_S2", "1") != "0"
+
+
+def _dgrad_s2(x_shape, weight, dyb, lddy, cout_pad, out_hw):
+    """Data gradient of a 3x3 stride-2 pad-1 conv by output parity (ssa_conv2d_dgrad_s2): four dense
+    sub-problems with 1, 2, 2, 4 taps instead of nine taps over the zero-inserted gradient."""
+    B, H, W, Cin = x_shape
+    Ho, Wo = out_hw
+    Cout = weight.shape[0]
+    packs = [_packed_filter(weight, 4 + c, 0, cout_pad) for c in range(4)]
+    dx = torch.empty((B, H, W, Cin), dtype=ACT_DTYPE, device=dyb.device)
+    wp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t, _ in packs])
+    kp = (ctypes.c_int * 4)(*[k for _, k in packs])
+    _note(2.0 * B * Ho * Wo * Cout * Cin * 9, _conv_bytes(B * Ho * Wo, cout_pad, B * H * W, Cin, (3, 3)))
+    check(lib().ssa_conv2d_dgrad_s2(B, H, W, Cin, Cin, Ho, Wo, cout_pad, lddy, _p(dyb), wp, kp, _p(dx), _s()),
+          "ssa_conv2d_dgrad_s2")
+    return dx
 
 
 def dgrad_tile_ok(x_shape, weight, stride, pad, dil, out_hw):

@@ -18,7 +18,7 @@ import pytest
 import torch
 
 HOST_ONLY = ("ssa_version", "ssa_bn_stat_replicas", "ssa_conv2d_igemm_tile", "ssa_group_begin", "ssa_group_end",
-             "ssa_group_abort", "ssa_launch_count", "ssa_profile_note")
+             "ssa_group_abort", "ssa_launch_count", "ssa_profile_note", "ssa_pack_tile_channels")
 
 
 class DryLib:
@@ -126,7 +126,7 @@ def test_train_step_and_eval_glue(name, crit, dry):
         assert p.grad.shape == p.shape and p.grad.dtype == torch.float32, n
     assert dry.calls["ssa_conv2d_wgrad"] + dry.calls["ssa_conv2d_wgrad_head"] + dry.calls["ssa_conv2d_wgrad_tile"] > 0
     assert dry.calls["ssa_bn_update_running_batched"] == 1          # one deferred running-stat update per step
-    assert dry.calls["ssa_pack_filters_batched"] <= 1
+    assert dry.calls["ssa_pack_filters_tiled"] + dry.calls["ssa_pack_filters_batched"] <= 1
     # second step: the filter cache is warm, nothing is re-packed one by one
     before = dry.calls["ssa_pack_filter"]
     net.zero_grad(set_to_none=True)
@@ -159,7 +159,7 @@ def test_fused_sgd_step_glue_and_filter_cache_refresh(dry):
         assert all(p._version > v for p, v in zip(net.parameters(), versions))
         assert dry.calls["ssa_sgd_momentum_step"] == step + 1
     # steps 2 and 3 start from updated parameters: exactly one batched re-pack each, no single packs
-    assert dry.calls["ssa_pack_filters_batched"] == 2
+    assert dry.calls["ssa_pack_filters_tiled"] == 2 and dry.calls["ssa_pack_filters_batched"] == 0
     assert all("momentum_buffer" in opt.state[p] for p in net.parameters())
 
 

@@ -95,6 +95,13 @@ CONV_CASES = [
     (1, 128, 129, 240, 128, 3, 1, 1, 1, False, False),
     (2, 96, 100, 256, 72, 1, 1, 0, 1, False, False),
     (1, 140, 128, 336, 64, 1, 1, 0, 1, True, False),
+    # 3x3 stride-2 down-convs: data gradient by output parity (ssa_conv2d_dgrad_s2) -- odd / even extents,
+    # Cout that is no multiple of 32, one-pixel-wide classes
+    (1, 37, 45, 48, 96, 3, 2, 1, 1, False, False),
+    (2, 33, 64, 96, 200, 3, 2, 1, 1, True, False),
+    (1, 128, 128, 64, 64, 3, 2, 1, 1, False, False),
+    (1, 2, 3, 48, 24, 3, 2, 1, 1, False, False),
+    (1, 1, 9, 48, 48, 3, 2, 1, 1, False, False),
 ]
 
 
@@ -146,6 +153,36 @@ def test_conv_fwd_bwd(case):
     check_close("conv_wgrad %s" % (case,), wd.grad, wr.grad, 1e-2, 4e-3)
     if b is not None:
         check_close("conv_bgrad %s" % (case,), bd.grad, br.grad, 1e-2, 4e-3)
+
+
+def test_stride2_dgrad_by_parity_matches_zero_inserted():
+    """ssa_conv2d_dgrad_s2 (four dense parity classes) against the zero-inserted transposed form it
+    replaces: same operands, same bf16 rounding of the result; the two differ only in the order of the
+    fp32 accumulation (taps that multiply inserted zeros contribute nothing)."""
+    hb = _hb()
+    for (B, H, W, Cin, Cout) in [(1, 64, 64, 48, 96), (2, 31, 50, 96, 96), (1, 17, 16, 192, 384)]:
+        hb.clear_pack_cache()
+        w = _rand(Cout, Cin, 3, 3, seed=11, scale=0.05).to(DEV)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dy = nhwc(_rand(B, Cout, Ho, Wo, seed=12)).to(DEV).to(torch.bfloat16).contiguous()
+        assert hb._DGRAD_S2
+        got = hb._conv_dgrad((B, H, W, Cin), w, dy, Cout, Cout, 2, 1, 1, (Ho, Wo))
+        hb._DGRAD_S2 = False
+        try:
+            want = hb._conv_dgrad((B, H, W, Cin), w, dy, Cout, Cout, 2, 1, 1, (Ho, Wo))
+        finally:
+            hb._DGRAD_S2 = True
+        torch.cuda.synchronize()
+        assert got.shape == want.shape == (B, H, W, Cin)
+        check_close("dgrad_s2 %s" % ((B, H, W, Cin, Cout),), got.float(), want.float(), 8e-3, 1e-3)
+        # inside a group bracket: the four classes leave as one launch per tile instantiation
+        hb.lib().ssa_launch_count(1)
+        with hb.group():
+            got2 = hb._conv_dgrad((B, H, W, Cin), w, dy, Cout, Cout, 2, 1, 1, (Ho, Wo))
+        torch.cuda.synchronize()
+        assert hb.lib().ssa_launch_count(1) <= (1 if H % 2 == 0 and W % 2 == 0 else 4)
+        assert torch.equal(got2.view(torch.int16), got.view(torch.int16))
+    hb.clear_pack_cache()
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
@@ -264,15 +301,20 @@ def test_batched_filter_repack():
     hb = _hb()
     hb.clear_pack_cache()
     ws = [torch.randn(48, 48, 3, 3, device=DEV), torch.randn(19, 512, 1, 1, device=DEV),
-          torch.randn(96, 48, 3, 3, device=DEV), torch.randn(64, 3, 3, 3, device=DEV)]
+          torch.randn(96, 48, 3, 3, device=DEV), torch.randn(64, 3, 3, 3, device=DEV),
+          torch.randn(512, 720, 3, 3, device=DEV), torch.randn(40, 300, 1, 1, device=DEV),
+          torch.randn(24, 3, 7, 7, device=DEV), torch.randn(384, 192, 3, 3, device=DEV)]
     specs = [(0, 48, 0), (1, 0, 48), (0, 512, 0), (1, 0, 24), (0, 48, 0), (1, 0, 96), (0, 16, 0),
-             (2, 48, 0), (3, 0, 48), (2, 512, 0), (2, 48, 0), (3, 0, 96), (2, 16, 0)]     # fragment-major forms
-    owners = [0, 0, 1, 1, 2, 2, 3, 0, 0, 1, 2, 2, 3]
+             (2, 48, 0), (3, 0, 48), (2, 512, 0), (2, 48, 0), (3, 0, 96), (2, 16, 0),     # fragment-major forms
+             (0, 720, 0), (1, 0, 512), (2, 720, 0), (3, 0, 512), (0, 304, 0), (1, 0, 40), (0, 8, 0), (1, 0, 24),
+             (0, 192, 0), (1, 0, 384), (2, 192, 0), (3, 0, 384)]
+    owners = [0, 0, 1, 1, 2, 2, 3, 0, 0, 1, 2, 2, 3, 4, 4, 4, 4, 5, 5, 6, 6, 7, 7, 7, 7]
     first = [hb._packed_filter(ws[o], *sp)[0] for o, sp in zip(owners, specs)]
     for w in ws:
         w.mul_(-0.5).add_(0.25)                # in-place update, like an optimizer step
     hb.refresh_packed_filters()
     torch.cuda.synchronize()
+    assert hb._JOB_TABLE["tiles"] is not None and hb._JOB_TABLE["ntiles"] > 600     # the tile-balanced kernel ran
     batched = [t.clone() for t in first]       # same persistent buffers, refreshed in place
     hb.clear_pack_cache()
     for o, sp, got in zip(owners, specs, batched):
