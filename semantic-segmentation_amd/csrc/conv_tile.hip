@@ -386,6 +386,7 @@ int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const 
   // leave as ONE launch.  SSA_GROUP_UNIFY=0 keeps the per-problem choice.
   static const bool unify = !(getenv("SSA_GROUP_UNIFY") && atoi(getenv("SSA_GROUP_UNIFY")) == 0);
   const bool grouped = unify && ssa::group_state().depth > 0 && d.cfg < 0;
+  static const bool chunk96 = !(getenv("SSA_TILE_CHUNK96") && atoi(getenv("SSA_TILE_CHUNK96")) == 0);
   const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && (tiles128 >= 512 || grouped)) ? 0 : 2)) : d.cfg;
   const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
   const bool split_n = (cfg & 2) != 0;
@@ -399,11 +400,18 @@ int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const 
       if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
       return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     case 96:
+      // grouped: 96-channel chunks, three taps per (double-buffered) filter stage -- 78 KB of LDS, two
+      // workgroups per CU, and the instantiation the 192- and 384-channel branches share (below)
+      if (grouped && chunk96) return dispatch_geom<96, 3, 1, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
       if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
       if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
       return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     case 192:
-    case 384:      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
+    case 384:
+      // grouped: Cin/96 passes of the 96-channel instantiation -- the 96/192/384-channel problems of a depth
+      // level leave as ONE launch (1,480 workgroups at two per CU instead of three launches of 360-640)
+      if (grouped && chunk96) return dispatch_geom<96, 3, 1, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
       if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
       return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
     default: return SSA_EUNSUPPORTED;
