@@ -77,6 +77,7 @@ struct TileArgs {
   const bf16_t* x; const uint4* wfrag; const float* bias; bf16_t* y; double* stats;
   const bf16_t* aux; const float* coef;
   int ldx, Cin, ldy, B, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux, aux_mode;
+  int variant;              // ConvTileAny: which instantiation runs this problem
 };
 
 template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
@@ -161,31 +162,39 @@ struct ConvTile {
       for (int r = 0; r < 16; ++r) acc[mi][nb][r] = 0.f;
 
   const bf16_t* xb = x + (long)b * H * W * ldx;
+  // this thread's halo pieces: global element offset of channel chunk 0 (-1: outside the image / no piece)
+  constexpr int IT = (NPIECE + 255) / 256;
+  int g_off[IT];
+  uint4 v[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int piece = tid + i * 256;
+    const int pix = piece / CP, cp = piece - pix * CP;
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    const int iy = y0 - R + hy, ix = x0 - R + hx;
+    const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    g_off[i] = ok ? (iy * W + ix) * ldx + cp * 8 : -1;
+  }
+  auto halo_gload = [&](int cc) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+      v[i] = g_off[i] >= 0 ? *reinterpret_cast<const uint4*>(xb + g_off[i] + cc * CK) : make_uint4(0, 0, 0, 0);
+  };
+  halo_gload(0);
   for (int cc = 0; cc < nchunk; ++cc) {
     if (cc > 0) __syncthreads();                // previous chunk's halo image and filter buffers are free
-    // ---- halo tile -> registers, filter stage 0 -> LDS (DMA), halo -> LDS: one burst
-    {
-      constexpr int IT = (NPIECE + 255) / 256;
-      uint4 v[IT];
+    // ---- filter stage 0 -> LDS (DMA), halo registers -> LDS
+    stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, 0, Bs, wave, lane);
 #pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int piece = tid + i * 256;
-        const int pix = piece / CP, cp = piece - pix * CP;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        const int iy = y0 - R + hy, ix = x0 - R + hx;
-        const bool ok = piece < NPIECE && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        v[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cc * CK + cp * 8)
-                  : make_uint4(0, 0, 0, 0);
-      }
-      stage_filter_chunk<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc, 0, Bs, wave, lane);
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int piece = tid + i * 256;
-        const int pix = piece / CP, cp = piece - pix * CP;
-        if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
-      }
+    for (int i = 0; i < IT; ++i) {
+      const int piece = tid + i * 256;
+      const int pix = piece / CP, cp = piece - pix * CP;
+      if (piece < NPIECE) *reinterpret_cast<uint4*>(smem + pix * PSB + cp * 16) = v[i];
     }
     __syncthreads();                            // halo + filter stage 0 landed (vmcnt(0) + barrier)
+    // the next channel chunk's halo: issued now, in flight during this chunk's MFMAs (192/384 channels =
+    // 2/4 chunks; their load -> barrier -> MFMA chains are the longest workgroups of a grouped launch)
+    if (cc + 1 < nchunk) halo_gload(cc + 1);
 
 #pragma unroll
     for (int st = 0; st < NSTAGE; ++st) {
@@ -306,12 +315,30 @@ struct ConvTile {
   }
 };
 
+// The two instantiations every grouped trunk level uses -- 48 channels (both n-blocks per workgroup) and
+// the 96-channel chunked one (96/192/384 channels) -- behind ONE kernel: a depth level's 3x3 convs
+// leave as a single launch (~1,500 workgroups of either kind, ~78 KB of LDS each, two per CU), so
+// the tail of one kind overlaps the body of the other.
+template <bool AUX>
+struct ConvTileAny {
+  typedef TileArgs Args;
+  static constexpr int NT = 256;
+  typedef ConvTile<48, 3, 2, 1, 32, 9, AUX> V0;
+  typedef ConvTile<96, 3, 1, 1, 32, 3, AUX> V1;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) {
+    if (a.variant == 0) V0::run(a, bx, by, gx);
+    else V1::run(a, bx, by, gx);
+  }
+};
+
 struct AuxArgs {
   const void* aux;
   int ld;
   const float* coef;
   int mode;               // 0: none, 1: add, 2: BatchNorm backward sums
 };
+
+static thread_local bool g_any_kernel = false;   // set by tile_impl: grouped launch through ConvTileAny
 
 template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
 int launch_tile_v(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
@@ -331,6 +358,21 @@ int launch_tile_v(const ssa_conv_desc& d, const void* x, const void* wfrag, cons
   a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + TW - 1) / TW; a.tiles_y = (d.H + TH - 1) / TH;
   a.ldaux = ax.ld; a.aux_mode = ax.mode;
+  a.variant = -1;
+  if constexpr (KS == 3 && MI == 1 && TW == 32 && ((CK == 48 && NB == 2 && TPC == 9) || (CK == 96 && NB == 1 && TPC == 3))) {
+    if (g_any_kernel) {
+      a.variant = CK == 48 ? 0 : 1;
+      constexpr size_t halo_b = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (96 * 2 + 16) + 1023) / 1024 * 1024;
+      constexpr size_t lds_b = halo_b + (size_t)2 * 1 * 3 * (96 / 16) * 1024;
+      constexpr size_t halo_a = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (48 * 2 + 16) + 1023) / 1024 * 1024;
+      constexpr size_t lds_a = halo_a + (size_t)1 * 2 * 9 * (48 / 16) * 1024;
+      constexpr size_t stage_a = (size_t)(AUX ? 2 : 1) * BM * (2 * 32 + 8) * 2 + 4 * 2 * 2 * 32 * sizeof(float);
+      size_t lds_any = lds_a > lds_b ? lds_a : lds_b;
+      if (stage_a > lds_any) lds_any = stage_a;
+      if (lds > lds_any) lds_any = lds;
+      return ssa::submit<ConvTileAny<AUX>>(a, a.tiles_x * a.tiles_y * d.B, (a.nb_total + NB - 1) / NB, lds_any, s);
+    }
+  }
   return ssa::submit<ConvTile<CK, KS, NB, MI, TW, TPC, AUX>>(a, a.tiles_x * a.tiles_y * d.B,
                                                              (a.nb_total + NB - 1) / NB, lds, s);
 }
@@ -391,6 +433,8 @@ int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const 
   const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
   const bool split_n = (cfg & 2) != 0;
   g_wide_tiles = grouped;
+  static const bool any_on = !(getenv("SSA_TILE_ANY") && atoi(getenv("SSA_TILE_ANY")) == 0);
+  g_any_kernel = grouped && chunk96 && any_on;
   switch (d.Cin) {
     case 48:
       if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
