@@ -53,6 +53,27 @@ __device__ __forceinline__ void block_reduce_2x8(const float* v0, const float* v
   }
 }
 
+// Sum of the statistics replicas of channel c ([nrep][2][C] fp64), in replica order.  The (up to 8,
+// kStatReplicas of the conv epilogues) replica loads are issued TOGETHER: a rolled loop over a run-time
+// nrep waits for each pair of loads in turn -- eight L2 round trips in the prologue of every workgroup
+// of every apply / backward-apply launch (11-19 us for a TWO-workgroup launch before this).
+__device__ __forceinline__ void replica_sums(const double* __restrict__ sums, int nrep, int C, int c,
+                                             double* s1, double* s2) {
+  double v1[8], v2[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const bool ok = r < nrep;
+    v1[r] = ok ? sums[(long)r * 2 * C + c] : 0.0;
+    v2[r] = ok ? sums[(long)r * 2 * C + C + c] : 0.0;
+  }
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { a += v1[r]; b += v2[r]; }      // adding +0.0 for r >= nrep changes nothing
+  for (int r = 8; r < nrep; ++r) { a += sums[(long)r * 2 * C + c]; b += sums[(long)r * 2 * C + C + c]; }
+  *s1 = a;
+  *s2 = b;
+}
+
 __device__ __forceinline__ void bn_stats_body(const bf16_t* __restrict__ x, long P, int C,
                                                       int ld, double* __restrict__ sums,
                                                       long pix_per_block, const int bx) {
@@ -181,7 +202,7 @@ __device__ __forceinline__ void bn_apply_train_body(
   // every workgroup derives the per-channel coefficients once (thread c -> channel c)
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+    replica_sums(sums, nrep, C, c, &s1, &s2);
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -312,7 +333,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   const int t = threadIdx.x;
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < nrep; ++r) { s1 += sums[(long)r * 2 * C + c]; s2 += sums[(long)r * 2 * C + C + c]; }
+    replica_sums(sums, nrep, C, c, &s1, &s2);
     const float is_ = invstd[c];
     sh[c] = mean[c];
     sh[C + c] = is_;

@@ -638,9 +638,21 @@ __global__ __launch_bounds__(256) void pack_filters_tiled_kernel(const PackJob* 
   const int co0 = t.y, ci0 = t.z, CT = t.w;
   const int nco = min(32, j.Cout - co0), nci = min(CT, j.Cin - ci0);
   const int run = nci * taps, rowlen = (CT * taps) | 1;
-  for (int idx = threadIdx.x; idx < nco * run; idx += 256) {
-    const int row = idx / run, i = idx - row * run;
-    tbuf[row * rowlen + i] = j.w[((long)(co0 + row) * j.Cin + ci0) * taps + i];
+  if ((run & 3) == 0 && ((j.Cin * taps) & 3) == 0 && ((ci0 * taps) & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(j.w) & 15u) == 0) {
+    // 16-byte loads: every run (row of the tile) starts on a 16-byte boundary
+    const int run4 = run >> 2;
+    for (int idx = threadIdx.x; idx < nco * run4; idx += 256) {
+      const int row = idx / run4, i = (idx - row * run4) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(j.w + ((long)(co0 + row) * j.Cin + ci0) * taps + i);
+      float* d = tbuf + row * rowlen + i;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < nco * run; idx += 256) {
+      const int row = idx / run, i = idx - row * run;
+      tbuf[row * rowlen + i] = j.w[((long)(co0 + row) * j.Cin + ci0) * taps + i];
+    }
   }
   __syncthreads();
   const int cls = j.mode >= 4 ? j.mode - 4 : -1;          // parity class (py, px) of a stride-2 data gradient

@@ -23,8 +23,9 @@
 // grid.y partitions the output (co part, n part) so that a workgroup owns at
 // most 12 accumulator tiles per wave:
 //     C=48: 2 m-blocks x 14 n-blocks (all taps)      C=64: 2 x 18
-//     C=96: 3 x 9 (one kernel row kh per part)       C=192/384: 6 x 6 (one tap,
-//     192 input channels and 192 output channels per part)
+//     C=96: 3 x 9 (one kernel row kh per part)       C=192/384: the C=96 instantiation over
+//     (96 output channels) x (kernel row, 96 input channels) sub-problems -- 12 / 48 parts
+//     (SSA_WGRAD_C96=0: 6 x 6, one tap of 192 input x 192 output channels per part)
 #include "common.h"
 #include "group.h"
 #include "../../include/semseg_hip.h"
@@ -77,23 +78,36 @@ struct ConvWgradTile {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_part = by % n_parts, co_part = by / n_parts;
   const int co0 = co_part * MB * 32;
-  const int n0 = n_part * NBW * 32;
   const int Kflat = 9 * Cin;
-  const int ci_base = n0 % Cin;
+  // Column parts of dW[co][(tap, ci)].  CX = 96 ("row mode", Cin = 96 / 192 / 384): a part is one kernel
+  // row kh x one block of 96 input channels -- n-block nb = (kw = nb / 3, 32 channels (nb % 3) of the
+  // block) --, so the 192- and 384-channel layers run as 2x2 / 4x4 (co block, ci block) sub-problems of
+  // the 96-channel instantiation.  Otherwise a part is NBW*32 consecutive columns.
+  constexpr bool ROWS = CX == 96;
+  const int n0 = ROWS ? 0 : n_part * NBW * 32;
+  const int ci_base = ROWS ? (n_part / 3) * 96 : n0 % Cin;
 
   // per-lane constants of the B (x) fragments of this wave's n-blocks
   const int li = lane & 15, lj = li >> 2, lq = li & 3, lg = (lane >> 4) & 1, lh = lane >> 5;
   int b_off[NBL];
-  bool b_ok[NBL];
+  int kcol0[NBL];             // first dW column of n-block l (-1: none)
 #pragma unroll
   for (int l = 0; l < NBL; ++l) {
     const int nb = wave + 4 * l;
-    const int n16 = n0 + nb * 32 + 16 * lg;
-    b_ok[l] = nb < NBW && n16 < Kflat;
-    const int tap = b_ok[l] ? n16 / Cin : 0;
-    const int ci = b_ok[l] ? n16 - tap * Cin - ci_base : -4 * lq;   // invalid: offset 0 (in bounds, discarded)
-    const int kh = tap / 3, kw = tap - kh * 3;
-    b_off[l] = (kh * HW_ + kw) * SX + (ci + 4 * lq) * 2;
+    if constexpr (ROWS) {
+      const int kh = n_part % 3, kw = nb / 3, c32 = (nb - kw * 3) * 32;
+      const bool ok = nb < NBW;
+      b_off[l] = ok ? (kh * HW_ + kw) * SX + (c32 + 16 * lg + 4 * lq) * 2 : 0;
+      kcol0[l] = ok ? (kh * 3 + kw) * Cin + ci_base + c32 : -1;
+    } else {
+      const int n16 = n0 + nb * 32 + 16 * lg;
+      const bool ok = nb < NBW && n16 < Kflat;
+      const int tap = ok ? n16 / Cin : 0;
+      const int ci = ok ? n16 - tap * Cin - ci_base : -4 * lq;   // invalid: offset 0 (in bounds, discarded)
+      const int kh = tap / 3, kw = tap - kh * 3;
+      b_off[l] = (kh * HW_ + kw) * SX + (ci + 4 * lq) * 2;
+      kcol0[l] = nb < NBW ? n0 + nb * 32 : -1;
+    }
   }
   const int a_col = (16 * lg + 4 * lq) * 2;     // byte offset of this lane's 4 channels inside an m-block
 
@@ -215,9 +229,8 @@ struct ConvWgradTile {
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int l = 0; l < NBL; ++l) {
-      const int nb = wave + 4 * l;
-      const int kcol = n0 + nb * 32 + (lane & 31);
-      if (nb >= NBW || kcol >= Kflat) continue;
+      const int kcol = kcol0[l] + (lane & 31);
+      if (kcol0[l] < 0 || kcol >= Kflat) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -229,27 +242,38 @@ struct ConvWgradTile {
 
 struct Plan { int cx, mb, nbw, n_parts, co_parts; };
 
+bool c96_on() {
+  static const bool on = !(getenv("SSA_WGRAD_C96") && atoi(getenv("SSA_WGRAD_C96")) == 0);
+  return on;
+}
+
 bool make_plan(int Cin, int cout_pad, Plan* p) {
   if (Cin != cout_pad) return false;
   switch (Cin) {
     case 48: *p = {48, 2, 14, 1, 1}; return true;
     case 64: *p = {64, 2, 18, 1, 1}; return true;
     case 96: *p = {96, 3, 9, 3, 1}; return true;
-    case 192: *p = {192, 6, 6, 9, 1}; return true;
-    case 384: *p = {192, 6, 6, 18, 2}; return true;
+    case 192: *p = c96_on() ? Plan{96, 3, 9, 6, 2} : Plan{192, 6, 6, 9, 1}; return true;
+    case 384: *p = c96_on() ? Plan{96, 3, 9, 12, 4} : Plan{192, 6, 6, 18, 2}; return true;
     default: return false;
   }
+}
+
+constexpr size_t wgrad_tile_lds(int cx, int mb) {
+  return (size_t)6 * 34 * tr_stride_bytes(cx * 2) + (size_t)128 * tr_stride_bytes(mb * 64);
 }
 
 template <int CX, int MB, int NBW>
 int launch(const ssa_conv_desc& d, const Plan& p, const void* x, const void* dy, int lddy, int cout_pad,
            int G, int tiles_per_wg, float* partial, hipStream_t s) {
-  constexpr size_t lds = (size_t)6 * 34 * tr_stride_bytes(CX * 2) + (size_t)128 * tr_stride_bytes(MB * 64);
+  constexpr size_t lds = wgrad_tile_lds(CX, MB);
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
   WgradTileArgs a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
   a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
   a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = tiles_per_wg; a.n_parts = p.n_parts;
+  // (Measured and rejected, profiles/r02_notes.md call P: the 48- and 96-channel instantiations behind one
+  // kernel, as conv_tile.hip's ConvTileAny -- no gain here, a flush's launches are 60-160 us each.)
   return ssa::submit<ConvWgradTile<CX, MB, NBW>>(a, G, p.n_parts * p.co_parts, lds, s);
 }
 
@@ -298,7 +322,9 @@ int ssa_conv2d_wgrad_tile(const ssa_conv_desc* dp, const void* x, const void* dy
     case 48: return launch<48, 2, 14>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
     case 64: return launch<64, 2, 18>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
     case 96: return launch<96, 3, 9>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
-    default: return launch<192, 6, 6>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+    default:
+      if (p.cx == 96) return launch<96, 3, 9>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
+      return launch<192, 6, 6>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
   }
 }
 

@@ -591,7 +591,7 @@ def _add_bf16(a, b):
 # weight gradients: deferred, grouped, accumulated into the gradient arena
 # --------------------------------------------------------------------------
 _WGRAD_TILE = os.environ.get("SSA_WGRAD_TILE", "1") != "0"       # halo-staged kernel for the trunk 3x3 convs
-_WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "16"))       # 128-pixel stages per workgroup in grouped launches
+_WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel stages per workgroup in grouped launches
 _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "96"))  # queued layers that trigger a flush
 _WGRAD_Q = []
 
