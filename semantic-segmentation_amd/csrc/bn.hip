@@ -553,7 +553,7 @@ Grid plan_grid(long P, int C, int rows_per_thread = -1, long max_blocks = 16384)
   return {(int)blocks, ppb};
 }
 Grid plan_reduce_grid(long P, int C) {
-  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 16), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
+  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 8), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
   return plan_grid(P, C, rows, cap);
 }
 
