@@ -46,7 +46,8 @@ def source_sha():
 
 
 def family(kernel):
-    return kernel.split("<")[0]
+    f = kernel.split("<")[0]
+    return "ConvTile" if f == "ConvTileAny" else f      # the two trunk instantiations behind one kernel (conv_tile.hip)
 
 
 def synth_batch(B, H, W, rank, device):

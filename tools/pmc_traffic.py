@@ -19,7 +19,7 @@ def short(name):
     name = re.sub(r"^void ", "", name)
     m = re.match(r"ssa::k_(?:grouped|single)<(\w+)", name)
     if m:
-        return m.group(1)
+        return "ConvTile" if m.group(1) == "ConvTileAny" else m.group(1)
     m = re.match(r"([^(]+)", name)
     n = (m.group(1) if m else name).strip()
     return re.sub(r"<.*", "", n)          # template arguments folded: one row per kernel family
