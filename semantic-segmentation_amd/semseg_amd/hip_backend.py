@@ -592,7 +592,10 @@ def _add_bf16(a, b):
 # --------------------------------------------------------------------------
 _WGRAD_TILE = os.environ.get("SSA_WGRAD_TILE", "1") != "0"       # halo-staged kernel for the trunk 3x3 convs
 _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel stages per workgroup in grouped launches
-_WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "96"))  # queued layers that trigger a flush
+# queued layers that trigger a flush before the end of backward.  Measured (profiles/r02_notes.md, call X): 48 / 96 /
+# 192 / end-of-backward-only = 31.0 / 30.0 / 29.4 / 29.1 ms per step -- the more layers a flush carries, the better its
+# persistent-workgroup launches fill the chip; the queued (x, dy) pairs of a 1024x1024 step are a few GB of 288.
+_WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "100000"))
 _WGRAD_Q = []
 
 
