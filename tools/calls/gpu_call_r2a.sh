@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call A: what round 1 left unverified and is kept (fused SGD, conv_tile_aux epilogues,
 # sibling archs, input-pipeline tail, RCCL inside capture over a one-rank communicator).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2a.log
 : > "$log"

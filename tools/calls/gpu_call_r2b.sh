@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call B: first contact of the lockstep/grouped rewrite with hardware.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2b.log
 : > "$log"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call C: the full GPU suite (incl. the 1024^2 parity tests), the bench line, a rocprofv3
 # kernel trace of the same command, the secondary rows.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2c.log
 : > "$log"

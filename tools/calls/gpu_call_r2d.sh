@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call D: re-run of what call C flagged (tolerance calibration), the new weight-gradient reduce,
 # and A/B timings of the launch-geometry knobs.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2d.log
 : > "$log"

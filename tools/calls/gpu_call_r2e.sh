@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call E: BN block reduce without LDS atomics, per-pixel bilinear for the logits, igemm tile choice
 # reverted; the teacher-forced parity test with the calibrated parameter-gradient tolerance.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2e.log
 : > "$log"

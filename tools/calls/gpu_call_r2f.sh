@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call F: aux-tile prefetch in conv_tile, grouped fan-out gradient sums, bilinear gather with hoisted
 # weights, attnscale heads on hardware.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2f.log
 : > "$log"

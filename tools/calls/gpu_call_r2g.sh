@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call G: attnscale teacher diagnostics, device BICUBIC + prefetcher tests.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2g.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call J: side streams for the buckets of a bracket (parallel branches of the captured graph).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2j.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call L: tile-balanced filter repack, stride-2 data gradient by output parity.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2l.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call M: 96-channel chunked ConvTile instantiation shared by the 96/192/384-channel branches.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2m.log
 : > "$log"

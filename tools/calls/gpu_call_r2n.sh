@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call N: ConvTileAny (48- and 96-chunk instantiations in one launch), next-chunk halo prefetch.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2n.log
 : > "$log"

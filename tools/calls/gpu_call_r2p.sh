@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call P: weight-gradient tile kernel: 192/384 channels as sub-problems of the 96-channel instantiation,
 # 48- and 96-channel instantiations in one launch.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2p.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call Q: BatchNorm apply kernels issue their data loads before the coefficient prologue; strip sweep; trace.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out/r2q_prof
 export TMPDIR=/tmp
 log=gpurun_out/r2q.log

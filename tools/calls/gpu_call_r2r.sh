@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call R: BatchNorm prologues load the statistics replicas together; 16-byte loads in the tiled repack; trace.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out/r2r_prof
 export TMPDIR=/tmp
 log=gpurun_out/r2r.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call S: BatchNorm rows-per-thread sweep after the prologue fix.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2s.log
 : > "$log"

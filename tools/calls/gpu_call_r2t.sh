@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call T: head weight gradient on 2-row tiles (2-3 workgroups per CU); BatchNorm reduce rows.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2t.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call U: ConvTileAny variant with three n-blocks per workgroup (halo read once per 96 output channels).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2u.log
 : > "$log"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, call V (evidence): smoke, the full GPU suite, the bench line with roofline + cpu baseline, rocprofv3
 # kernel trace + stats of the same command, PMC traffic passes (FETCH_SIZE / WRITE_SIZE separately), secondary rows.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out/r2v_prof gpurun_out/r2v_pmc_fetch gpurun_out/r2v_pmc_write
 export TMPDIR=/tmp
 log=gpurun_out/r2v.log

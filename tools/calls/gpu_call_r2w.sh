@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call W: conv_halo_gemm with software-pipelined fragment reads (SSA_HALO_PRE=1).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2w.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call X: weight-gradient flush threshold sweep; clean re-run of the 1024^2 parity tests and the attnscale tests.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2x.log
 : > "$log"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call Y: bench line + rocprofv3 trace of the final default (weight-gradient flush at the end of backward).
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out/r2y_prof
 export TMPDIR=/tmp
 log=gpurun_out/r2y.log

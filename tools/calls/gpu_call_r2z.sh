@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 2, call Z: knob sweep under the single weight-gradient flush.
-cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 mkdir -p gpurun_out
 log=gpurun_out/r2z.log
 : > "$log"
