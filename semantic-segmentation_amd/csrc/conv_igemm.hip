@@ -477,8 +477,16 @@ struct WgradReduceK {
     const float* src0 = partial + (long)co * Kflat;
     for (int k = threadIdx.x; k < Kflat; k += NT) {
       const float* src = src0 + k;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      // eight splits in flight per thread (strips of 8 tiles give a trunk layer 2-80 splits)
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
       int sp = 0;
+      for (; sp + 7 < nsplit; sp += 8) {
+        const float v0 = src[(long)sp * split_stride], v1 = src[(long)(sp + 1) * split_stride];
+        const float v2 = src[(long)(sp + 2) * split_stride], v3 = src[(long)(sp + 3) * split_stride];
+        const float v4 = src[(long)(sp + 4) * split_stride], v5 = src[(long)(sp + 5) * split_stride];
+        const float v6 = src[(long)(sp + 6) * split_stride], v7 = src[(long)(sp + 7) * split_stride];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+      }
       for (; sp + 3 < nsplit; sp += 4) {
         s0 += src[(long)sp * split_stride];
         s1 += src[(long)(sp + 1) * split_stride];
@@ -487,7 +495,7 @@ struct WgradReduceK {
       }
       for (; sp < nsplit; ++sp) s0 += src[(long)sp * split_stride];
       const int tap = k / Cin_pad, ci = k - tap * Cin_pad;
-      if (ci < Cin) sh[ci * taps + tap] = (s0 + s1) + (s2 + s3);
+      if (ci < Cin) sh[ci * taps + tap] = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     }
     __syncthreads();
     float* __restrict__ dst = a.dw + (long)co * Cin * taps;

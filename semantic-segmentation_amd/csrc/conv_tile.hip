@@ -472,6 +472,7 @@ int ssa_conv2d_tile_supported(const ssa_conv_desc* d) {
   if (d->stride != 1 || d->dil != 1 || d->transposed || d->pad != d->KH / 2) return 0;
   if (d->Ho != d->H || d->Wo != d->W || d->out_f32) return 0;
   if (d->Cout % 8 || d->ldy % 8 || d->ldx % 8) return 0;
+  if ((long)d->H * d->W * d->ldx >= (1L << 31)) return 0;      // 32-bit element offsets inside one image
   return d->Cin == 48 || d->Cin == 64 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
 }
 
