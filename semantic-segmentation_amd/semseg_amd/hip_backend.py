@@ -331,6 +331,12 @@ def end_forward():
 def begin_step(device=None):
     _BN_UPDATES.step = {}
     _PENDING_STATS.clear()
+    if _GRADS.armed or _WGRAD_Q:
+        # a backward pass that raised never ran its end-of-backward callback: its queued weight-gradient jobs
+        # and its half-filled gradient slices are abandoned here -- otherwise the arena would stay "armed" and
+        # no later backward pass would ever publish a gradient again
+        del _WGRAD_Q[:]
+        _GRADS.abandon()
     refresh_packed_filters()
     if device is not None:
         _ARENA.reset(device)
@@ -383,6 +389,11 @@ class _GradArena:
             Variable._execution_engine.queue_callback(self.publish)
             self.armed = True
         return v
+
+    def abandon(self):
+        self.armed = False
+        self.chunks = []
+        self.slots = {}
 
     def publish(self):
         self.armed = False

@@ -268,3 +268,33 @@ def test_two_rank_syncbn_ddp_glue():
         # one per (layer, pass) = 2 * 2 * 316 = 1,264; plus the gradient arena chunks and the bias bucket
         assert n_calls // 2 < 700, n_calls
         assert n_elems // 2 >= n_params
+
+
+def test_a_backward_pass_that_raises_does_not_poison_later_steps(dry):
+    """The end-of-backward callback (publication of the gradient arena, the weight-gradient flush) does not run when
+    backward raises: the next step must start from a clean arena instead of staying 'armed' forever (which would
+    leave every later step without gradients)."""
+    from semseg_amd import hip_backend
+    net = _build("deepv3.DeepV3PlusR50", "ce").train()
+    inputs = _batch()
+    loss = net(inputs)
+    boom = {"n": 0}
+    real = hip_backend._bn_bwd
+
+    def failing(*a, **k):
+        boom["n"] += 1
+        if boom["n"] == 3:
+            raise RuntimeError("injected failure in the middle of backward")
+        return real(*a, **k)
+    hip_backend._bn_bwd = failing
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            loss.backward()
+    finally:
+        hip_backend._bn_bwd = real
+    assert hip_backend._GRADS.armed or hip_backend._WGRAD_Q          # the aborted pass left its state behind
+    net.zero_grad(set_to_none=True)
+    net(inputs).backward()                                             # begin_step abandons it
+    assert not hip_backend._WGRAD_Q and not hip_backend._GRADS.slots and not hip_backend._GRADS.armed
+    missing = [n for n, p in net.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
