@@ -77,7 +77,7 @@ __device__ __forceinline__ void replica_sums(const double* __restrict__ sums, in
 __device__ __forceinline__ void bn_stats_body(const bf16_t* __restrict__ x, long P, int C,
                                                       int ld, double* __restrict__ sums,
                                                       long pix_per_block, const int bx) {
-  extern __shared__ float sh[];
+  SSA_DYN_LDS(float, sh);
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
@@ -196,7 +196,7 @@ __device__ __forceinline__ void bn_apply_train_body(
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
     long pix_per_block, const int bx) {
-  extern __shared__ float sh[];                 // [2C]: scale, shift for this launch
+  SSA_DYN_LDS(float, sh);                 // [2C]: scale, shift for this launch
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   // every workgroup derives the per-channel coefficients once (thread c -> channel c)
@@ -273,7 +273,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
     const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
     double* __restrict__ sums, int nrep, long pix_per_block, const float* __restrict__ mscale,
     const float* __restrict__ mshift, const int bx) {
-  extern __shared__ float sh[];
+  SSA_DYN_LDS(float, sh);
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
@@ -328,7 +328,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
     const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg, const int bx) {
-  extern __shared__ float sh[];                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
+  SSA_DYN_LDS(float, sh);                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   for (int c = t; c < C; c += NT) {
@@ -410,7 +410,7 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
 __device__ __forceinline__ void colsum_body(const bf16_t* __restrict__ x, long P, int C,
                                                     int ld, double* __restrict__ sums,
                                                     long pix_per_block, const int bx) {
-  extern __shared__ float sh[];
+  SSA_DYN_LDS(float, sh);
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;

@@ -9,6 +9,33 @@ typedef unsigned short bf16_t;                                   // raw bf16 bit
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));     // MFMA A/B fragment
 typedef float f32x16_t __attribute__((ext_vector_type(16)));     // 32x32 MFMA C/D
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+// The three gfx950-only operations the kernels use go through these wrappers, and dynamic LDS through
+// SSA_DYN_LDS, so that the SAME kernel sources also compile for the CPU emulation harness of the test-suite
+// (tools/emu, -DSSA_EMU: index arithmetic and barrier structure checked without a GPU).  The product build
+// never defines SSA_EMU.
+#ifdef SSA_EMU
+#define SSA_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_lds())
+__device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return emu::mfma_32x32x16_bf16(a, b, c); }
+__device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return emu::ds_read_tr16_b64(lds_ptr); }
+__device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
+#else
+#define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+// D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
+__device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: 4x4 transposing LDS read (lane map: tests/test_kernels_gpu.py::test_probe_tr16)
+__device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(lds_ptr));
+}
+// global -> LDS DMA of 16 bytes per lane: lane l's piece lands at lds_dst (wave-uniform) + 16 * l
+__device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+#endif
 
 #define SSA_OK 0
 #define SSA_EINVAL (-1)

@@ -55,7 +55,7 @@ struct ConvHaloGemm {
   constexpr int TAPS = KS * KS;
   constexpr int HALO_BYTES = (HH_ * HW_ * PSB + 1023) / 1024 * 1024;
   constexpr int BST_BYTES = NB * CST * 1024;    // one (chunk, tap) stage of the filter
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   unsigned char* Hs = smem;                     // [2][HALO_BYTES]
   unsigned char* Bs = smem + 2 * HALO_BYTES;    // [2][BST_BYTES]
 
@@ -109,9 +109,7 @@ struct ConvHaloGemm {
         const int nb = fi / CST, j = fi - nb * CST;
         const int nbg = min(nb0 + nb, nb_total - 1);
         const uint4* src = wfrag + ((long)nbg * ksteps + t * csteps + c * CST + j) * 64 + lane;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)src,
-            (__attribute__((address_space(3))) void*)(Bs + buf * BST_BYTES + fi * 1024), 16, 0, 0);
+        ssa_glds16(src, Bs + buf * BST_BYTES + fi * 1024);
       }
     }
   };
@@ -160,7 +158,7 @@ struct ConvHaloGemm {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = ssa_mfma32(af[mi], bfr[ni], acc[mi][ni]);
     }
     if (fetch_halo) halo_store((c + 1) & 1);
     __syncthreads();

@@ -51,7 +51,7 @@ __device__ __forceinline__ void mma_stage(const bf16_t* __restrict__ As,
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = ssa_mfma32(af[mi], bfr[ni], acc[mi][ni]);
   }
 }
 
@@ -84,7 +84,7 @@ struct ConvIgemm {
   constexpr int RPP = NT / PPR;
   constexpr int A_IT = (BM + RPP - 1) / RPP, B_IT = (BN + RPP - 1) / RPP;
   constexpr int STAGE = (BM + BN) * LDT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,7 +289,6 @@ struct ConvIgemm {
 // Row stride S of the LDS image satisfies S % 256 == 64 bytes, which spreads
 // the 32 lanes the LDS services together over 32 distinct 8-byte slots.
 // ----------------------------------------------------------------------------
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 __host__ __device__ constexpr int tr_row_stride(int cols) {  // in elements
@@ -305,10 +304,8 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int stride, int 
   const int col = row0 + 16 * ((lane >> 4) & 1) + 4 * q;
   const int pix = kbase + 8 * (lane >> 5) + j;
   const bf16_t* p0 = tile + pix * stride + col;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4_t __attribute__((address_space(3)))*)(p0));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4_t __attribute__((address_space(3)))*)(p0 + 4 * stride));
+  const s16x4_t lo = ssa_tr16_b64(p0);
+  const s16x4_t hi = ssa_tr16_b64(p0 + 4 * stride);
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -336,7 +333,7 @@ struct ConvWgradTr {
   constexpr int A_PIECES = BKP * PA, B_PIECES = BKP * PB;
   constexpr int A_IT = (A_PIECES + NT - 1) / NT, B_IT = (B_PIECES + NT - 1) / NT;
   constexpr int STAGE = BKP * (SA + SB);
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   bf16_t* lds = reinterpret_cast<bf16_t*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,7 +433,7 @@ struct ConvWgradTr {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = ssa_mfma32(af[mi], bfr[ni], acc[mi][ni]);
       }
       if (kt + 1 < nk) lstore(buf ^ 1);
       __syncthreads();
@@ -467,7 +464,7 @@ struct WgradReduceK {
   struct Args { const float* partial; float* dw; int nsplit, cout_pad, Cout, Cin_pad, Cin, KH, KW, accumulate; };
   static constexpr int NT = 256;
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
-    extern __shared__ float sh[];                 // [Cin * taps] in OIHW order
+    SSA_DYN_LDS(float, sh);                 // [Cin * taps] in OIHW order
     const float* __restrict__ partial = a.partial;
     const int nsplit = a.nsplit, Cin_pad = a.Cin_pad, Cin = a.Cin;
     const int co = bx;
@@ -577,7 +574,7 @@ __device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int* r, i
 // bf16-rounded row is then written from LDS.  Rows that do not fit (48 KiB) fall back to
 // the element-wise gather.
 __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob* __restrict__ jobs) {
-  extern __shared__ float rowbuf[];
+  SSA_DYN_LDS(float, rowbuf);
   const PackJob j = jobs[blockIdx.y];
   if (j.mode >= 4) {                                       // parity-class operands: element-wise
     for (int r = blockIdx.x; r < j.rows; r += gridDim.x)
@@ -639,7 +636,7 @@ __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob
 // packed once in full by ssa_pack_filter.
 __global__ __launch_bounds__(256) void pack_filters_tiled_kernel(const PackJob* __restrict__ jobs,
                                                                  const int4* __restrict__ tiles) {
-  extern __shared__ float tbuf[];
+  SSA_DYN_LDS(float, tbuf);
   const int4 t = tiles[blockIdx.x];
   const PackJob j = jobs[t.x];
   const int taps = j.KH * j.KW;

@@ -64,9 +64,7 @@ __device__ __forceinline__ void stage_filter_chunk(const uint4* __restrict__ wfr
       const int tl = rem / CST, j = rem - tl * CST;
       const int nbg = min(nb0 + nb, nb_total - 1);   // n-blocks past the end re-read the last one (never stored)
       const uint4* src = wfrag + ((long)nbg * ksteps_total + (tap0 + tl) * csteps_total + cc * CST + j) * 64 + lane;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)(dst + (size_t)fi * 1024), 16, 0, 0);
+      ssa_glds16(src, dst + (size_t)fi * 1024);
     }
   }
 }
@@ -109,7 +107,7 @@ struct ConvTile {
   constexpr int STAGE_BYTES = NB * STAGE_KS * 1024;
   constexpr int NBUF = NSTAGE > 1 ? 2 : 1;
   constexpr int HALO_BYTES = (HH_ * HW_ * PSB + 1023) / 1024 * 1024;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   unsigned char* Bs = smem + HALO_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,7 +213,7 @@ struct ConvTile {
           const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * STAGE_KS + ksl) * 1024);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            acc[mi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bfr, acc[mi][nb], 0, 0, 0);
+            acc[mi][nb] = ssa_mfma32(af[mi], bfr, acc[mi][nb]);
         }
       }
       if (st + 1 < NSTAGE) __syncthreads();     // next stage landed; this buffer is free for stage st+2

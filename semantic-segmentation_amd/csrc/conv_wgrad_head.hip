@@ -24,7 +24,6 @@
 
 namespace {
 
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 __host__ __device__ constexpr int trs(int row_bytes) {   // smallest 64*odd >= row_bytes
@@ -34,9 +33,8 @@ __host__ __device__ constexpr int trs(int row_bytes) {   // smallest 64*odd >= r
 }
 
 __device__ __forceinline__ bf16x8_t tr8(const unsigned char* p, int stride_bytes) {
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4_t __attribute__((address_space(3)))*)(p + 4 * stride_bytes));
+  const s16x4_t lo = ssa_tr16_b64(p);
+  const s16x4_t hi = ssa_tr16_b64(p + 4 * stride_bytes);
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -66,7 +64,7 @@ struct ConvWgradHead {
   constexpr int XP = CX / 8, DP = 16;                    // 16-byte pieces per pixel
   constexpr int XN = TH * XW * XP, DN = TH * TW * DP;
   constexpr int XI = (XN + 511) / 512, DI = (DN + 511) / 512;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   unsigned char* Xs = smem;
   unsigned char* Ds = smem + X_BYTES;
 
@@ -164,7 +162,7 @@ struct ConvWgradHead {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[j], acc[m][j], 0, 0, 0);
+          acc[m][j] = ssa_mfma32(af[m], bfr[j], acc[m][j]);
     }
   }
 

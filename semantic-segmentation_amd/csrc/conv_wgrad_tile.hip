@@ -33,7 +33,6 @@
 
 namespace {
 
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 __host__ __device__ constexpr int tr_stride_bytes(int row_bytes) {   // smallest 64*odd >= row_bytes
@@ -43,9 +42,8 @@ __host__ __device__ constexpr int tr_stride_bytes(int row_bytes) {   // smallest
 }
 
 __device__ __forceinline__ bf16x8_t tr_read8(const unsigned char* p, int stride_bytes) {
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4_t __attribute__((address_space(3)))*)(p + 4 * stride_bytes));
+  const s16x4_t lo = ssa_tr16_b64(p);
+  const s16x4_t hi = ssa_tr16_b64(p + 4 * stride_bytes);
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
@@ -70,7 +68,7 @@ struct ConvWgradTile {
   constexpr int HALO_BYTES = HH_ * HW_ * SX;
   constexpr int NBL = (NBW + 3) / 4;           // n-blocks per wave
   constexpr int XP = CX / 8, DP = MB * 4;      // 16-byte pieces per pixel
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SSA_DYN_LDS(unsigned char, smem);
   unsigned char* Xs = smem;
   unsigned char* Ds = smem + HALO_BYTES;
 
@@ -218,7 +216,7 @@ struct ConvWgradTile {
         if (wave + 4 * l < NBW) {               // wave-uniform: waves without a 4th n-block skip it
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
-            acc[mb][l] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mb], bfr[l], acc[mb][l], 0, 0, 0);
+            acc[mb][l] = ssa_mfma32(af[mb], bfr[l], acc[mb][l]);
         }
     }
   }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(NT) void pixel_loss_kernel(const float* __restrict_
                                                         int C, int ignore_index,
                                                         double* __restrict__ acc,
                                                         float* __restrict__ dlogits) {
-  extern __shared__ float tile[];  // [NT][C]
+  SSA_DYN_LDS(float, tile);  // [NT][C]
   double lsum = 0.0, lcnt = 0.0;
   for (long base = (long)blockIdx.x * NT; base < P; base += (long)gridDim.x * NT) {
     const long npx = min((long)NT, P - base);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NT) void rmi_pool_kernel(const float* __restrict__ 
                                                       const int64_t* __restrict__ labels, int H,
                                                       int W, int C, float* __restrict__ ppr,
                                                       float* __restrict__ pla, int Hp, int Wp) {
-  extern __shared__ float sm[];  // [4][CELLS*4][C] probs, then [4][CELLS*4] labels (as float)
+  SSA_DYN_LDS(float, sm);  // [4][CELLS*4][C] probs, then [4][CELLS*4] labels (as float)
   float* pr = sm;
   float* lb = sm + 4 * CELLS * 4 * C;
   const int b = blockIdx.z, py = blockIdx.y, px0 = blockIdx.x * CELLS;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void tri_index(int e, int* i, int* j) {
 __global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ ppr,
                                                       const float* __restrict__ pla, int Hp, int Wp,
                                                       double* __restrict__ gram) {
-  extern __shared__ float sm[];  // la tile [GROWS+2][Wp], pr tile [GROWS+2][Wp]
+  SSA_DYN_LDS(float, sm);  // la tile [GROWS+2][Wp], pr tile [GROWS+2][Wp]
   const int bc = blockIdx.y;
   const int Hn = Hp - 2, Wn = Wp - 2;
   const int yb = blockIdx.x * GROWS;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict_
                                                         const long* __restrict__ labels, long P, int C,
                                                         unsigned char* __restrict__ pred_out,
                                                         unsigned long long* __restrict__ hist) {
-  extern __shared__ unsigned int lh[];          // [C*C]
+  SSA_DYN_LDS(unsigned int, lh);          // [C*C]
   for (int i = threadIdx.x; i < C * C; i += 256) lh[i] = 0u;
   __syncthreads();
   for (long p = blockIdx.x * 256L + threadIdx.x; p < P; p += (long)gridDim.x * 256) {

@@ -16,7 +16,7 @@ __global__ void probe_mfma32_kernel(const bf16_t* __restrict__ a, const bf16_t* 
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+  acc = ssa_mfma32(af, bf, acc);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -24,7 +24,6 @@ __global__ void probe_mfma32_kernel(const bf16_t* __restrict__ a, const bf16_t* 
   }
 }
 
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
 // LDS holds lds[i] = i (u16).  mode 0: lane supplies address of element 4*lane
 // (contiguous 8-byte pieces).  mode 1: lane l supplies element
 // 64*(l>>4) + 16*((l&15)>>2) + 4*(l&3)   (row (l&15)>>2, piece l&3 of a [4][16] block)
@@ -38,8 +37,7 @@ __global__ void probe_tr16_kernel(unsigned short* __restrict__ out, int mode) {
   if (mode == 0) e = 4 * l;
   else if (mode == 1) e = 64 * (l >> 4) + 16 * ((l & 15) >> 2) + 4 * (l & 3);
   else e = 64 * (l >> 4) + 16 * (l & 3) + 4 * ((l & 15) >> 2);
-  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4_t __attribute__((address_space(3)))*)(lds + e));
+  s16x4_t v = ssa_tr16_b64(lds + e);
   for (int j = 0; j < 4; ++j) out[l * 4 + j] = (unsigned short)v[j];
 }
 

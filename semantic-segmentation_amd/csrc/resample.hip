@@ -275,7 +275,7 @@ template <typename InT, typename OutT>
 __device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, int B, int Hi, int Wi, int C, int ldx,
                                                      OutT* __restrict__ y, int Ho, int Wo, float sh, float sw,
                                                      const int bx, const int gx) {
-  extern __shared__ float tile[];               // [256][C]
+  SSA_DYN_LDS(float, tile);               // [256][C]
   const int npix = B * Ho * Wo;
   const int tid = threadIdx.x;
   for (int p0 = bx * 256; p0 < npix; p0 += gx * 256) {
