@@ -399,6 +399,65 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   }
 }
 
+// Coefficient tables for the BatchNorm passes that are folded into a convolution's operand staging
+// (csrc/conv_tile_p.hip, conv_wgrad_tile.hip) -- the prologue of bn_apply_train_body / bn_bwd_apply_body as
+// kernels of their own, one workgroup of 256 channels each.
+//   forward: batch sums -> coef[4][C] = scale, shift, mean, invstd (+ pass_stats for the deferred running-statistics
+//            update, exactly what block 0 of bn_apply_train_body publishes)
+//   backward: (sum m*dz, sum m*dz*xhat) -> xf[5][C] = A, B0, C0, ma, mb with
+//            dy = A*(m ? dz : 0) + B0 + C0*x  ==  gamma*invstd * (m*dz - s1/N - xhat * s2/N),  m = [ma*x + mb > 0]
+//            and the parameter gradients dbeta += s1, dgamma += s2 (scaled for data-parallel averaging)
+__device__ __forceinline__ void bn_coef_train_body(const double* __restrict__ sums, int nrep, double count, int C,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float eps, float* __restrict__ coef, float* __restrict__ pass_stats,
+                                                   const int bx) {
+  const int c = bx * NT + threadIdx.x;
+  if (c == 0 && pass_stats) pass_stats[2 * C] = (float)count;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  replica_sums(sums, nrep, C, c, &s1, &s2);
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double b = beta ? (double)beta[c] : 0.0;
+  coef[c] = (float)(g * invstd);
+  coef[C + c] = (float)(b - mean * g * invstd);
+  coef[2 * C + c] = (float)mean;
+  coef[3 * C + c] = (float)invstd;
+  if (pass_stats) {
+    pass_stats[c] = (float)mean;
+    pass_stats[C + c] = (float)var;
+  }
+}
+
+__device__ __forceinline__ void bn_bwd_coef_body(const double* __restrict__ sums, int nrep, double count, int C,
+                                                 const float* __restrict__ gamma, const float* __restrict__ coef,
+                                                 float* __restrict__ xf, float* __restrict__ dgamma,
+                                                 float* __restrict__ dbeta, float param_grad_scale, int accumulate_pg,
+                                                 const int bx) {
+  const int c = bx * NT + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  replica_sums(sums, nrep, C, c, &s1, &s2);
+  const float mu = coef[2 * C + c], is_ = coef[3 * C + c];
+  const float a = (gamma ? gamma[c] : 1.f) * is_;
+  const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
+  xf[c] = a;
+  xf[C + c] = a * (c2 * is_ * mu - c1);
+  xf[2 * C + c] = -a * c2 * is_;
+  xf[3 * C + c] = coef[c];
+  xf[4 * C + c] = coef[C + c];
+  if (accumulate_pg) {
+    if (dbeta) unsafeAtomicAdd(&dbeta[c], (float)(s1 * param_grad_scale));
+    if (dgamma) unsafeAtomicAdd(&dgamma[c], (float)(s2 * param_grad_scale));
+  } else {
+    if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
+    if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
+  }
+}
+
 __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -490,6 +549,24 @@ struct BnBwdApplyK {
     bn_bwd_apply_body(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
                       a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
                       a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, bx);
+  }
+};
+
+struct BnCoefTrainK {
+  struct Args { const double* sums; const float* gamma; const float* beta; float* coef; float* pass_stats;
+                double count; int C, nrep; float eps; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_coef_train_body(a.sums, a.nrep, a.count, a.C, a.gamma, a.beta, a.eps, a.coef, a.pass_stats, bx);
+  }
+};
+struct BnBwdCoefK {
+  struct Args { const double* sums; const float* gamma; const float* coef; float* xf; float* dgamma; float* dbeta;
+                double count; int C, nrep; float param_grad_scale; int accumulate_pg; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
+    bn_bwd_coef_body(a.sums, a.nrep, a.count, a.C, a.gamma, a.coef, a.xf, a.dgamma, a.dbeta, a.param_grad_scale,
+                     a.accumulate_pg, bx);
   }
 };
 
@@ -613,6 +690,21 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
                         running_var, num_batches_tracked, coef, pass_stats, post, count, P, pix_per_img, g.ppb,
                         ldx, ldr, ldz, C, nrep, relu, momentum, eps};
   return ssa::submit<BnApplyTrainK>(a, g.blocks, 1, 2 * C * sizeof(float), (hipStream_t)stream);
+}
+
+int ssa_bn_coef_train(const double* sums, int nrep, double count, int C, const float* gamma, const float* beta,
+                      float eps, float* coef, float* pass_stats, void* stream) {
+  if (!sums || !coef || C <= 0 || nrep < 1 || count <= 0) return SSA_EINVAL;
+  BnCoefTrainK::Args a{sums, gamma, beta, coef, pass_stats, count, C, nrep, eps};
+  return ssa::submit<BnCoefTrainK>(a, (C + NT - 1) / NT, 1, 0, (hipStream_t)stream);
+}
+
+int ssa_bn_bwd_coef(const double* sums, int nrep, double count, int C, const float* gamma, const float* coef,
+                    float* xf, float* dgamma, float* dbeta, float param_grad_scale, int accumulate_param_grads,
+                    void* stream) {
+  if (!sums || !coef || !xf || C <= 0 || nrep < 1 || count <= 0) return SSA_EINVAL;
+  BnBwdCoefK::Args a{sums, gamma, coef, xf, dgamma, dbeta, count, C, nrep, param_grad_scale, accumulate_param_grads};
+  return ssa::submit<BnBwdCoefK>(a, (C + NT - 1) / NT, 1, 0, (hipStream_t)stream);
 }
 
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {

@@ -20,6 +20,7 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return emu::mfma_32x32x16_bf16(a, b, c); }
 __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return emu::ds_read_tr16_b64(lds_ptr); }
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
+__device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
 #else
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
@@ -35,6 +36,10 @@ __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// LDS written by some lanes of a wave, read by others of the SAME wave: the hardware runs a wave's LDS operations
+// in order, so only the compiler must not move the reads above the writes (the emulation runs lanes as
+// independent fibers and needs a real rendezvous here)
+__device__ __forceinline__ void ssa_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 #endif
 
 #define SSA_OK 0
@@ -53,12 +58,16 @@ namespace ssa { void count_launches(int n); }   // group.hip: library-wide launc
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
-// round-to-nearest-even, NaN kept quiet
+// round-to-nearest-even, NaN kept quiet: v_cvt_pk_bf16_f32 on gfx950 (one instruction; the shift-and-add
+// sequence it replaces was five VALU operations per element in every epilogue and staging transform)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f2bf_pair(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
@@ -68,10 +77,10 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 v;
-  v.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  v.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-  v.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-  v.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  v.x = f2bf_pair(f[0], f[1]);
+  v.y = f2bf_pair(f[2], f[3]);
+  v.z = f2bf_pair(f[4], f[5]);
+  v.w = f2bf_pair(f[6], f[7]);
   return v;
 }
 

@@ -34,3 +34,31 @@ def out_dir():
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
     return d
+
+
+# ---- SSA_EMU=1: run the `-m gpu` kernel tests against the CPU emulation build of the kernel sources
+# (tests/emu_util.py, tools/emu) with CPU tensors as device memory -- a development aid for machines without
+# a GPU (small shapes only: a workgroup is 256 fibers).  Never set by the driver; the product is untouched.
+_EMU = bool(os.environ.get("SSA_EMU"))
+
+
+@pytest.fixture(autouse=True)
+def _emu_mode(request):
+    if not _EMU:
+        yield
+        return
+    import torch
+    from emu_util import emu_backend
+    mod = request.module
+    saved_dev = getattr(mod, "DEV", None)
+    if saved_dev is not None:
+        mod.DEV = "cpu"
+    saved_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        with emu_backend():
+            yield
+    finally:
+        torch.cuda.synchronize = saved_sync
+        if saved_dev is not None:
+            mod.DEV = saved_dev

@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests."""
+import os
+
 import torch
 
 
@@ -37,6 +39,10 @@ def check_close_robust(name, got, ref, rel_max=1e-2, rel_mean=4e-3, outliers=1e-
     such an element's gradient differs by its full magnitude.  At most `outliers` of the elements may
     exceed the max-error bound (a wrong tile edge or channel block is orders of magnitude more)."""
     assert torch.isfinite(got.detach().float()).all(), name + ": non-finite output"
+    if os.environ.get("SSA_EMU"):
+        # the emulation sums an MFMA's 16 products in index order, the hardware does not: a different handful of
+        # pre-activations lands on the other side of zero (2 elements of a 9,216-element problem are 2e-4)
+        outliers = max(outliers, 5e-4)
     mx, scale, mean_err, mean_ref = report(name, got, ref)
     err = (got.detach().float().cpu() - ref.detach().float().cpu()).abs()
     frac = float((err > rel_max * scale).float().mean())
