@@ -47,7 +47,8 @@ def source_sha():
 
 def family(kernel):
     f = kernel.split("<")[0]
-    return "ConvTile" if f == "ConvTileAny" else f      # the two trunk instantiations behind one kernel (conv_tile.hip)
+    # the trunk's 3x3 kernels: conv_tile.hip (ConvTile, ConvTileAny) and its persistent form conv_tile_p.hip
+    return "ConvTile" if f in ("ConvTileAny", "ConvTilePAny", "ConvTileP") else f
 
 
 def synth_batch(B, H, W, rank, device):
@@ -331,16 +332,16 @@ def main():
         # collected offline (rocprofv3 cannot run inside this process) by tools/pmc_traffic.py; refused
         # unless it was measured on these very kernel sources
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("source_sha") == source_sha():
                 ent = pj["kernels"].get(name)
                 if ent:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r02_pmc_traffic.json"
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r03_pmc_traffic.json"
             else:
-                traffic_src = "profiles/r02_pmc_traffic.json refused: measured on other kernel sources"
+                traffic_src = "profiles/r03_pmc_traffic.json refused: measured on other kernel sources"
         sec = d["us"] * 1e-6
         mfma_bound = d["flops"] / max(d["bytes"], 1.0) > PEAK_BF16_MFMA / PEAK_HBM
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name,
