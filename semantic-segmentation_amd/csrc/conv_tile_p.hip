@@ -39,6 +39,14 @@ namespace {
 
 constexpr int kStatReplicas = 8;   // as conv_tile.hip (ssa_bn_stat_replicas)
 
+// -DSSA_TILE_TIMING (tools/tilebench.py --timing; never in the product build): wave 0 of workgroup 0 writes
+// s_memtime stamps of every phase of its first iterations to the `coef` pointer (reinterpreted, XF 0 / aux 0 only)
+#ifdef SSA_TILE_TIMING
+#define SSA_STAMP(k) do { if (tdbg && it < 24) { tdbg[it * 8 + (k)] = (long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SSA_STAMP(k) do { } while (0)
+#endif
+
 struct TilePArgs {
   const bf16_t* x; const bf16_t* x2; const float* xf;     // staged input; XF 2: the layer input x; transform table
   const uint4* wfrag; const float* bias; bf16_t* y; double* stats;
@@ -134,32 +142,48 @@ struct ConvTileP {
     uint4 v2[XF == 2 ? IT : 1];
     unsigned okmask = 0;                       // bit i: piece i lies inside the image
 
-    auto tile_origin = [&](int t, int* b, int* x0, int* y0) {
-      const int tx_i = t % tiles_x;
-      const int r = t / tiles_x;
-      const int ty_i = r % tiles_y;
-      *b = r / tiles_y;
-      *x0 = tx_i * TW;
-      *y0 = ty_i * TH;
-    };
-    // global -> registers: the halo of (tile t, channel chunk cc)
-    auto fetch = [&](int t, int cc) {
-      int b, x0, y0;
-      tile_origin(t, &b, &x0, &y0);
-      const bf16_t* xb = x + (long)b * H * W * ldx + cc * CK + cg * 8;
-      const bf16_t* xb2 = XF == 2 ? x2 + (long)b * H * W * ldx2 + cc * CK + cg * 8 : nullptr;
+    // tile-invariant part of this thread's pieces: halo coordinates (hy << 8 | hx, 0xffff: no such piece) and the
+    // element offset relative to the tile's first halo pixel; invalid lanes load the tile's own first pixel instead
+    // (always inside the image) and are zeroed at staging time -- ten unconditional loads issue back to back
+    int hyx[IT], rel[IT], rel2[XF == 2 ? IT : 1];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int pix = prow + i * RP;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      const bool have = stg && pix < NPIX;
+      hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
+      rel[i] = (hy * W + hx) * ldx;
+      if constexpr (XF == 2) rel2[i] = (hy * W + hx) * ldx2;
+    }
+    const int rel_c = (W + 1) * ldx, rel2_c = (W + 1) * ldx2;     // halo pixel (1, 1) = output pixel (0, 0) of the tile
+    // tile walk without divisions: (image, tile row, tile column) of the tile whose halo is fetched next
+    int f_b, f_ty, f_tx;
+    {
+      f_tx = t_begin % tiles_x;
+      const int r = t_begin / tiles_x;
+      f_ty = r % tiles_y;
+      f_b = r / tiles_y;
+    }
+    int c_b = f_b, c_ty = f_ty, c_tx = f_tx;                       // ... and of the tile being computed
+    // global -> registers: the halo of (the fetch tile, channel chunk cc)
+    auto fetch = [&](int cc) {
+      const int x0 = f_tx * TW, y0 = f_ty * TH;
+      const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + cc * CK + cg * 8;
+      const bf16_t* xb2 = XF == 2 ? x2 + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx2 + cc * CK + cg * 8 : nullptr;
       okmask = 0;
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
-        const int pix = prow + i * RP;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = stg && pix < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const int po = iy * W + ix;
-        v[i] = ok ? *reinterpret_cast<const uint4*>(xb + (long)po * ldx) : make_uint4(0, 0, 0, 0);
-        if constexpr (XF == 2)
-          v2[i] = ok ? *reinterpret_cast<const uint4*>(xb2 + (long)po * ldx2) : make_uint4(0, 0, 0, 0);
+        const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
+        const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
+        if constexpr (XF == 2) v2[i] = *reinterpret_cast<const uint4*>(xb2 + (ok ? rel2[i] : rel2_c));
         okmask |= (ok ? 1u : 0u) << i;
+      }
+    };
+    auto advance = [&](int* b, int* ty, int* tx) {
+      if (++*tx == tiles_x) {
+        *tx = 0;
+        if (++*ty == tiles_y) { *ty = 0; ++*b; }
       }
     };
     // registers -> (transform) -> LDS halo image of channel chunk cc
@@ -179,8 +203,14 @@ struct ConvTileP {
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
             v[i] = pack8(f);
+          } else {
+            v[i] = make_uint4(0, 0, 0, 0);
           }
         }
+      } else if constexpr (XF == 0) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+          if (!((okmask >> i) & 1u)) v[i] = make_uint4(0, 0, 0, 0);
       } else if constexpr (XF == 2) {
         // two passes of four channels: 20 coefficient registers live at a time instead of 40
 #pragma unroll
@@ -212,11 +242,14 @@ struct ConvTileP {
             }
           }
         }
+#pragma unroll
+        for (int i = 0; i < IT; ++i)
+          if (!((okmask >> i) & 1u)) v[i] = make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int pix = prow + i * RP;
-        if (stg && pix < NPIX) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = v[i];
+        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = v[i];
       }
     };
 
@@ -243,21 +276,26 @@ struct ConvTileP {
     f32x16_t acc[NB];
 
     if (n_iter <= 0) return;
+#ifdef SSA_TILE_TIMING
+    long* tdbg = (AUXM == 0 && XF == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
+#endif
     // ---- prologue: first halo into registers, the filter (slice / first stage) on its way into LDS
-    fetch(t_begin, 0);
+    fetch(0);
     stage_filter<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, 0, 0, Bs, wave, lane);
     int s = 0;                                         // global filter-stage counter (streamed variant)
-    int t = t_begin, cc = 0;
+    int cc = 0;
     for (int it = 0; it < n_iter; ++it) {
       // everyone is past the barrier that ended the previous iteration: the halo image is free
+      SSA_STAMP(0);
       stage(cc);
+      SSA_STAMP(1);
       __syncthreads();                                 // halo image + filter stage s (slice) landed
+      SSA_STAMP(2);
       const bool last_chunk = cc + 1 == nchunk;
-      int tn = t, ccn = cc + 1;
-      if (last_chunk) { tn = t + 1; ccn = 0; }
-      if (it + 1 < n_iter) fetch(tn, ccn);             // next halo: in flight during this iteration's MFMAs
-      int b_, x0, y0;
-      tile_origin(t, &b_, &x0, &y0);
+      int ccn = cc + 1;
+      if (last_chunk) { ccn = 0; advance(&f_b, &f_ty, &f_tx); }
+      if (it + 1 < n_iter) fetch(ccn);                 // next halo: in flight during this iteration's MFMAs
+      const int b_ = c_b, x0 = c_tx * TW, y0 = c_ty * TH;
       if constexpr (AUX) {
         if (last_chunk) {
           const bf16_t* ab = aux + (long)b_ * H * W * ldaux;
@@ -278,6 +316,7 @@ struct ConvTileP {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
       }
+      SSA_STAMP(3);
 #pragma unroll
       for (int st = 0; st < NSTAGE; ++st) {
         if constexpr (!RESIDENT) {
@@ -291,20 +330,35 @@ struct ConvTileP {
           }
         }
         const unsigned char* Bc = Bs + (RESIDENT ? 0 : (s & 1) * STAGE_BYTES) + lane * 16;
-#pragma unroll
-        for (int ksl = 0; ksl < STAGE_KS; ++ksl) {
+        // fragments of k-step ksl + RD - 1 are read while the MFMAs of k-step ksl run: a ring of RD register sets
+        // (left to itself the compiler reads two k-steps, waits, multiplies, and only then reads the next two)
+        constexpr int RD = 4;
+        bf16x8_t ra[RD], rb[RD][NB];
+        auto rd_frag = [&](int ksl) {
           const int tap = st * TPC + ksl / CST, cs = ksl % CST;
           const int kh = tap / 3, kw = tap - kh * 3;
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(smem + a_off + (kh * HW_ + kw) * PSB + cs * 32);
+          ra[ksl % RD] = *reinterpret_cast<const bf16x8_t*>(smem + a_off + (kh * HW_ + kw) * PSB + cs * 32);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const bf16x8_t bfr = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * STAGE_KS + ksl) * 1024);
-            acc[nb] = ssa_mfma32(af, bfr, acc[nb]);
-          }
+          for (int nb = 0; nb < NB; ++nb)
+            rb[ksl % RD][nb] = *reinterpret_cast<const bf16x8_t*>(Bc + (nb * STAGE_KS + ksl) * 1024);
+        };
+#pragma unroll
+        for (int p = 0; p < RD - 1 && p < STAGE_KS; ++p) rd_frag(p);
+        __builtin_amdgcn_sched_group_barrier(0x100, (RD - 1) * (1 + NB), 0);
+#pragma unroll
+        for (int ksl = 0; ksl < STAGE_KS; ++ksl) {
+          if (ksl + RD - 1 < STAGE_KS) rd_frag(ksl + RD - 1);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = ssa_mfma32(ra[ksl % RD], rb[ksl % RD][nb], acc[nb]);
+          if (ksl + RD - 1 < STAGE_KS) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NB, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
         }
+        if (st == 0) SSA_STAMP(4);
         __syncthreads();        // stage s+1 landed; buffer s & 1 (and, after the last stage, the halo image) is free
+        if (st == 0) SSA_STAMP(5);
         if constexpr (!RESIDENT) ++s;
       }
+      SSA_STAMP(6);
       if (last_chunk) {
         // ---- wave-local epilogue: (+bias) -> bf16 -> this wave's LDS slice -> whole pixel rows
         // slice: inside the halo image (resident filter) / inside the filter buffer just consumed (streamed)
@@ -361,7 +415,8 @@ struct ConvTileP {
         }
         if constexpr (RESIDENT) __syncthreads();       // the slices live in the halo image the next tile overwrites
       }
-      t = tn;
+      SSA_STAMP(7);
+      if (last_chunk) advance(&c_b, &c_ty, &c_tx);
       cc = ccn;
     }
 

@@ -9,9 +9,11 @@ import torch.distributed as dist
 from torch.utils.data import Sampler
 
 
-def shard_indices(n, epoch, rank, world, pad=False, consecutive_sample=False, permutation=False):
-    """Indices of `rank`'s share of a dataset of `n` samples in `epoch`."""
-    per_rank = int(math.ceil(n / world)) if pad else n // world
+def shard_indices(n, epoch, rank, world, pad=False, consecutive_sample=False, permutation=False, per_rank=None):
+    """Indices of `rank`'s share of a dataset of `n` samples in `epoch`.  per_rank: the share length if the
+    caller fixed it (DistributedSampler.set_num_samples), otherwise ceil (pad) / floor of n / world."""
+    if per_rank is None:
+        per_rank = int(math.ceil(n / world)) if pad else n // world
     total = per_rank * world
     if permutation:
         g = torch.Generator()
@@ -44,8 +46,10 @@ class DistributedSampler(Sampler):
         self.total_size = self.num_samples * self.num_replicas
 
     def __iter__(self):
+        # the share length is self.num_samples, as in the reference's __iter__ (datasets/sampler.py:78-100): after
+        # set_num_samples() that is the ceiling also for a sampler built with pad=False
         return iter(shard_indices(len(self.dataset), self.epoch, self.rank, self.num_replicas, self.pad,
-                                  self.consecutive_sample, self.permutation))
+                                  self.consecutive_sample, self.permutation, per_rank=self.num_samples))
 
     def __len__(self):
         return self.num_samples

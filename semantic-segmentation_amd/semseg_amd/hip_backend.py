@@ -331,10 +331,10 @@ def end_forward():
 def begin_step(device=None):
     _BN_UPDATES.step = {}
     _PENDING_STATS.clear()
-    if _GRADS.armed or _WGRAD_Q:
-        # a backward pass that raised never ran its end-of-backward callback: its queued weight-gradient jobs
-        # and its half-filled gradient slices are abandoned here -- otherwise the arena would stay "armed" and
-        # no later backward pass would ever publish a gradient again
+    if _GRADS.armed or _WGRAD_Q or _GRADS.slots or _GRADS.chunks:
+        # a backward pass that raised never ran its end-of-backward callback (or raised inside it): its queued
+        # weight-gradient jobs and its half-filled gradient slices are abandoned here -- otherwise the arena would
+        # stay "armed" (or keep stale slots) and no later backward pass would ever publish a gradient again
         del _WGRAD_Q[:]
         _GRADS.abandon()
     refresh_packed_filters()
@@ -369,9 +369,16 @@ class _GradArena:
         self.total_last = 0
         self.armed = False
 
+    def _arm(self):
+        if not self.armed:
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self.publish)
+            self.armed = True
+
     def slot(self, p):
         e = self.slots.get(id(p))
         if e is not None and e[0] is p:
+            self._arm()
             return e[1]
         n = _roundup(p.numel(), 64)
         if not self.chunks or self.chunks[-1][1] + n > self.chunks[-1][0].numel() or \
@@ -384,10 +391,7 @@ class _GradArena:
         v = c[0][c[1]:c[1] + p.numel()].view(p.shape)
         c[1] += n
         self.slots[id(p)] = (p, v)
-        if not self.armed:
-            from torch.autograd import Variable
-            Variable._execution_engine.queue_callback(self.publish)
-            self.armed = True
+        self._arm()
         return v
 
     def abandon(self):
@@ -397,23 +401,28 @@ class _GradArena:
 
     def publish(self):
         self.armed = False
-        flush_wgrads()
-        if not self.slots:
-            return
-        if _GRAD_SINK[0] is not None:
-            _GRAD_SINK[0]([(c[0], c[1]) for c in self.chunks])
-        dst, src = [], []
-        for p, v in self.slots.values():
-            if p.grad is None:
-                p.grad = v
-            else:
-                dst.append(p.grad)
-                src.append(v)
-        if dst:
-            torch._foreach_add_(dst, src)
-        self.total_last = sum(c[1] for c in self.chunks)
-        self.chunks = []
-        self.slots = {}
+        try:
+            flush_wgrads()
+            if not self.slots:
+                return
+            if _GRAD_SINK[0] is not None:
+                _GRAD_SINK[0]([(c[0], c[1]) for c in self.chunks])
+            dst, src = [], []
+            for p, v in self.slots.values():
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    dst.append(p.grad)
+                    src.append(v)
+            if dst:
+                torch._foreach_add_(dst, src)
+            self.total_last = sum(c[1] for c in self.chunks)
+        finally:
+            # also when the flush / the all-reduce raised: stale slots would make the next backward return early
+            # from slot() and never publish again
+            del _WGRAD_Q[:]
+            self.chunks = []
+            self.slots = {}
 
 
 _GRADS = _GradArena()
@@ -492,8 +501,13 @@ def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
 
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs
 _TILE_P = os.environ.get("SSA_TILE_P", "1") != "0"
-_TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "512"))      # workgroups a grouped level aims at (~2 per CU)
-_BLOCK_FOLD = os.environ.get("SSA_BLOCK_FOLD", "1") != "0"     # bn1 folded into conv2 / conv1's gradients (BasicBlockGroupFn)
+_TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "500"))      # most workgroups a grouped level may launch (< 2 per CU)
+# bn1 folded into conv2's operand staging / conv1's gradients (BasicBlockGroupFn).  Measured on MI355X (profiles/
+# r03_notes.md, calls A and E): 32 BnApplyTrain + 32 BnBwdApply launches less (-1.1 ms), but the staging transforms sit on
+# the critical path of latency-bound kernels (+5 us per conv2 launch, +15 us per conv1 data gradient, +0.6 ms in the
+# weight-gradient kernels) and the two coefficient launches per level cost 0.4 ms: 26.6 ms per step against 25.8 ms
+# with the BatchNorm passes materialised.  Kept, tested, off.
+_BLOCK_FOLD = os.environ.get("SSA_BLOCK_FOLD", "0") != "0"
 
 
 def tile_p_supported(d):
@@ -509,17 +523,34 @@ def _tile_p_units(d):
     return tiles * nb * (d.Cin // 96)
 
 
+def _tile_p_wgs(d, units):
+    """Workgroups ssa_conv2d_tile_p launches for this problem at `units` per workgroup (mirror of launch_p)."""
+    tiles = d.B * ((d.W + 31) // 32) * ((d.H + 3) // 4)
+    nb = (d.Cout + 31) // 32
+    groups, nchunk = ((nb + 1) // 2, 1) if d.Cin == 48 else (nb, d.Cin // 96)
+    tpw = max(1, units // nchunk)
+    nstrips = -(-tiles // tpw)
+    tpw = -(-tiles // nstrips)
+    return -(-tiles // tpw) * groups
+
+
 @contextlib.contextmanager
 def tile_strip(descs):
     """Strip length of the persistent conv kernel for a level whose 3x3 problems are `descs` (those the kernel does
-    not take count for nothing): total work / target workgroup count, handed to the library for the launches
-    issued inside the bracket (same thread)."""
-    units = sum(_tile_p_units(d) for d in descs if tile_p_supported(d))
-    if units <= 0:
+    not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (two per CU) --
+    a grouped launch of 520 workgroups runs as two rounds of 512 + 8 and takes 37 us where 492 take 29
+    (profiles/r03_notes.md, call D).  Handed to the library for the launches issued inside the bracket (same thread)."""
+    ds = [d for d in descs if tile_p_supported(d)]
+    if not ds:
         yield
         return
+    units = 16
+    for u in range(1, 17):
+        if sum(_tile_p_wgs(d, u) for d in ds) <= _TILE_P_WGS:
+            units = u
+            break
     L = lib()
-    L.ssa_conv_tile_strip(max(1, min(16, int(round(units / float(_TILE_P_WGS))))))
+    L.ssa_conv_tile_strip(units)
     try:
         yield
     finally:
@@ -1170,7 +1201,7 @@ class BasicBlockGroupFn(torch.autograd.Function):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), training mode, 3x3 stride-1 convs without
     bias, for N independent problems (branches x scale passes); network/hrnetv2.py:37-66.
 
-    Folded form (default, SSA_BLOCK_FOLD=1; every problem of the level must qualify, `_block_fold_ok`):
+    Folded form (SSA_BLOCK_FOLD=1; every problem of the level must qualify, `_block_fold_ok`):
     forward  conv1 (+ bn1 statistics) -> bn1 coefficients -> conv2 whose operand staging applies bn1 + ReLU
              (+ bn2 statistics) -> bn2 + residual + ReLU: 3 grouped passes over HBM and one coefficient launch;
              bn1's output is never written.
@@ -1387,10 +1418,11 @@ class SumActGroupFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, relu, counts, *ts):
         zs, off = [], 0
+        dense = [t.contiguous() for t in ts]      # before the bracket: a temporary must outlive the deferred launch
         with group():
             for c in counts:
                 assert 1 <= c <= 4
-                cs = [t.contiguous() for t in ts[off:off + c]]
+                cs = dense[off:off + c]
                 off += c
                 z = torch.empty_like(cs[0])
                 args = [_p(t) for t in cs] + [None] * (4 - c)

@@ -5,6 +5,8 @@ import json
 import os
 import random
 
+import torch
+
 import numpy as np
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_golden.json")
@@ -53,6 +55,18 @@ def test_product_sampler_matches_reference_and_oracle():
     # every sample appears exactly once per epoch when the split is padded and strided
     seen = sorted(i for r in range(8) for i in shard_indices(64, 4, r, 8, True, False, True))
     assert seen == list(range(64))
+    # set_num_samples() on a sampler built with pad=False (n % world != 0): the reference's __iter__ then yields the
+    # CEILING with wrap-around padding (datasets/sampler.py:78-110); restated here from its text
+    for rank in range(4):
+        s = DistributedSampler(list(range(10)), pad=False, permutation=True, num_replicas=4, rank=rank)
+        s.set_epoch(7)
+        assert len(list(s)) == 2
+        s.set_num_samples()
+        g = torch.Generator()
+        g.manual_seed(7)
+        order = torch.randperm(10, generator=g).tolist()
+        order += order[:12 - 10]
+        assert len(s) == 3 and list(s) == order[rank:12:4]
 
 
 def test_oracle_nearest_matches_pillow():

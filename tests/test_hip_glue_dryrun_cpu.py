@@ -211,13 +211,14 @@ def test_lockstep_grouping_and_gradient_arena_glue(dry):
     assert not hip_backend._WGRAD_Q
 
 
-def test_folded_basic_block_glue(dry):
+def test_folded_basic_block_glue(dry, monkeypatch):
     """Large enough an input that whole trunk levels qualify for the folded residual block (every problem of the
     level at least 16 pixels wide): bn1 then runs as a coefficient launch + conv2's staging transform (xf 1) in the
     forward pass, as a coefficient launch + conv1's data-gradient staging transform (xf 2, with the identity
     gradient in its epilogue) in the backward pass, and both weight gradients take a folded operand."""
     from semseg_amd import hip_backend
-    assert hip_backend._BLOCK_FOLD and hip_backend._TILE_P
+    monkeypatch.setattr(hip_backend, "_BLOCK_FOLD", True)
+    assert hip_backend._TILE_P
     net = _build("ocrnet.HRNet_Mscale", "rmi").train()
     net(_batch(1, 256, 512)).backward()
     c = dry.calls

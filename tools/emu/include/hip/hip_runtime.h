@@ -164,6 +164,7 @@ template <class T> static inline T __shfl(T v, int src, int /*width*/ = 64) {
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 namespace emu {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
