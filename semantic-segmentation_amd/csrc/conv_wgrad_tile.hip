@@ -30,6 +30,7 @@
 #include "group.h"
 #include "../../include/semseg_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -138,6 +139,7 @@ struct ConvWgradTile {
   constexpr int XNA = (256 / XP) * XP, XRP = XNA / XP, XQ = XF == 1 ? (HH_ * HW_ + XRP - 1) / XRP : 1;
   constexpr int DNA = (256 / DP) * DP, DRP = DNA / DP, DQ = XF == 2 ? (TH * TW + DRP - 1) / DRP : 1;
   uint4 xq[XQ], dq[DQ], dq2[DQ];
+  unsigned xmask = 0, dmask = 0;               // untransformed operands: bit i = piece i lies inside the image
   unsigned qok = 0;                            // bit i: piece i of the transformed operand lies inside the image
   const int xcg = tid % XP, xpr = tid / XP, dcg = tid % DP, dpr = tid / DP;
   float* Tb = reinterpret_cast<float*>(smem + HALO_BYTES + TH * TW * SD);   // [2][CX] (XF 1) / [5][MB*32] (XF 2)
@@ -201,17 +203,22 @@ struct ConvWgradTile {
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = tid < XNA && pix < HH_ * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xq[i] = ok ? *reinterpret_cast<const uint4*>(xb + (long)(hy * W + hx) * ldx + xcg * 8) : make_uint4(0, 0, 0, 0);
+        xq[i] = *reinterpret_cast<const uint4*>(xb + (ok ? (hy * W + hx) * ldx + xcg * 8 : (W + 1) * ldx));
         qok |= (ok ? 1u : 0u) << i;
       }
     } else {
+      // every lane loads (pieces outside the image read the tile's first output pixel and are zeroed when they
+      // are staged): a select on the loaded value made the compiler wait for each batch of loads inside this
+      // function -- the "prefetch" of the next tile then stalled for a full memory latency, twice per tile
+      xmask = 0;
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
         int rc, go, lo;
         if constexpr (PRE) { rc = x_rc_[i]; go = x_go_[i]; lo = x_lo_[i]; } else { x_piece(i, &rc, &go, &lo); }
         const int iy = y0 - 1 + (rc >> 8), ix = x0 - 1 + (rc & 255);
         const bool ok = lo >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xv[i] = ok ? *reinterpret_cast<const uint4*>(xb + go) : make_uint4(0, 0, 0, 0);
+        xv[i] = *reinterpret_cast<const uint4*>(xb + (ok ? go : (W + 1) * ldx));
+        xmask |= (ok ? 1u : 0u) << i;
       }
     }
     if constexpr (XF == 2) {
@@ -222,17 +229,19 @@ struct ConvWgradTile {
         const int pix = dpr + i * DRP;
         const int ty = pix / TW, tx = pix - ty * TW;
         const bool ok = tid < DNA && pix < TH * TW && y0 + ty < H && x0 + tx < W && co0 + dcg * 8 < cout_pad;
-        dq[i] = ok ? *reinterpret_cast<const uint4*>(db + (long)(ty * W + tx) * lddy + dcg * 8) : make_uint4(0, 0, 0, 0);
-        dq2[i] = ok ? *reinterpret_cast<const uint4*>(x2b + (long)(ty * W + tx) * ldx2 + dcg * 8) : make_uint4(0, 0, 0, 0);
+        dq[i] = *reinterpret_cast<const uint4*>(db + (ok ? (ty * W + tx) * lddy + dcg * 8 : 0));
+        dq2[i] = *reinterpret_cast<const uint4*>(x2b + (ok ? (ty * W + tx) * ldx2 + dcg * 8 : 0));
         qok |= (ok ? 1u : 0u) << i;
       }
     } else {
+      dmask = 0;
 #pragma unroll
       for (int i = 0; i < DI; ++i) {
         int rc, go, lo;
         if constexpr (PRE) { rc = d_rc_[i]; go = d_go_[i]; lo = d_lo_[i]; } else { d_piece(i, &rc, &go, &lo); }
         const bool ok = lo >= 0 && y0 + (rc >> 8) < H && x0 + (rc & 255) < W;
-        dv[i] = ok ? *reinterpret_cast<const uint4*>(db + go) : make_uint4(0, 0, 0, 0);
+        dv[i] = *reinterpret_cast<const uint4*>(db + (ok ? go : 0));
+        dmask |= (ok ? 1u : 0u) << i;
       }
     }
   };
@@ -251,6 +260,8 @@ struct ConvWgradTile {
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
           xq[i] = pack8(f);
+        } else {
+          xq[i] = make_uint4(0, 0, 0, 0);
         }
         const int pix = xpr + i * XRP;
         if (tid < XNA && pix < HH_ * HW_) *reinterpret_cast<uint4*>(Xs + pix * SX + xcg * 16) = xq[i];
@@ -260,7 +271,7 @@ struct ConvWgradTile {
       for (int i = 0; i < XI; ++i) {
         int lo;
         if constexpr (PRE) { lo = x_lo_[i]; } else { int rc, go; x_piece(i, &rc, &go, &lo); }
-        if (lo >= 0) *reinterpret_cast<uint4*>(Xs + lo) = xv[i];
+        if (lo >= 0) *reinterpret_cast<uint4*>(Xs + lo) = ((xmask >> i) & 1u) ? xv[i] : make_uint4(0, 0, 0, 0);
       }
     }
     if constexpr (XF == 2) {
@@ -298,13 +309,15 @@ struct ConvWgradTile {
 #pragma unroll
       for (int i = 0; i < DQ; ++i) {
         const int pix = dpr + i * DRP;
-        if (tid < DNA && pix < TH * TW) *reinterpret_cast<uint4*>(Ds + pix * SD + dcg * 16) = dq[i];
+        if (tid < DNA && pix < TH * TW)
+          *reinterpret_cast<uint4*>(Ds + pix * SD + dcg * 16) = ((qok >> i) & 1u) ? dq[i] : make_uint4(0, 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < DI; ++i) {
         const int piece = tid + i * 256;
-        if (piece < DN) *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = dv[i];
+        if (piece < DN)
+          *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = ((dmask >> i) & 1u) ? dv[i] : make_uint4(0, 0, 0, 0);
       }
     }
   };
@@ -314,28 +327,50 @@ struct ConvWgradTile {
     stage();
     __syncthreads();
     if (t + 1 < t_end) fetch(t + 1);           // next tile's loads fly during this tile's MFMAs
-    // ---- 8 k-steps of 16 pixels (half a tile row each)
+    // ---- 8 k-steps of 16 pixels (half a tile row each).  The wave's n-block count (NBL or NBL - 1) is hoisted out
+    // of the loop, so each variant is straight-line code, and the fragments of k-step ks + 1 are read (into the other
+    // half of a register ring) while the MFMAs of k-step ks run -- left to itself the compiler read, waited,
+    // multiplied, and only then read again.
+    // columns n >= 9*Cin of the last n-block read whatever lies at offset 0 of the image: a B column only feeds its
+    // own output column, and those columns are never stored
+    auto k_loop = [&](auto nl_c) {
+      constexpr int NL = decltype(nl_c)::value;
+      bf16x8_t af[2][MB], bfr[2][NL > 0 ? NL : 1];
+      auto rd = [&](int ks, int slot) {
+        const int ty = ks >> 1, tx0 = (ks & 1) * 16;
+        const int kp = tx0 + 8 * lh + lj;         // this lane's first pixel column inside the row
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int ty = ks >> 1, tx0 = (ks & 1) * 16;
-      const int kp = tx0 + 8 * lh + lj;         // this lane's first pixel column inside the row
-      bf16x8_t af[MB], bfr[NBL];
+        for (int mb = 0; mb < MB; ++mb) af[slot][mb] = tr_read8(Ds + (ty * TW + kp) * SD + mb * 64 + a_col, SD);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-        af[mb] = tr_read8(Ds + (ty * TW + kp) * SD + mb * 64 + a_col, SD);
-      // columns n >= 9*Cin of the last n-block read whatever lies at offset 0 of the image:
-      // a B column only feeds its own output column, and those columns are never stored
+        for (int l = 0; l < NL; ++l) bfr[slot][l] = tr_read8(Xs + (ty * HW_ + kp) * SX + b_off[l], SX);
+      };
+      constexpr bool PIPE = CX != 192;          // the 192-channel instantiation has no registers for a second set
+      if constexpr (PIPE) {
+        rd(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MB + NL), 0);    // the prologue reads are a group of their own
+      }
 #pragma unroll
-      for (int l = 0; l < NBL; ++l)
-        if (wave + 4 * l < NBW) bfr[l] = tr_read8(Xs + (ty * HW_ + kp) * SX + b_off[l], SX);
+      for (int ks = 0; ks < 8; ++ks) {
+        if constexpr (PIPE) {
+          if (ks + 1 < 8) rd(ks + 1, (ks + 1) & 1);
+        } else {
+          rd(ks, 0);
+        }
+        const int slot = PIPE ? (ks & 1) : 0;
 #pragma unroll
-      for (int l = 0; l < NBL; ++l)
-        if (wave + 4 * l < NBW) {               // wave-uniform: waves without a 4th n-block skip it
+        for (int l = 0; l < NL; ++l)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
-            acc[mb][l] = ssa_mfma32(af[mb], bfr[l], acc[mb][l]);
+            acc[mb][l] = ssa_mfma32(af[slot][mb], bfr[slot][l], acc[mb][l]);
+        if constexpr (PIPE) {
+          if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MB + NL), 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MB * NL, 0);
         }
-    }
+      }
+    };
+    constexpr int NL_LO = NBW / 4, NL_HI = (NBW + 3) / 4;      // n-blocks of waves >= NBW % 4 / of the others
+    if (NL_HI == NL_LO || wave < NBW % 4) k_loop(std::integral_constant<int, NL_HI>());
+    else k_loop(std::integral_constant<int, NL_LO>());
   }
 
   // ---- this workgroup's block of partial[g][co][k] (zeros if it had no tile)
