@@ -32,7 +32,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDT = BK + 8;
 
-template <int MI, int NI>
+template <int MI, int NI, int BK = ::BK, int LDT = BK + 8>
 __device__ __forceinline__ void mma_stage(const bf16_t* __restrict__ As,
                                           const bf16_t* __restrict__ Bs, int a_row0,
                                           int b_row0, int lane,
@@ -67,9 +67,17 @@ struct IgemmArgs {
   int o_mul, o_py, o_px, o_W, o_HW;
 };
 
+// K-stage depth of the forward / data-gradient kernel: 64 for the small tiles.  Their launches are chains of
+// dependent K-stages (store -> barrier -> fragment reads -> two MFMAs) on a mostly idle chip -- a 3x3 stride-2 conv
+// with 192 input channels is 54 stages of 32 --, so halving the stage count is what shortens them; the 128-wide
+// tiles keep 32 (two workgroups per CU).  The packed filter rows stay padded to 32 (the last stage is masked).
+template <int MI, int NI> struct IgemmBK { static constexpr int value = MI * NI <= 2 ? 64 : 32; };
+
 template <int WGM, int WGN, int MI, int NI>
 struct ConvIgemm {
   typedef IgemmArgs Args;
+  static constexpr int BK = IgemmBK<MI, NI>::value;
+  static constexpr int LDT = BK + 8;
   static constexpr int NT = 64 * WGM * WGN;
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
   const ssa_conv_desc& d = a.d;
@@ -119,7 +127,7 @@ struct ConvIgemm {
     kw = tap - kh * d.KW;
   }
   const int tr_mask = (1 << tr_shift) - 1;
-  const int nk = d.Kpad / BK;
+  const int nk = (d.Kpad + BK - 1) / BK;
   const int o_mul = a.o_mul, o_py = a.o_py, o_px = a.o_px, o_W = a.o_W, o_HW = a.o_HW;
   auto opix = [&](int m) -> long {
     if (o_mul == 0) return m;
@@ -128,9 +136,17 @@ struct ConvIgemm {
     return (long)b * o_HW + (long)(oy * o_mul + o_py) * o_W + ox * o_mul + o_px;
   };
 
-  uint4 ra[A_IT], rb[B_IT];
-  auto gload = [&](int kt) {
+  // Global loads run PD - 1 K-stages ahead of the MFMAs, through a ring of PD register sets.  With one stage in
+  // flight (the first version) a 32-deep K-step cost a full memory latency: these launches are small (a 64x64 tile
+  // is two MFMAs per wave and K-step), so the loop ran at ~1 us per step whatever it computed (profiles/r03_notes.md).
+  // Every lane loads (pieces outside the image / past Cout read a valid address and are zeroed when they are staged):
+  // a select on the loaded value would put the wait inside the load phase.
+  constexpr int PD = 4;
+  uint4 ra[PD][A_IT], rb[PD][B_IT];
+  unsigned amask[PD], bmask[PD];
+  auto gload = [&](int kt, int slot) {
     const bool kvalid = kh < d.KH;
+    unsigned am = 0, bm = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int iy = iy0[i] + kh * d.dil, ix = ix0[i] + kw * d.dil;
@@ -143,16 +159,20 @@ struct ConvIgemm {
         ok = ok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
       }
       const long pix = ok ? (long)(pb[i] + iy * d.W + ix) : 0;
-      const bf16_t* p = x + pix * d.ldx + kc;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+      const bf16_t* p = x + pix * d.ldx + (ok ? kc : 0);
+      ra[slot][i] = *reinterpret_cast<const uint4*>(p);
+      am |= (ok ? 1u : 0u) << i;
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
       const int r = r0 + j * RPP, n = n0 + r;
-      const bool ok = (r < BN) && (n < d.Cout);
-      const bf16_t* p = w + (long)n * d.Kpad + kt * BK + pc * 8;
-      rb[j] = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+      const bool ok = (r < BN) && (n < d.Cout) && (kt * BK + pc * 8 < d.Kpad);
+      const bf16_t* p = w + (ok ? (long)n * d.Kpad + kt * BK + pc * 8 : 0);
+      rb[slot][j] = *reinterpret_cast<const uint4*>(p);
+      bm |= (ok ? 1u : 0u) << j;
     }
+    amask[slot] = am;
+    bmask[slot] = bm;
     // advance the cursor by one stage
     kc += BK;
     while (kc >= d.Cin) {
@@ -160,18 +180,20 @@ struct ConvIgemm {
       if (++kw == d.KW) { kw = 0; ++kh; }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int slot) {
     bf16_t* As = lds + buf * STAGE;
     bf16_t* Bs = As + BM * LDT;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int r = r0 + i * RPP;
-      if (r < BM) *reinterpret_cast<uint4*>(As + r * LDT + pc * 8) = ra[i];
+      if (r < BM)
+        *reinterpret_cast<uint4*>(As + r * LDT + pc * 8) = ((amask[slot] >> i) & 1u) ? ra[slot][i] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
       const int r = r0 + j * RPP;
-      if (r < BN) *reinterpret_cast<uint4*>(Bs + r * LDT + pc * 8) = rb[j];
+      if (r < BN)
+        *reinterpret_cast<uint4*>(Bs + r * LDT + pc * 8) = ((bmask[slot] >> j) & 1u) ? rb[slot][j] : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -183,16 +205,24 @@ struct ConvIgemm {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  gload(0);
-  lstore(0);
+#pragma unroll
+  for (int j = 0; j < PD - 1; ++j)
+    if (j < nk) gload(j, j);
+  lstore(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const bf16_t* As = lds + buf * STAGE;
-    mma_stage<MI, NI>(As, As + BM * LDT, wm * MI * 32, wn * NI * 32, lane, acc);
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int kt = kt0 + j;                    // stage kt lives in ring slot kt % PD = j (kt0 is a multiple of PD)
+      if (kt < nk) {
+        const int buf = kt & 1;
+        if (kt + PD - 1 < nk) gload(kt + PD - 1, (j + PD - 1) % PD);
+        const bf16_t* As = lds + buf * STAGE;
+        mma_stage<MI, NI, BK, LDT>(As, As + BM * LDT, wm * MI * 32, wn * NI * 32, lane, acc);
+        if (kt + 1 < nk) lstore(buf ^ 1, (j + 1) % PD);
+        __syncthreads();
+      }
+    }
   }
 
   // ------------------------------------------------------------- epilogue
@@ -751,7 +781,7 @@ int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float
   constexpr int BM = WGM * MI * 32, BN = WGN * NI * 32;
   const long M = (long)d.B * d.Ho * d.Wo;
   const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (d.Cout + BN - 1) / BN;
-  size_t lds = (size_t)2 * (BM + BN) * LDT * 2;
+  size_t lds = (size_t)2 * (BM + BN) * (IgemmBK<MI, NI>::value + 8) * 2;
   const size_t cs = (size_t)BM * (BN + 8) * 2 + (size_t)WGM * 2 * BN * sizeof(float);
   if (cs > lds) lds = cs;
   IgemmArgs a;

@@ -40,6 +40,19 @@ def main():
     print("-- instantiations")
     for k, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1])[:top]:
         print("%8.3f ms %5d  avg %7.1f us  %s" % (t / 1e6, c, t / c / 1e3, k))
+    if len(sys.argv) > 3:
+        # every launch of the step in issue order: start (us from the step's first launch), duration, gap to the
+        # previous launch's end, workgroups x threads, LDS bytes, kernel
+        with open(sys.argv[3], "w") as f:
+            prev_end = t0
+            for r in step:
+                st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)
+                grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+                f.write("%9.1f %7.1f %6.1f %6d x %4d  lds %6s  %s\n" % (
+                    (st - t0) / 1e3, (en - st) / 1e3, (st - prev_end) / 1e3, grid // max(wg, 1), wg,
+                    r.get("LDS_Block_Size", r.get("LDS_Block_Size_v", "?")), short(r["Kernel_Name"])))
+                prev_end = en
 
 
 if __name__ == "__main__":
