@@ -231,11 +231,11 @@ def main():
             step()
         torch.cuda.synchronize()
         lib().ssa_launch_count(1)
-        c0 = rccl.comm().calls if (dist_on and backend == "nccl" and rccl.ENABLED) else 0
+        c0 = rccl.total_calls() if (dist_on and backend == "nccl" and rccl.ENABLED) else 0
         step()
         launches_per_step = int(lib().ssa_launch_count(0))
         if dist_on and backend == "nccl" and rccl.ENABLED:
-            collectives_per_step = rccl.comm().calls - c0
+            collectives_per_step = rccl.total_calls() - c0
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     capture_error = None
@@ -392,6 +392,11 @@ def main():
                        "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)",
                        "library_launches_per_step": launches_per_step,
                        "collectives_per_step": collectives_per_step,
+                       # gradient exchange: ranges of the arena are all-reduced on a communication stream while backward
+                       # runs; what no compute can hide is the LAST range -- estimate = its bytes x 2 (ring all-reduce
+                       # traffic per rank) / 300 GB/s of xGMI per GPU
+                       "grad_exchanges_per_step": getattr(model, "exchanges", None) if dist_on else None,
+                       "exposed_comm_ms_estimate": (getattr(model, "tail_elements", 0) * 4 * 2 / 300e9 * 1e3) if dist_on else None,
                        "logit_tolerance": "north_star asks 1e-3 relative; bf16 storage gives ~1e-1 end to end on random "
                                           "weights (the fp32-oracle-with-bf16-storage emulation gives the same); every op "
                                           "holds one-bf16-rounding tolerance teacher-forced at this config "

@@ -349,11 +349,16 @@ def _is_param(t):
     return isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32
 
 
-_GRAD_SINK = [None]     # callable(list of (chunk, used_elements)) run before publication (DDP all-reduce)
+_GRAD_SINK = [None]     # data-parallel wrapper's exchange: object with reduce_range(buf, lo, hi) and finish()
 
 
-def set_grad_sink(fn):
-    _GRAD_SINK[0] = fn
+def set_grad_sink(sink):
+    """sink.reduce_range(buf, lo, hi): average buf[lo:hi] over the ranks, in place (may run on a communication
+    stream); sink.finish(): make the compute stream wait for every exchange issued so far.  With a sink installed the
+    queued weight gradients are flushed every SSA_DDP_FLUSH_AT layers DURING backward and the arena range completed by
+    each flush is handed to reduce_range at once -- the exchange overlaps the rest of backward
+    (apex.parallel.DistributedDataParallel's buckets, network/__init__.py:37-39)."""
+    _GRAD_SINK[0] = sink
 
 
 class _GradArena:
@@ -364,8 +369,9 @@ class _GradArena:
     FIRST_CHUNK = 1 << 24       # elements, until the total of a step is known
 
     def __init__(self):
-        self.chunks = []        # [tensor, used]
-        self.slots = {}         # id(param) -> (param, view)
+        self.chunks = []        # [tensor, used, elements already handed to the gradient sink]
+        self.slots = {}         # id(param) -> (param, view, chunk index, offset)
+        self.late = []          # (param, view): contributions that arrived after the parameter's slice was exchanged
         self.total_last = 0
         self.armed = False
 
@@ -379,25 +385,47 @@ class _GradArena:
         e = self.slots.get(id(p))
         if e is not None and e[0] is p:
             self._arm()
-            return e[1]
+            if e[3] >= self.chunks[e[2]][2]:
+                return e[1]
+            # the slice is already on its way to the other ranks (a parameter used again later in backward):
+            # this contribution gets a slice of its own, exchanged with a later range and added at publication
+            v = self._take(p)[0]
+            self.late.append((p, v))
+            return v
+        v, ci, off = self._take(p)
+        self.slots[id(p)] = (p, v, ci, off)
+        self._arm()
+        return v
+
+    def _take(self, p):
         n = _roundup(p.numel(), 64)
         if not self.chunks or self.chunks[-1][1] + n > self.chunks[-1][0].numel() or \
                 self.chunks[-1][0].device != p.device:
             size = max(n, self.total_last if not self.chunks else self.FIRST_CHUNK, 1)
             if not self.chunks and not self.total_last:
                 size = max(n, self.FIRST_CHUNK)
-            self.chunks.append([torch.zeros((size,), dtype=torch.float32, device=p.device), 0])
+            self.chunks.append([torch.zeros((size,), dtype=torch.float32, device=p.device), 0, 0])
         c = self.chunks[-1]
-        v = c[0][c[1]:c[1] + p.numel()].view(p.shape)
+        off = c[1]
+        v = c[0][off:off + p.numel()].view(p.shape)
         c[1] += n
-        self.slots[id(p)] = (p, v)
-        self._arm()
-        return v
+        return v, len(self.chunks) - 1, off
+
+    def reduce_completed(self):
+        """Hand every arena range that is final (its kernels are enqueued) to the gradient sink."""
+        sink = _GRAD_SINK[0]
+        if sink is None:
+            return
+        for c in self.chunks:
+            if c[1] > c[2]:
+                sink.reduce_range(c[0], c[2], c[1])
+                c[2] = c[1]
 
     def abandon(self):
         self.armed = False
         self.chunks = []
         self.slots = {}
+        self.late = []
 
     def publish(self):
         self.armed = False
@@ -406,14 +434,18 @@ class _GradArena:
             if not self.slots:
                 return
             if _GRAD_SINK[0] is not None:
-                _GRAD_SINK[0]([(c[0], c[1]) for c in self.chunks])
+                self.reduce_completed()
+                _GRAD_SINK[0].finish()
             dst, src = [], []
-            for p, v in self.slots.values():
+            for p, v, _, _ in self.slots.values():
                 if p.grad is None:
                     p.grad = v
                 else:
                     dst.append(p.grad)
                     src.append(v)
+            for p, v in self.late:
+                dst.append(p.grad)
+                src.append(v)
             if dst:
                 torch._foreach_add_(dst, src)
             self.total_last = sum(c[1] for c in self.chunks)
@@ -423,6 +455,7 @@ class _GradArena:
             del _WGRAD_Q[:]
             self.chunks = []
             self.slots = {}
+            self.late = []
 
 
 _GRADS = _GradArena()
@@ -688,6 +721,9 @@ _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel sta
 # 192 / end-of-backward-only = 31.0 / 30.0 / 29.4 / 29.1 ms per step -- the more layers a flush carries, the better its
 # persistent-workgroup launches fill the chip; the queued (x, dy) pairs of a 1024x1024 step are a few GB of 288.
 _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "100000"))
+# ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
+# range while backward goes on (a step queues ~640 layers: three exchanges, the last one short)
+_DDP_FLUSH_AT = int(os.environ.get("SSA_DDP_FLUSH_AT", "256"))
 _WGRAD_Q = []
 
 
@@ -794,6 +830,9 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
         _WGRAD_Q.append(job(_GRADS.slot(weight), True))
         if len(_WGRAD_Q) >= _WGRAD_FLUSH_AT:
             flush_wgrads()
+        elif _GRAD_SINK[0] is not None and len(_WGRAD_Q) >= _DDP_FLUSH_AT:
+            flush_wgrads()
+            _GRADS.reduce_completed()
         return None
     dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
     _run_wgrad_jobs([job(dw, False)], -1)

@@ -33,10 +33,10 @@ def sync_world(enabled=True, group=None):
     return 0
 
 
-def _all_reduce_(t, average=False, group=None):
+def _all_reduce_(t, average=False, group=None, comm_index=0):
     from . import rccl
     if rccl.usable(t, group):
-        rccl.comm().all_reduce_(t, average)      # one RCCL call on the stream the kernels run on
+        rccl.comm(comm_index).all_reduce_(t, average)      # one RCCL call on the current stream
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         if average:
@@ -55,6 +55,23 @@ def allreduce_bn_sums(sums, group=None):
     return sums
 
 
+class _Sink:
+    """What hip_backend's gradient arena talks to (weak: a dead wrapper exchanges nothing)."""
+
+    def __init__(self, ref):
+        self.ref = ref
+
+    def reduce_range(self, buf, lo, hi):
+        ddp = self.ref()
+        if ddp is not None and hi > lo:
+            ddp._reduce_range(buf, lo, hi)
+
+    def finish(self):
+        ddp = self.ref()
+        if ddp is not None:
+            ddp._finish_exchanges()
+
+
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, message_size=10_000_000, delay_allreduce=False, process_group=None, **_):
         super().__init__()
@@ -71,19 +88,48 @@ class DistributedDataParallel(nn.Module):
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._on_grad)
             from . import hip_backend
-            ref = weakref.ref(self)
-            hip_backend.set_grad_sink(lambda chunks: ref() is not None and ref()._reduce_arena(chunks))
+            self.exchanges = 0            # gradient all-reduces issued in the current backward pass
+            self.tail_elements = 0        # elements of the LAST exchange: the part no later compute can hide
+            self._comm_stream = None
+            self._overlap = os.environ.get("SSA_DDP_OVERLAP", "1") != "0"
+            hip_backend.set_grad_sink(_Sink(weakref.ref(self)))
+
+    def __del__(self):
+        try:
+            from . import hip_backend
+            sink = hip_backend._GRAD_SINK[0]
+            if isinstance(sink, _Sink) and sink.ref() is None:
+                hip_backend.set_grad_sink(None)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def forward(self, *args, **kwargs):
         self._hooked = []
         self._callback_queued = False
+        if self.active:
+            self.exchanges = 0
         return self.module(*args, **kwargs)
 
-    # -- gradients accumulated by the kernels in the backend's arena
-    def _reduce_arena(self, chunks):
-        for buf, used in chunks:
-            if used:
-                _all_reduce_(buf[:used], True, self.group)
+    # -- gradients accumulated by the kernels in the backend's arena: ranges as they complete (hip_backend._GradArena)
+    def _reduce_range(self, buf, lo, hi):
+        """Mean over ranks of buf[lo:hi], in place.  Device memory: on a communication stream of its own (second RCCL
+        communicator: the SyncBN exchanges keep the compute stream's), fenced by an event after the kernels that
+        produced the range -- a parallel branch of the captured step, concurrent with the rest of backward."""
+        t = buf[lo:hi]
+        self.exchanges += 1
+        self.tail_elements = hi - lo
+        if t.is_cuda and self._overlap:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                _all_reduce_(t, True, self.group, comm_index=1)
+        else:
+            _all_reduce_(t, True, self.group)
+
+    def _finish_exchanges(self):
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     # -- gradients that arrive through autograd (autograd thread)
     def _on_grad(self, p):

@@ -87,7 +87,7 @@ class DirectComm:
             self.comm = ctypes.c_void_p()
 
 
-_COMM = None
+_COMMS = {}
 
 
 def usable(t, group=None):
@@ -95,16 +95,21 @@ def usable(t, group=None):
     return ENABLED and group is None and t.is_cuda and dist.get_backend() == "nccl"
 
 
-def comm():
-    """The process-wide communicator (created on first use, after init_process_group)."""
-    global _COMM
-    if _COMM is None:
-        _COMM = DirectComm()
-    return _COMM
+def comm(index=0):
+    """Process-wide communicators (created on first use, after init_process_group).  0: the compute stream's
+    (SyncBN sums, end-of-step exchanges); 1: the gradient exchange that runs on a communication stream concurrently
+    with backward -- collectives of ONE communicator must not be in flight on two streams at once."""
+    c = _COMMS.get(index)
+    if c is None:
+        c = _COMMS[index] = DirectComm()
+    return c
+
+
+def total_calls():
+    return sum(c.calls for c in _COMMS.values())
 
 
 def shutdown():
-    global _COMM
-    if _COMM is not None:
-        _COMM.destroy()
-        _COMM = None
+    for c in _COMMS.values():
+        c.destroy()
+    _COMMS.clear()
