@@ -32,7 +32,17 @@ def _amp_shim():
     amp.float_function = lambda f: f
     amp.half_function = lambda f: f
     amp.disable_casts = contextlib.nullcontext
-    amp.initialize = lambda model, optimizers=None, opt_level="O1", **kw: (model, optimizers)
+
+    def initialize(model, optimizers=None, opt_level="O1", **kw):
+        # train.py:381 hands (net, optim) through here before it wraps the net for data parallelism.
+        # SSA_GRAPHED_STEP=1: hand back the hipGraph proxies (semseg_amd/graphed.py) -- the unmodified loop then
+        # replays one captured step per iteration
+        import os
+        if os.environ.get("SSA_GRAPHED_STEP", "0") == "1" and optimizers is not None and not isinstance(optimizers, (list, tuple)):
+            from .graphed import graph_training
+            return graph_training(model, optimizers)
+        return model, optimizers
+    amp.initialize = initialize
 
     @contextlib.contextmanager
     def scale_loss(loss, optimizers, **kw):   # bf16 needs no loss scaling

@@ -1,0 +1,158 @@
+"""The training step of the reference's loop (train.py:480-533) as ONE replayed hipGraph.
+
+    optim.zero_grad(); loss = net(inputs); loss.mean().backward(); optim.step()
+
+is ~840 kernel launches through ctypes plus Python autograd when it runs eagerly -- host bound (about four times the
+GPU time of the step at batch 1).  `GraphedTrainStep` captures exactly that sequence once per input shape (static
+input buffers, the batch is copied in) and replays it; `graph_training(net, optim)` wraps the two objects the
+reference's loop holds so that the UNMODIFIED loop runs the captured step:
+
+    net, optim = semseg_amd.graph_training(net, optim)      # e.g. from the amp.initialize shim, train.py:381
+    ...
+    optim.zero_grad()            # no-op (inside the graph)
+    main_loss = net(inputs)      # copy-in + replay: forward, backward AND optimizer step; returns the step's loss
+    main_loss.mean().backward()  # a leaf: nothing left to do
+    optim.step()                 # no-op (inside the graph); learning-rate changes reach the graph through the
+                                 # optimizer's device scalar (FusedSGD.sync_lr)
+
+Everything the step needs is capture safe by construction (no host synchronisation, torch's caching allocator,
+kernels on the current stream; at N > 1 the SyncBN and gradient exchanges are direct RCCL nodes).  Evaluation
+(`net.eval()` / `torch.no_grad()`) goes straight to the module.
+"""
+import torch
+from torch import nn
+
+
+class GraphedTrainStep:
+    """Captured `zero_grad -> net(inputs) -> backward -> optim.step` for dict inputs of device tensors."""
+
+    def __init__(self, net, optim, warmup=2):
+        self.net, self.optim, self.warmup = net, optim, warmup
+        self._graphs = {}          # input signature -> (graph, static inputs, static loss)
+
+    def _signature(self, inputs):
+        return tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(inputs.items()) if torch.is_tensor(v))
+
+    def _eager(self, static, loss_out):
+        self.optim.zero_grad(set_to_none=True)
+        loss = self.net(static)
+        loss = loss.mean()
+        loss.backward()
+        self.optim.step()
+        loss_out.copy_(loss.detach())
+
+    def _capture(self, inputs):
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+        dev = next(v.device for v in static.values() if torch.is_tensor(v))
+        loss_out = torch.zeros((), device=dev)
+        # the warm-up passes below are real steps; what they change is put back after the capture, so that a new
+        # input shape costs the training run nothing but time
+        params = [p for g in self.optim.param_groups for p in g["params"]]
+        snap_p = [p.detach().clone() for p in params]
+        snap_m = [self.optim.state[p]["momentum_buffer"].clone() if "momentum_buffer" in self.optim.state.get(p, {}) else None
+                  for p in params]
+        bufs = list(self.net.buffers())
+        snap_b = [b.detach().clone() for b in bufs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):        # allocator, momentum buffers, packed-filter cache
+                self._eager(static, loss_out)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.optim.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            self._eager(static, loss_out)
+        with torch.no_grad():
+            for p, s0, m0 in zip(params, snap_p, snap_m):
+                p.copy_(s0)                     # (bumps the version counter: the captured step re-packs the filters)
+                buf = self.optim.state.get(p, {}).get("momentum_buffer")
+                if buf is not None:
+                    if m0 is not None:
+                        buf.copy_(m0)
+                    else:
+                        buf.zero_()             # a zero buffer is the optimizer's first-step state
+            for b, s0 in zip(bufs, snap_b):
+                b.copy_(s0)
+        return graph, static, loss_out
+
+    def __call__(self, inputs):
+        """One training step on `inputs`; returns the step's (mean) loss as a detached 0-dim tensor."""
+        sig = self._signature(inputs)
+        ent = self._graphs.get(sig)
+        fresh = ent is None
+        if fresh:
+            ent = self._graphs[sig] = self._capture(inputs)
+        graph, static, loss_out = ent
+        if hasattr(self.optim, "sync_lr"):
+            self.optim.sync_lr()                # the scheduler's current learning rate -> the device scalar
+        if not fresh:
+            for k, v in inputs.items():
+                if torch.is_tensor(v):
+                    static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return loss_out.clone()
+
+
+class _GraphedNet(nn.Module):
+    """What the reference's loop calls as `net(inputs)`: in training mode the whole captured step."""
+
+    def __init__(self, net, stepper):
+        super().__init__()
+        self.wrapped = net
+        self._stepper = [stepper]              # not a submodule
+
+    def forward(self, inputs):
+        if self.wrapped.training and torch.is_grad_enabled():
+            loss = self._stepper[0](inputs)
+            return loss.requires_grad_(True)   # a leaf: the loop's own .backward() has nothing to do
+        return self.wrapped(inputs)
+
+    def train(self, mode=True):
+        self.wrapped.train(mode)
+        return super().train(mode)
+
+    def state_dict(self, *a, **k):
+        return self.wrapped.state_dict(*a, **k)
+
+    def load_state_dict(self, *a, **k):
+        return self.wrapped.load_state_dict(*a, **k)
+
+    def parameters(self, recurse=True):
+        return self.wrapped.parameters(recurse)
+
+    def named_parameters(self, *a, **k):
+        return self.wrapped.named_parameters(*a, **k)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(super().__getattr__("wrapped"), name)     # .module of the data-parallel wrapper etc.
+
+
+class _GraphedOptim:
+    """The optimizer as the loop sees it: zero_grad / step are inside the captured step."""
+
+    def __init__(self, optim):
+        self.__dict__["_optim"] = optim
+
+    def zero_grad(self, *a, **k):
+        pass
+
+    def step(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_optim"], name)
+
+    def __setattr__(self, name, value):
+        setattr(self.__dict__["_optim"], name, value)
+
+
+def graph_training(net, optim, warmup=2):
+    """(net, optim) -> proxies under which the reference's unmodified train() loop runs one hipGraph replay per
+    iteration (see the module docstring)."""
+    stepper = GraphedTrainStep(net, optim, warmup)
+    return _GraphedNet(net, stepper), _GraphedOptim(optim)

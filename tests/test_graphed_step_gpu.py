@@ -1,0 +1,73 @@
+"""The reference's training loop (train.py:480-533: zero_grad, net(inputs), mean, backward, optim.step) run through
+semseg_amd.graph_training -- the product's captured-step helper -- against the same loop run eagerly, at the
+benchmarked shape (nullloader: 1 x 3 x 1024 x 1024, datasets/nullloader.py:58-68, with the bench's synthetic batch so
+that the RMI covariances are not degenerate), three iterations from identical initial state.  Same kernels, same
+order; what may differ is the order of the fp64 / fp32 atomics inside the BatchNorm sums, hence a tolerance."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build():
+    from semseg_amd.config import cfg
+    from semseg_amd.loss import RMILoss
+    from semseg_amd.loss.optimizer import FusedSGD
+    from semseg_amd.network import ocrnet
+    cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
+    cfg.LOSS.OCR_AUX_RMI = False
+    cfg.MODEL.N_SCALES = None
+    cfg.MODEL.BNFUNC = None
+    torch.manual_seed(0)
+    net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255))
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight)
+    net = net.cuda().train()
+    return net, FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+
+
+def _reference_loop(net, optim, batches):
+    """train.py:480-533, the lines that touch the model."""
+    losses = []
+    for inputs in batches:
+        optim.zero_grad()
+        main_loss = net(inputs)
+        main_loss = main_loss.mean()
+        losses.append(main_loss.detach().clone())
+        main_loss.backward()
+        optim.step()
+    torch.cuda.synchronize()
+    return [float(v) for v in losses]
+
+
+def test_reference_loop_through_the_captured_step_matches_eager():
+    import semseg_amd
+    import __graft_entry__ as ge
+    crop = int(os.environ.get("SSA_PARITY_CROP", "1024"))
+    batches = []
+    for i in range(3):
+        images, gts = ge._synth(1, crop, crop, 40 + i, "cuda")
+        batches.append({"images": images, "gts": gts})
+    net, optim = _build()
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    eager = _reference_loop(net, optim, batches)
+    w_eager = net.ocr.cls_head.weight.detach().clone()
+
+    net2, optim2 = _build()
+    net2.load_state_dict(init)
+    gnet, goptim = semseg_amd.graph_training(net2, optim2)
+    graphed = _reference_loop(gnet, goptim, batches)
+    w_graphed = net2.ocr.cls_head.weight.detach().clone()
+    print("eager", eager, "graphed", graphed)
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 2e-3 * abs(a), (eager, graphed)
+    rel = float((w_eager - w_graphed).abs().max() / w_eager.abs().max())
+    assert rel < 1e-3, rel
+    # evaluation goes straight to the module
+    gnet.eval()
+    with torch.no_grad():
+        out = gnet({"images": batches[0]["images"]})
+    assert tuple(out["pred"].shape) == (1, 19, crop, crop)
