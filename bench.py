@@ -159,6 +159,7 @@ def main():
                     "trains on 1024x2048: scripts/train_cityscapes_sota.yml:14)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--eager-steps", type=int, default=3, help="eager steps timed after the graph run (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -282,6 +283,17 @@ def main():
         dt = float(t.item())
     loss_val = float(static_loss.item())
     ms = dt / args.steps * 1e3
+    # the same program without the hipGraph: what a loop that does not go through semseg_amd.graph_training pays
+    # (~840 ctypes launches + Python autograd per step, host bound)
+    eager_ms = None
+    if graph is not None and args.eager_steps > 0:
+        step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.eager_steps):
+            step()
+        sync()
+        eager_ms = (time.perf_counter() - t0) / args.eager_steps * 1e3
     ips = args.batch * world * args.steps / dt
     flop_scale = (args.crop / 1024.0) * (crop_w / 1024.0)
 
@@ -389,6 +401,7 @@ def main():
                                    % (args.crop, crop_w, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "hipgraph": graph is not None, "capture_error": capture_error, "loss": loss_val,
+                       "eager_ms_per_step": eager_ms,
                        "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)",
                        "library_launches_per_step": launches_per_step,
                        "collectives_per_step": collectives_per_step,

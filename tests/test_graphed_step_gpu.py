@@ -26,6 +26,11 @@ def _build():
         if isinstance(m, torch.nn.Conv2d):
             torch.nn.init.kaiming_normal_(m.weight)
     net = net.cuda().train()
+    # Dropout2d(0.05) of the OCR head draws its mask from torch's generator, whose state a captured graph advances
+    # differently from eager launches: off for this comparison (the mask path itself: test_kernels_gpu.py::test_bn_train)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
     return net, FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
 
 
