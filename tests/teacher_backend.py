@@ -46,8 +46,10 @@ class Record:
         err = (got - ref).abs()
         scale = float(ref.abs().max())
         mref = float(ref.abs().mean())
-        rmax = float(err.max()) / (scale + 1e-30)
+        rmax = float(err.max()) / (scale + 1e-30)          # the true worst element: this is what is REPORTED
         rmean = float(err.mean()) / (mref + 1e-30)
+        excused = 0.0                                       # fraction of elements beyond the max bound, if allowed
+        rmax_eff = rmax
         if what.startswith("d") and rmax > tol[0]:
             # gradients through a ReLU mask recomputed from bf16 data: an element whose pre-activation is
             # within rounding of zero may fall on the other side of the mask than the teacher's and then
@@ -56,12 +58,14 @@ class Record:
             # the filter footprint -- 2048 elements = 0.13 % of layer4's 768-pixel input per flip -- so the
             # allowance there is 0.5 % of the elements; the mean bound still holds for all of them.
             frac = 5e-3 if what.startswith("din") else 1e-4
-            if float((err > tol[0] * scale).float().mean()) <= frac:
-                rmax = tol[0]
-        ok = finite and (scale == 0.0 and float(err.max()) == 0.0 or (rmax <= tol[0] and rmean <= tol[1]))
+            beyond = float((err > tol[0] * scale).float().mean())
+            if beyond <= frac:
+                rmax_eff = tol[0]
+                excused = beyond
+        ok = finite and (scale == 0.0 and float(err.max()) == 0.0 or (rmax_eff <= tol[0] and rmean <= tol[1]))
         cos = float((got * ref).sum() / (got.norm() * ref.norm() + 1e-30))
         ratio = float(got.norm() / (ref.norm() + 1e-30))
-        self.rows.append((idx, op, what, tuple(ref.shape), rmax, rmean, tol, ok, cos, ratio))
+        self.rows.append((idx, op, what, tuple(ref.shape), rmax, rmean, tol, ok, cos, ratio, excused))
 
     def failures(self):
         return [r for r in self.rows if not r[7]]
@@ -70,17 +74,22 @@ class Record:
         lines = ["%d ops, %d comparisons, %d failures" % (self.n_ops, len(self.rows), len(self.failures()))]
         worst = sorted(self.rows, key=lambda r: -max(r[4] / r[6][0], r[5] / r[6][1]))[:k]
         for r in self.failures()[:40] + [w for w in worst if w[7]]:
+            note = "" if r[7] else "FAIL"
+            if r[10] > 0:
+                note += " (%.2e of the elements beyond the max bound: ReLU-mask flips, allowed)" % r[10]
             lines.append("  op %4d %-14s %-18s %-22s max %.4f (tol %.4f) mean %.4f (tol %.4f) cos %.4f |got|/|ref| %.3f %s" % (
-                r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], r[8], r[9], "" if r[7] else "FAIL"))
+                r[0], r[1], r[2], r[3], r[4], r[6][0], r[5], r[6][1], r[8], r[9], note))
         return "\n".join(lines)
+
+
+F32_CHANNELS = {1, 19}          # class logits / attention maps are fp32 on the HIP path (add the class count of the model)
 
 
 def _hip_dtype(t):
     d = getattr(t, "_hip_dtype", None)
     if d is not None:
         return d
-    # class logits ([..,19]) and attention maps ([..,1]) are fp32 on the HIP path, activations bf16
-    return torch.float32 if (t.dim() == 4 and t.shape[-1] in (1, 19)) or t.dim() == 0 else torch.bfloat16
+    return torch.float32 if (t.dim() == 4 and t.shape[-1] in F32_CHANNELS) or t.dim() == 0 else torch.bfloat16
 
 
 def _isolated(fn):
