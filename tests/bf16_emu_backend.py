@@ -15,14 +15,32 @@ import torch
 from oracle_backend import OracleBackend
 
 
+import contextlib
+
+# storage type the emulation rounds to: bf16 = the product's; fp16 = what the reference's apex-O1 path stores
+# (`storage(torch.float16)`: the noise floor the REFERENCE'S OWN mixed-precision run has against its fp32 run,
+# tests/test_storage_floor_cpu.py)
+_STORAGE = [torch.bfloat16]
+
+
+@contextlib.contextmanager
+def storage(dtype):
+    prev = _STORAGE[0]
+    _STORAGE[0] = dtype
+    try:
+        yield
+    finally:
+        _STORAGE[0] = prev
+
+
 class _Round(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+        return x.to(_STORAGE[0]).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(_STORAGE[0]).to(g.dtype)
 
 
 R = _Round.apply

@@ -30,6 +30,7 @@ GRAD_TOL = (2e-2, 6e-3)        # data gradients (bf16, through BN)
 # to bf16 (the emulation rounds the gradient of a bf16-stored weight), the HIP side's dy is bf16 --
 # measured 0.2 % typical, 0.5 % in the tail of the 2,250 comparisons of a step.
 PARAM_TOL = (5e-2, 8e-3)
+OCR_GATHER_TOL = tuple([5e-3, 2e-3])   # (built at run time: CPython merges equal literal tuples, and `is BF16_TOL` selects F32_TOL)
 LOSS_TOL = (1e-4, 1e-4)
 
 
@@ -345,7 +346,9 @@ class TeacherBackend(BackendBase):
         return y
 
     def ocr_gather(self, feats, logits):
-        y = self._one("ocr_gather", "ocr_gather", [feats, logits], ((1e-2, 4e-3), (2e-2, 8e-3)))
+        # fp32 output of a sum over H*W products whose probability operand the HIP path stores in bf16 (2^-9 each,
+        # independent): against the fp32 teacher that is 7e-4 of mean|ref| at 131,072 pixels (1024 x 2048 eval)
+        y = self._one("ocr_gather", "ocr_gather", [feats, logits], (OCR_GATHER_TOL, (2e-2, 8e-3)))
         y._hip_dtype = torch.float32
         return y
 
