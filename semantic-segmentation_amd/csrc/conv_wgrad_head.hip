@@ -43,14 +43,27 @@ __device__ __forceinline__ bf16x8_t tr8(const unsigned char* p, int stride_bytes
 // KS = 1: NT = 2 (two 32-channel blocks per wave), 256 input channels per workgroup.
 struct WgradHeadArgs {
   const bf16_t* x; const bf16_t* dy; float* partial;
-  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, ci_tiles;
+  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, ci_tiles, G, wgs_y;
 };
+
+// Bijective XCD-aware order (block b runs on XCD b % 8): XCD x gets one contiguous range of work items.
+__device__ __forceinline__ int xcd_order(int v, int n) {
+  const int q = n >> 3, r = n & 7, x = v & 7, k = v >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
 
 template <int KS>
 struct ConvWgradHead {
   typedef WgradHeadArgs Args;
   static constexpr int NT = 512;
-  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by_, const int /*gx*/) {
+  static __device__ __forceinline__ void run(const Args& a, const int bx_, const int by0_, const int /*gx*/) {
+  // Work items in the order (pixel strip, co tile, ci tile, kernel row), dealt to the XCDs in contiguous ranges: the
+  // 18 workgroups (6 ci tiles x 3 kernel rows) that stream the same dy block, and the 12 that stream the same x
+  // block, then run on ONE XCD at about the same pixel and share its L2 -- in launch order (strip fastest) every
+  // workgroup fetched its operands from HBM by itself: 3.9 GB of fabric traffic for 0.72 GB of operands
+  // (profiles/r03_pmc.txt), the kernel ran at the fabric's bandwidth, not the MFMA's.
+  const int w_ = xcd_order(by0_ * a.G + bx_, a.G * a.wgs_y);
+  const int bx = w_ / a.wgs_y, by_ = w_ - bx * a.wgs_y;
   const bf16_t* __restrict__ x = a.x;
   const bf16_t* __restrict__ dy = a.dy;
   float* __restrict__ partial = a.partial;
@@ -102,6 +115,7 @@ struct ConvWgradHead {
   const int t_begin = bx * tiles_per_wg;
   const int t_end = min(total_tiles, t_begin + tiles_per_wg);
   uint4 xv[XI], dv[DI];
+  unsigned xmask = 0, dmask = 0;               // bit i: piece i lies inside the image (others are zeroed when staged)
   auto fetch = [&](int t) {
     int r_ = t;
     const int tx_i = r_ % tiles_x; r_ /= tiles_x;
@@ -118,7 +132,9 @@ struct ConvWgradHead {
       const int hy = pix / XW, hx = pix - hy * XW;
       const int iy = y0 + hy + yoff, ix = x0 + hx + xoff;
       const bool ok = piece < XN && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ci0 + cp * 8 < Cin;
-      xv[i] = ok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx + cp * 8) : make_uint4(0, 0, 0, 0);
+      // every lane loads (a select on the loaded value makes the compiler wait for the loads right here)
+      xv[i] = *reinterpret_cast<const uint4*>(ok ? xb + ((long)iy * W + ix) * ldx + cp * 8 : x);
+      xmask = i == 0 ? (ok ? 1u : 0u) : (xmask | ((ok ? 1u : 0u) << i));
     }
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
@@ -126,19 +142,22 @@ struct ConvWgradHead {
       const int pix = piece / DP, cp = piece - pix * DP;
       const int oy = y0 + pix / TW, ox = x0 + pix % TW;
       const bool ok = piece < DN && oy < H && ox < W && co0 + cp * 8 < cout_pad;
-      dv[i] = ok ? *reinterpret_cast<const uint4*>(db + ((long)oy * W + ox) * lddy + cp * 8) : make_uint4(0, 0, 0, 0);
+      dv[i] = *reinterpret_cast<const uint4*>(ok ? db + ((long)oy * W + ox) * lddy + cp * 8 : dy);
+      dmask = i == 0 ? (ok ? 1u : 0u) : (dmask | ((ok ? 1u : 0u) << i));
     }
   };
   auto stage = [&]() {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int piece = tid + i * 512;
-      if (piece < XN) *reinterpret_cast<uint4*>(Xs + (piece / XP) * SX + (piece % XP) * 16) = xv[i];
+      if (piece < XN)
+        *reinterpret_cast<uint4*>(Xs + (piece / XP) * SX + (piece % XP) * 16) = ((xmask >> i) & 1u) ? xv[i] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
       const int piece = tid + i * 512;
-      if (piece < DN) *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = dv[i];
+      if (piece < DN)
+        *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = ((dmask >> i) & 1u) ? dv[i] : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -148,21 +167,27 @@ struct ConvWgradHead {
     stage();
     __syncthreads();
     if (t + 1 < t_end) fetch(t + 1);           // next tile's loads fly during this tile's MFMAs
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {           // 16 pixels (half a tile row) per k-step
+    // 16 pixels (half a tile row) per k-step; the fragments of k-step ks + 1 are read while the MFMAs of ks run
+    bf16x8_t af[2][2], bfr[2][NT];
+    auto rd = [&](int ks, int slot) {
       const int ty = ks >> 1, kp = (ks & 1) * 16 + 8 * lh + lj;
-      bf16x8_t af[2], bfr[NT];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        af[m] = tr8(Ds + (ty * TW + kp) * SD + (wm * 2 + m) * 64 + a_col, SD);
+      for (int m = 0; m < 2; ++m) af[slot][m] = tr8(Ds + (ty * TW + kp) * SD + (wm * 2 + m) * 64 + a_col, SD);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bfr[j] = tr8(Xs + (ty * XW + kp) * SX + b_off[j], SX);
+      for (int j = 0; j < NT; ++j) bfr[slot][j] = tr8(Xs + (ty * XW + kp) * SX + b_off[j], SX);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NT), 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) rd(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[m][j] = ssa_mfma32(af[m], bfr[j], acc[m][j]);
+          acc[m][j] = ssa_mfma32(af[ks & 1][m], bfr[ks & 1][j], acc[m][j]);
+      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (2 + NT), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
     }
   }
 
@@ -221,6 +246,7 @@ int launch_head(const ssa_conv_desc& d, const HeadPlan& p, const void* x, const 
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
   a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
   a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = p.tpw; a.ci_tiles = p.ci_tiles;
+  a.G = p.G; a.wgs_y = p.wgs_y;
   return ssa::submit<ConvWgradHead<KS>>(a, p.G, p.wgs_y, lds, s);
 }
 
