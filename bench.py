@@ -343,17 +343,22 @@ def main():
         # rocprofv3 passes over this same command, corrected as MI355X_MICROARCH.md prescribes),
         # collected offline (rocprofv3 cannot run inside this process) by tools/pmc_traffic.py; refused
         # unless it was measured on these very kernel sources
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        traffic, traffic_src, mfma_busy, pmc_fam = None, None, None, {}
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("source_sha") == source_sha():
                 ent = pj["kernels"].get(name)
                 if ent:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], "profiles/r03_pmc_traffic.json"
+                    traffic, traffic_src = ent.get("hbm_bytes_per_launch"), "profiles/r03_pmc.json"
+                    mfma_busy = ent.get("mfma_busy_frac")
+                # MFMA-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles), fabric bytes, LDS conflicts per family
+                pmc_fam = {k: {"mfma_busy_frac": v.get("mfma_busy_frac"), "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
+                               "lds_conflict_frac": v.get("lds_conflict_frac"), "waves_per_simd": v.get("waves_per_simd")}
+                           for k, v in pj["kernels"].items() if k in CONV_FAMILIES}
             else:
-                traffic_src = "profiles/r03_pmc_traffic.json refused: measured on other kernel sources"
+                traffic_src = "profiles/r03_pmc.json refused: measured on other kernel sources"
         sec = d["us"] * 1e-6
         mfma_bound = d["flops"] / max(d["bytes"], 1.0) > PEAK_BF16_MFMA / PEAK_HBM
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name,
@@ -362,6 +367,7 @@ def main():
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": d["flops"] / sec / PEAK_BF16_MFMA if mfma_bound else d["bytes"] / sec / PEAK_HBM,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "mfma_busy_frac": mfma_busy, "pmc_conv_families": pmc_fam,
                 "launches_per_step": d["launches"] // 2, "problems_per_launch": d["jobs"] / d["launches"],
                 "avg_launch_us": d["us"] / d["launches"], "flop_per_launch": d["flops"] / d["launches"],
                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

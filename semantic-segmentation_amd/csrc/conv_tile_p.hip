@@ -42,7 +42,9 @@ constexpr int kStatReplicas = 8;   // as conv_tile.hip (ssa_bn_stat_replicas)
 // -DSSA_TILE_TIMING (tools/tilebench.py --timing; never in the product build): wave 0 of workgroup 0 writes
 // s_memtime stamps of every phase of its first iterations to the `coef` pointer (reinterpreted, XF 0 / aux 0 only)
 #ifdef SSA_TILE_TIMING
-#define SSA_STAMP(k) do { if (tdbg && it < 24) { tdbg[it * 8 + (k)] = (long)__builtin_amdgcn_s_memtime(); } } while (0)
+// (stamps go to spare LDS during the loop -- a global store would sit in the vmcnt queue every barrier waits for -- and
+// are copied out at the end)
+#define SSA_STAMP(k) do { if (tdbg && it < 24) { tlds[it * 8 + (k)] = (long)__builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define SSA_STAMP(k) do { } while (0)
 #endif
@@ -278,6 +280,7 @@ struct ConvTileP {
     if (n_iter <= 0) return;
 #ifdef SSA_TILE_TIMING
     long* tdbg = (AUXM == 0 && XF == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
+    long* tlds = reinterpret_cast<long*>(smem + LDS);          // 1.5 KB past the kernel's own LDS (the timing build asks for it)
 #endif
     // ---- prologue: first halo into registers, the filter (slice / first stage) on its way into LDS
     fetch(0);
@@ -420,6 +423,10 @@ struct ConvTileP {
       cc = ccn;
     }
 
+#ifdef SSA_TILE_TIMING
+    if (tdbg)
+      for (int i = 0; i < 24 * 8; ++i) tdbg[i] = i < n_iter * 8 ? tlds[i] : 0;
+#endif
     // ---- statistics of the strip: lanes -> wave -> workgroup -> one fp64 atomic per channel
     if constexpr (AUXM == 1) return;          // residual add: no statistics (stats is NULL by contract)
     if (stats != nullptr) {
@@ -472,7 +479,11 @@ struct ConvTilePAny {
   static constexpr int NT = 256;
   typedef ConvTileP<48, 2, 9, XF, AUXM> V0;
   typedef ConvTileP<96, 1, 3, XF, AUXM> V1;
+#ifdef SSA_TILE_TIMING
+  static constexpr size_t LDS = (V0::LDS > V1::LDS ? V0::LDS : V1::LDS) + 1536;
+#else
   static constexpr size_t LDS = V0::LDS > V1::LDS ? V0::LDS : V1::LDS;
+#endif
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) {
     if (a.variant == 0) V0::run(a, bx, by, gx);
     else V1::run(a, bx, by, gx);
