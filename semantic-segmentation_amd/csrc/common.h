@@ -21,6 +21,7 @@ __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t 
 __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return emu::ds_read_tr16_b64(lds_ptr); }
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
 __device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
+template <int VM, int LGKM = 0> __device__ __forceinline__ void ssa_wait_vm_barrier() { __syncthreads(); }
 #else
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
@@ -40,6 +41,19 @@ __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) {
 // in order, so only the compiler must not move the reads above the writes (the emulation runs lanes as
 // independent fibers and needs a real rendezvous here)
 __device__ __forceinline__ void ssa_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+// Workgroup barrier that lets the newest VM vector-memory operations of this wave stay in flight:
+//   s_waitcnt vmcnt(VM) lgkmcnt(LGKM) ; s_barrier
+// (__syncthreads() is a fence: it waits vmcnt(0), i.e. for every LDS DMA issued so far -- a pipeline that keeps
+// more than one stage of global_load_lds in flight needs this form).  Memory operations retire in order, so after
+// the barrier everything every wave issued BEFORE its newest VM operations is visible in LDS.  The caller must
+// know VM exactly: every wave has to issue the same operations on every path to this point.  The emulation's
+// DMA lands at the next barrier whatever VM is (tools/emu), which is the latest the hardware may deliver it.
+// LGKM > 0 likewise leaves the newest LGKM LDS reads in flight (reads of data no DMA overwrites before the next
+// barrier: a fragment read-ahead that runs across the barrier).
+template <int VM, int LGKM = 0> __device__ __forceinline__ void ssa_wait_vm_barrier() {
+  static_assert(VM >= 0 && VM < 64 && LGKM >= 0 && LGKM < 16, "vmcnt is a 6-bit counter, lgkmcnt a 4-bit one");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)\n\ts_barrier" ::"n"(VM), "n"(LGKM) : "memory");
+}
 #endif
 
 #define SSA_OK 0

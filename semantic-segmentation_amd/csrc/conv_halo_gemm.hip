@@ -10,31 +10,140 @@
 //   * A operand: the (8+2)x(32+2) input HALO tile of the chunk is staged in LDS
 //     once and serves all 9 taps (each tap is the same image at a shifted pixel
 //     offset) -- 9x less L2->LDS traffic for A than an im2col gather, which is
-//     what makes a 128-wide N tile affordable (A+B ~ 21 B/clk/CU at full MFMA
-//     rate instead of ~47).  Double buffered; the next chunk's global loads are
-//     held in registers during one tap's MFMAs.
+//     what makes a 128-wide N tile affordable.  It arrives by DMA as well
+//     (global_load_lds_dwordx4, no registers, no ds_write), pixel-major with the
+//     16-byte pieces of a pixel XOR-swizzled so that ds_read_b128 is conflict free
+//     without padding (a DMA fills 64 CONSECUTIVE slots).  3x3: double buffered per
+//     chunk; 1x1: in the same ring as the filter.
 //   * B operand: the filter in MFMA-fragment order ([n-block][k-step][lane][8],
-//     ssa_pack_filter mode 2/3), streamed per (chunk, tap) straight into LDS with
-//     global_load_lds_dwordx4 (1 KiB per wave instruction), double buffered.
-//   * one barrier per (chunk, tap) stage: 12..16 MFMAs per wave between barriers,
-//     two waves per SIMD to cover each other's LDS/DMA waits.
-// Halo pixel stride is CK*2+16 bytes (an odd number of 16-byte slots): the 16
-// lanes ds_read_b128 services together read distinct slots.
+//     ssa_pack_filter mode 2/3), streamed per (chunk, tap) stage straight into a
+//     RING of LDS buffers with global_load_lds_dwordx4 (1 KiB per wave
+//     instruction), RING - 1 stages ahead of the MFMAs.  A stage is only 12..16
+//     MFMAs per wave (~1000 clocks per SIMD with two waves); an L2 hit takes about
+//     twice that under load, so with one stage of lookahead (round 2: double
+//     buffer + __syncthreads, whose fence waits vmcnt(0)) every stage ended in a
+//     wait for its successor's filter: 0.85 us per stage, 38 % of the MFMA peak.
+//     The stage now ends in  s_waitcnt vmcnt(K) ; s_barrier  with K = the number
+//     of vector-memory operations issued after the NEXT stage's filter (memory
+//     operations retire in order): only that one has to have landed.  Every wave
+//     issues the same operations in every stage (out-of-range prefetches are
+//     clamped, not skipped), so K is a compile-time constant per tap.
 #include "common.h"
 #include "group.h"
 #include "../../include/semseg_hip.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int kStatReplicasG = 8;   // must equal conv_tile.hip's kStatReplicas
+
+__device__ uint4 g_zero_piece;      // 16 zero bytes: what a halo piece outside the image loads
 
 struct HaloArgs {
   const bf16_t* x; const uint4* wfrag; const float* bias; void* y; double* stats;
   int ldx, Cin, ldy, out_f32, B, H, W, Cout, nb_total, tiles_x, tiles_y;
 };
 
-template <int CK, int KS>
-struct ConvHaloGemm {
+// Epilogue shared by the two kernels: bias, bf16 rounding, BatchNorm partial sums of the ROUNDED values, the tile
+// staged through LDS for 16-byte row stores (or plain fp32 stores for the logit convs).
+struct HaloTile { int bx, nb0, b, y0, x0, wm, wn; };
+
+__device__ __forceinline__ void halo_epilogue(const HaloArgs& a, const HaloTile& k, f32x16_t (&acc)[2][2], unsigned char* smem) {
+  constexpr int NB = 4, TW = 32, BM = 256;
+  const float* __restrict__ bias = a.bias;
+  void* __restrict__ yv = a.y;
+  double* __restrict__ stats = a.stats;
+  const int ldy = a.ldy, out_f32 = a.out_f32, H = a.H, W = a.W, Cout = a.Cout;
+  const int bx = k.bx, nb0 = k.nb0, b = k.b, y0 = k.y0, x0 = k.x0, wm = k.wm, wn = k.wn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n_base = nb0 * 32 + wn * 64;
+  if (out_f32) {
+    float* y = reinterpret_cast<float*>(yv) + (long)b * H * W * ldy;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n_base + ni * 32 + (lane & 31);
+      const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (wm * 2 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int oy = y0 + row / TW, ox = x0 + row % TW;
+          if (oy < H && ox < W && n < Cout) y[((long)oy * W + ox) * ldy + n] = acc[mi][ni][r] + bv;
+        }
+    }
+    return;
+  }
+  constexpr int LDC = NB * 32 + 8;
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 wm][2][128]
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = wn * 64 + ni * 32 + (lane & 31);
+    const int n = nb0 * 32 + col;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+    float sacc = 0.f, qacc = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * 2 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const bf16_t o = f2bf(acc[mi][ni][r] + bv);
+        Cs[row * LDC + col] = o;
+        if (stats != nullptr) {
+          const float f = (y0 + row / TW < H && x0 + row % TW < W) ? bf2f(o) : 0.f;
+          sacc += f;
+          qacc += f * f;
+        }
+      }
+    if (stats != nullptr) {
+      sacc += __shfl_xor(sacc, 32, 64);
+      qacc += __shfl_xor(qacc, 32, 64);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * 128 + col] = sacc;
+        red[(wm * 2 + 1) * 128 + col] = qacc;
+      }
+    }
+  }
+  __syncthreads();
+  if (stats != nullptr) {
+    double* st = stats + (long)(bx % kStatReplicasG) * 2 * Cout;
+    if (tid < 256) {
+      const int which = tid >> 7, col = tid & 127;
+      const int n = nb0 * 32 + col;
+      if (n < Cout) {
+        const float v = (red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col]) +
+                        (red[(2 * 2 + which) * 128 + col] + red[(3 * 2 + which) * 128 + col]);
+        atomicAdd(&st[which * Cout + n], (double)v);
+      }
+    }
+  }
+  bf16_t* yb = reinterpret_cast<bf16_t*>(yv) + (long)b * H * W * ldy;
+  constexpr int CPR = NB * 4;
+  for (int idx = tid; idx < BM * CPR; idx += 512) {
+    const int row = idx / CPR, cp = idx - row * CPR;
+    const int oy = y0 + row / TW, ox = x0 + row % TW, n = nb0 * 32 + cp * 8;
+    if (oy >= H || ox >= W || n >= Cout) continue;
+    bf16_t* dst = yb + ((long)oy * W + ox) * ldy + n;
+    const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (n + 8 <= Cout) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
+    }
+  }
+}
+
+// 1x1 convs: a stage is a whole chunk -- 32 KiB of input tile + 16 KiB of filter per 12..16 MFMAs per wave, the
+// L1 -> LDS path (64 B/clk/CU) is what bounds them, not the stage latency; they keep the register-staged, padded
+// halo image and the double-buffered filter of round 2 (the DMA/swizzle pipeline of the 3x3 kernel measured
+// 109 -> 132 us on 720->720 @ 256x256: its zero-source padding pieces and duplicate filter blocks cost L1 cycles).
+template <int CK>
+struct ConvHaloGemm1 {
+  static constexpr int KS = 1;
+  // CK = 48: the pipeline is 80 KiB of LDS -- two workgroups per CU when the kernel stays within 128 registers
+  // (it did by itself in round 2; with 142 the 720->720 conv ran 105 -> 136 us)
+  static constexpr int WPE = CK == 48 ? 4 : 2;
   typedef HaloArgs Args;
   static constexpr int NT = 512;
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
@@ -45,7 +154,7 @@ struct ConvHaloGemm {
   double* __restrict__ stats = a.stats;
   const int ldx = a.ldx, Cin = a.Cin, ldy = a.ldy, out_f32 = a.out_f32, H = a.H, W = a.W, Cout = a.Cout;
   const int nb_total = a.nb_total, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
-  constexpr int NB = 4, TW = 32, TH = 8, BM = 256, R = KS / 2;
+  constexpr int NB = 4, TW = 32, TH = 8, R = KS / 2;
   constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
   constexpr int PSB = CK * 2 + 16;
   constexpr int CP = CK / 8;
@@ -164,103 +273,205 @@ struct ConvHaloGemm {
     __syncthreads();
     c = cn; t = tn;
   }
-
-  // ---- epilogue
-  const int n_base = nb0 * 32 + wn * 64;
-  if (out_f32) {
-    float* y = reinterpret_cast<float*>(yv) + (long)b * H * W * ldy;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = n_base + ni * 32 + (lane & 31);
-      const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (wm * 2 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int oy = y0 + row / TW, ox = x0 + row % TW;
-          if (oy < H && ox < W && n < Cout) y[((long)oy * W + ox) * ldy + n] = acc[mi][ni][r] + bv;
-        }
-    }
-    return;
-  }
-  constexpr int LDC = NB * 32 + 8;
-  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
-  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);   // [4 wm][2][128]
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = wn * 64 + ni * 32 + (lane & 31);
-    const int n = nb0 * 32 + col;
-    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
-    float sacc = 0.f, qacc = 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * 2 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const bf16_t o = f2bf(acc[mi][ni][r] + bv);
-        Cs[row * LDC + col] = o;
-        if (stats != nullptr) {
-          const float f = (y0 + row / TW < H && x0 + row % TW < W) ? bf2f(o) : 0.f;
-          sacc += f;
-          qacc += f * f;
-        }
-      }
-    if (stats != nullptr) {
-      sacc += __shfl_xor(sacc, 32, 64);
-      qacc += __shfl_xor(qacc, 32, 64);
-      if (lane < 32) {
-        red[(wm * 2 + 0) * 128 + col] = sacc;
-        red[(wm * 2 + 1) * 128 + col] = qacc;
-      }
-    }
-  }
-  __syncthreads();
-  if (stats != nullptr) {
-    double* st = stats + (long)(bx % kStatReplicasG) * 2 * Cout;
-    if (tid < 256) {
-      const int which = tid >> 7, col = tid & 127;
-      const int n = nb0 * 32 + col;
-      if (n < Cout) {
-        const float v = (red[(0 * 2 + which) * 128 + col] + red[(1 * 2 + which) * 128 + col]) +
-                        (red[(2 * 2 + which) * 128 + col] + red[(3 * 2 + which) * 128 + col]);
-        atomicAdd(&st[which * Cout + n], (double)v);
-      }
-    }
-  }
-  bf16_t* yb = reinterpret_cast<bf16_t*>(yv) + (long)b * H * W * ldy;
-  constexpr int CPR = NB * 4;
-  for (int idx = tid; idx < BM * CPR; idx += 512) {
-    const int row = idx / CPR, cp = idx - row * CPR;
-    const int oy = y0 + row / TW, ox = x0 + row % TW, n = nb0 * 32 + cp * 8;
-    if (oy >= H || ox >= W || n >= Cout) continue;
-    bf16_t* dst = yb + ((long)oy * W + ox) * ldy + n;
-    const bf16_t* src = Cs + row * LDC + cp * 8;
-    if (n + 8 <= Cout) {
-      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
-    } else {
-      for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
-    }
-  }
+  HaloTile k = {bx, nb0, b, y0, x0, wm, wn};
+  halo_epilogue(a, k, acc, smem);
   }
 };
 
-template <int CK, int KS>
-int launch_halo(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
+// 3x3 convs.
+template <int CK, int RING>
+struct ConvHaloGemm3 {
+  typedef HaloArgs Args;
+  static constexpr int NT = 512;
+  static constexpr int KS = 3, NB = 4, TW = 32, TH = 8, R = 1;
+  static constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R;
+  static constexpr int CP = CK / 8;                    // 16-byte pieces of a pixel's chunk that carry data
+  static constexpr int NPIECE = HH_ * HW_ * 8;         // LDS slots: 8 per pixel (128 bytes; CK = 48 leaves 2 unused)
+  static constexpr int IT = (NPIECE + 511) / 512;      // halo DMAs per wave and chunk
+  static constexpr int HWI = (NPIECE + 63) / 64;       // wave instructions that land inside the halo image
+  static constexpr int HALO_BYTES = HWI * 1024;
+  static constexpr int CST = CK / 16;                  // c-steps per chunk
+  static constexpr int TAPS = 9;
+  static constexpr int BST_BYTES = NB * CST * 1024;    // one (chunk, tap) stage of the filter
+  static constexpr int NFRAG = NB * CST;               // 1 KiB fragment blocks per stage, dealt to the 8 waves
+  static constexpr int NF = (NFRAG + 7) / 8;           // filter DMAs per wave and stage
+  static constexpr int D = RING - 1;                   // filter stages in flight
+  static constexpr int RS = CST % 2 == 0 ? 2 : 3;      // fragment register ring (CST % RS == 0: slot 0 starts every stage)
+  static constexpr int DUMP_BYTES = IT * 8 > HWI ? 1024 : 0;   // where the wave instructions past the image land
+  static constexpr size_t PIPE_BYTES = 2 * (size_t)HALO_BYTES + (size_t)RING * BST_BYTES + DUMP_BYTES;
+  static_assert(RING >= 4, "stage s reads ahead into stage s + 1: its filter must have landed one barrier earlier");
+
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const uint4* __restrict__ wfrag = a.wfrag;
+  const int ldx = a.ldx, Cin = a.Cin, H = a.H, W = a.W;
+  const int nb_total = a.nb_total, tiles_x = a.tiles_x, tiles_y = a.tiles_y;
+  SSA_DYN_LDS(unsigned char, smem);
+  unsigned char* Hs = smem;                                 // [2][HALO_BYTES]
+  unsigned char* Bs = smem + 2 * HALO_BYTES;                // [RING][BST_BYTES]
+  unsigned char* dump = Bs + RING * BST_BYTES;              // [DUMP_BYTES]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves
+  int bid = bx;
+  const int tx_i = bid % tiles_x; bid /= tiles_x;
+  const int ty_i = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int nb0 = by * NB;
+  const int x0 = tx_i * TW, y0 = ty_i * TH;
+  const int nchunk = Cin / CK;
+  const int csteps = Cin / 16;                  // c-steps per tap in the packed filter
+  const int ksteps = TAPS * csteps;
+
+  // Halo image in LDS: pixel-major, 128 bytes per pixel, the 16-byte piece q of pixel p in slot  q ^ ((p >> 1) & 7)
+  // -- written by DMA (a wave instruction fills 64 consecutive slots; WHICH piece of the chunk a lane fetches is
+  // free), read with ds_read_b128: the 16 lanes the LDS services together read the same q of 16 pixels with
+  // distinct p mod 16, i.e. 16 distinct slots of the 256-byte bank row.  A thread's IT pieces: source pointer and
+  // channel step per chunk; pieces outside the image or the chunk fetch a zero block (step 0).
+  const bf16_t* g_ptr[IT];
+  int g_step[IT];
+  const bf16_t* xb = x + (long)b * H * W * ldx;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int piece = tid + i * 512;
+    const int pix = piece >> 3, q = (piece & 7) ^ ((pix >> 1) & 7);
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    const int iy = y0 - R + hy, ix = x0 - R + hx;
+    const bool ok = piece < NPIECE && q < CP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    g_ptr[i] = ok ? xb + ((long)iy * W + ix) * ldx + q * 8 : reinterpret_cast<const bf16_t*>(&g_zero_piece);
+    g_step[i] = ok ? CK : 0;
+  }
+  auto halo_dma = [&](int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int wi = i * 8 + wave;              // this wave instruction's 1 KiB of the image (or the dump block)
+      ssa_glds16(g_ptr[i] + chunk * g_step[i], wi < HWI ? Hs + buf * HALO_BYTES + wi * 1024 : dump);
+    }
+  };
+  // filter stage (chunk c, tap t): NB x CST fragment blocks of 1 KiB dealt to the 8 waves.  Every wave issues NF
+  // DMAs: when NFRAG is not a multiple of 8 (CK = 48: 12 blocks) the waves without a block of their own fetch one
+  // another wave also fetches (same bytes to the same place) -- the stage-end wait needs the same count in every wave.
+  auto filt_stage = [&](int c, int t, int slot) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int fi = f * 8 + wave;
+      if (NFRAG % 8 != 0 && f == NF - 1 && fi >= NFRAG) fi -= 8;
+      const int nb = fi / CST, j = fi - nb * CST;
+      const int nbg = min(nb0 + nb, nb_total - 1);
+      const uint4* src = wfrag + ((long)nbg * ksteps + t * csteps + c * CST + j) * 64 + lane;
+      ssa_glds16(src, Bs + slot * BST_BYTES + fi * 1024);
+    }
+  };
+
+  // A fragment of this lane: output pixel (row wm * 2 + mi, column lane & 31) of the tile, k half lane >> 5
+  int a_pix[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) a_pix[mi] = (wm * 2 + mi) * HW_ + (lane & 31);
+  const int a_half = (lane >> 5) << 4;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // Fragment registers: a ring of RS c-steps that runs ACROSS the stage barriers -- the last c-step of a stage
+  // reads the first fragments of the next stage (its halo image and filter are visible since the previous barrier),
+  // so the MFMAs resume right behind the barrier instead of behind an LDS round trip of all eight waves at once.
+  bf16x8_t af[RS][2], bfr[RS][2];
+  auto rd = [&](const unsigned char* Hbuf, const int tap_off, const unsigned char* Bc, const int j, const int sl) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int p = a_pix[mi] + tap_off;
+      const int adr = (p << 7) | (((p << 3) & 0x70) ^ a_half);     // piece 2j + half of pixel p: slot ^ ((p >> 1) & 7)
+      af[sl][mi] = *reinterpret_cast<const bf16x8_t*>(Hbuf + (adr ^ (j << 5)));
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bfr[sl][ni] = *reinterpret_cast<const bf16x8_t*>(Bc + ((wn * 2 + ni) * CST + j) * 1024);
+  };
+
+  // Stage s = (chunk c, tap t) issues the filter DMAs of stage s + D (and at tap 0 the next chunk's halo) and ends in
+  //     s_waitcnt vmcnt(K) lgkmcnt(4) ; s_barrier
+  // K = number of DMAs this wave issued after those of stage s + 2: memory operations retire in order, so the
+  // operands of stage s + 2 have landed -- for every wave once all are through the barrier, i.e. stage s + 1 may
+  // read ahead into them.  Every wave has then also finished reading stage s (lgkmcnt(4): all LDS reads but the
+  // four read-ahead ones have returned), whose filter slot stage s + 1 hands to the DMAs of stage s + 1 + D.
+  const int last = nchunk - 1;
+  int slot = 0;                                 // filter ring slot of the current stage
+  halo_dma(0, 0);
+#pragma unroll
+  for (int q = 0; q < D; ++q) filt_stage(min(q / TAPS, last), q % TAPS, q);
+  ssa_wait_vm_barrier<0, 0>();
+  rd(Hs, 0, Bs + lane * 16, 0, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  for (int c = 0; c < nchunk; ++c) {
+    auto tap = [&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      constexpr int td = (t + D) % TAPS, cd_inc = (t + D) / TAPS;
+      int sd = slot + D; if (sd >= RING) sd -= RING;
+      int sn = slot + 1; if (sn >= RING) sn -= RING;
+      filt_stage(min(c + cd_inc, last), td, sd);
+      if (t == 0) halo_dma(min(c + 1, last), (c + 1) & 1);        // read from stage (c, 8)'s last c-step on
+      constexpr int tap_off = (t / 3) * HW_ + t % 3;
+      constexpr int tn = (t + 1) % TAPS, tap_off_n = (tn / 3) * HW_ + tn % 3;
+      const unsigned char* Hc = Hs + (c & 1) * HALO_BYTES;
+      const unsigned char* Hn = Hs + ((t + 1 == TAPS ? c + 1 : c) & 1) * HALO_BYTES;
+      const unsigned char* Bc = Bs + slot * BST_BYTES + lane * 16;
+      const unsigned char* Bn = Bs + sn * BST_BYTES + lane * 16;
+#pragma unroll
+      for (int j = 0; j < CST; ++j) {
+        if (j + 1 < CST) rd(Hc, tap_off, Bc, j + 1, (j + 1) % RS);
+        else rd(Hn, tap_off_n, Bn, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = ssa_mfma32(af[j % RS][mi], bfr[j % RS][ni], acc[mi][ni]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      ssa_wait_vm_barrier<(D - 2) * NF + (t < D - 1 ? IT : 0), 4>();
+      slot = sn;
+    };
+    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+    tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+    tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+  }
+  ssa_wait_vm_barrier<0, 0>();                  // the clamped prefetches of the last stages land before LDS is reused
+  HaloTile k = {bx, nb0, b, y0, x0, wm, wn};
+  halo_epilogue(a, k, acc, smem);
+  }
+};
+
+template <class K>
+int launch_halo(const ssa_conv_desc& d, size_t pipe, const void* x, const void* wfrag, const float* bias, void* y,
                 double* stats, hipStream_t s) {
-  constexpr int R = KS / 2;
-  constexpr size_t halo = ((size_t)(8 + 2 * R) * (32 + 2 * R) * (CK * 2 + 16) + 1023) / 1024 * 1024;
-  constexpr size_t bst = (size_t)4 * (CK / 16) * 1024;
   constexpr size_t stage = (size_t)256 * (128 + 8) * 2 + 4 * 2 * 128 * sizeof(float);
-  constexpr size_t pipe = 2 * halo + 2 * bst;
-  constexpr size_t lds = pipe > stage ? pipe : stage;
-  static_assert(lds <= 160 * 1024, "does not fit in LDS");
+  const size_t lds = pipe > stage ? pipe : stage;
   HaloArgs a;
   a.x = (const bf16_t*)x; a.wfrag = (const uint4*)wfrag; a.bias = bias; a.y = y; a.stats = stats;
   a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.out_f32 = d.out_f32; a.B = d.B; a.H = d.H; a.W = d.W;
   a.Cout = d.Cout; a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 7) / 8;
-  return ssa::submit<ConvHaloGemm<CK, KS>>(a, a.tiles_x * a.tiles_y * d.B, (a.nb_total + 3) / 4, lds, s);
+  return ssa::submit<K>(a, a.tiles_x * a.tiles_y * d.B, (a.nb_total + 3) / 4, lds, s);
+}
+
+template <int CK, int RING>
+int launch_halo3(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y, double* stats,
+                 hipStream_t s) {
+  typedef ConvHaloGemm3<CK, RING> K;
+  static_assert(K::PIPE_BYTES <= 160 * 1024, "does not fit in LDS");
+  return launch_halo<K>(d, K::PIPE_BYTES, x, wfrag, bias, y, stats, s);
+}
+
+template <int CK>
+int launch_halo1(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y, double* stats,
+                 hipStream_t s) {
+  constexpr size_t halo = ((size_t)8 * 32 * (CK * 2 + 16) + 1023) / 1024 * 1024;
+  constexpr size_t bst = (size_t)4 * (CK / 16) * 1024;
+  return launch_halo<ConvHaloGemm1<CK>>(d, 2 * halo + 2 * bst, x, wfrag, bias, y, stats, s);
 }
 
 int pick_ck(int Cin) {
@@ -296,11 +507,11 @@ int ssa_conv2d_halo(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   hipStream_t s = (hipStream_t)stream;
   const int ck = pick_ck(d.Cin);
   if (d.KH == 3) {
-    if (ck == 64) return launch_halo<64, 3>(d, x, w_frag, bias, y, stats, s);
-    return launch_halo<48, 3>(d, x, w_frag, bias, y, stats, s);
+    if (ck == 64) return launch_halo3<64, 4>(d, x, w_frag, bias, y, stats, s);
+    return launch_halo3<48, 4>(d, x, w_frag, bias, y, stats, s);
   }
-  if (ck == 64) return launch_halo<64, 1>(d, x, w_frag, bias, y, stats, s);
-  return launch_halo<48, 1>(d, x, w_frag, bias, y, stats, s);
+  if (ck == 64) return launch_halo1<64>(d, x, w_frag, bias, y, stats, s);
+  return launch_halo1<48>(d, x, w_frag, bias, y, stats, s);
 }
 
 }  // extern "C"

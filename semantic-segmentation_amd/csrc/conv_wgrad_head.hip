@@ -210,6 +210,164 @@ struct ConvWgradHead {
   }
 };
 
+__device__ uint4 g_zero_piece;      // 16 zero bytes: what a piece outside the image / the channel range fetches
+
+// 3x3 (one kernel row kh per workgroup): the same tiling with both operand images brought in by LDS DMA
+// (global_load_lds_dwordx4), double buffered by tile.  Round 2 moved every tile through registers -- 9 x 16-byte loads
+// per thread whose destination registers the compiler reused for address arithmetic (a wait for the first load
+// right in the issue sequence), then 9 ds_write_b128 between two barriers; measured on 720->512 @ 256x256
+// (tools/headbench.py, experiment builds): 569 us = 346 us of MFMA loop + 96 us staging + 127 us of exposed fetch,
+// nothing overlapping because all eight waves of the one resident workgroup are in the same phase.  A DMA needs no
+// registers and no store phase, and the next tile's images land while this tile's 48 MFMAs per wave run.
+//   * DMA fills 64 CONSECUTIVE 16-byte slots per wave instruction, so the images are unpadded (pixel-major, 256
+//     bytes per pixel) and the conflict-free layout the transposing reads need comes from a swizzle instead: the
+//     16-byte piece q of pixel p lies in slot  q ^ ((p & 3) << 2)  -- which piece a lane fetches is free.  The 32
+//     lanes ds_read_b64_tr_b16 services together read 4 consecutive pixels x one 64-byte channel block: with the
+//     swizzle the four pixels' blocks are the four different 64-byte windows of the 256-byte bank row.
+//   * pieces outside the image or the channel range fetch a zero block; every wave issues the same 9 DMAs per tile.
+struct ConvWgradHead3 {
+  typedef WgradHeadArgs Args;
+  static constexpr int NT = 512;
+  static constexpr int TW = 32, TH = 4, XW = TW + 2, CX = 128;
+  static constexpr int X_BYTES = TH * XW * 256, D_BYTES = TH * TW * 256, BUF_BYTES = X_BYTES + D_BYTES;
+  static constexpr int XWI = X_BYTES / 1024;           // 34 wave instructions fill the x image, 32 the dy image
+  static constexpr int XI = (XWI + 7) / 8, DI = D_BYTES / 1024 / 8, NI = XI + DI;   // DMAs per wave and tile: 5 + 4
+  static constexpr size_t LDS = 2 * (size_t)BUF_BYTES + 1024;                        // + the dump block
+  static __device__ __forceinline__ void run(const Args& a, const int bx_, const int by0_, const int /*gx*/) {
+  const int w_ = xcd_order(by0_ * a.G + bx_, a.G * a.wgs_y);
+  const int bx = w_ / a.wgs_y;
+  int by = w_ - bx * a.wgs_y;
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ dy = a.dy;
+  float* __restrict__ partial = a.partial;
+  const int ldx = a.ldx, Cin = a.Cin, lddy = a.lddy, cout_pad = a.cout_pad, B = a.B, H = a.H, W = a.W;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, tiles_per_wg = a.tiles_per_wg, ci_tiles = a.ci_tiles;
+  SSA_DYN_LDS(unsigned char, smem);
+  unsigned char* dump = smem + 2 * BUF_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int kh = by % 3; by /= 3;
+  const int ci_t = by % ci_tiles, co_t = by / ci_tiles;
+  const int co0 = co_t * 128, ci0 = ci_t * CX;
+  const int Kflat = 9 * Cin;
+
+  // ---- DMA role of this lane: piece (pixel p, slot) of wave instruction i * 8 + wave; the slot holds piece
+  // q = slot ^ ((p & 3) << 2) of the pixel.  rel: element offset from the tile's first pixel; yx: (row << 8 | col)
+  // inside the image window, 0xffff if the piece is never real (channel range / past the image)
+  int rel[NI], yx[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const bool isx = i < XI;
+    const int wi = (isx ? i : i - XI) * 8 + wave;
+    const int piece = wi * 64 + lane;
+    const int p = piece >> 4, q = (piece & 15) ^ ((p & 3) << 2);
+    const int r = isx ? p / XW : p >> 5, c = isx ? p - r * XW : p & 31;
+    const bool real = isx ? (wi < XWI && ci0 + q * 8 < Cin) : (co0 + q * 8 < cout_pad);
+    rel[i] = (r * W + c) * (isx ? ldx : lddy) + q * 8;
+    yx[i] = real ? ((r << 8) | c) : 0xffff;
+  }
+  // tile walk without divisions
+  int f_tx, f_ty, f_b;
+  const int total_tiles = B * tiles_x * tiles_y;
+  const int t_begin = bx * tiles_per_wg;
+  const int t_end = min(total_tiles, t_begin + tiles_per_wg);
+  {
+    f_tx = t_begin % tiles_x;
+    const int r_ = t_begin / tiles_x;
+    f_ty = r_ % tiles_y;
+    f_b = r_ / tiles_y;
+  }
+  auto dma = [&](int buf) {                    // both images of the tile (f_b, f_ty, f_tx) -> buffer buf; then advance
+    const int x0 = f_tx * TW, y0 = f_ty * TH;
+    const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 + kh - 1) * W + (x0 - 1)) * ldx + ci0;
+    const bf16_t* db = dy + ((long)f_b * H * W + (long)y0 * W + x0) * lddy + co0;
+    unsigned char* Xb = smem + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool isx = i < XI;
+      const int wi = (isx ? i : i - XI) * 8 + wave;
+      const int iy = (isx ? y0 + kh - 1 : y0) + (yx[i] >> 8), ix = (isx ? x0 - 1 : x0) + (yx[i] & 255);
+      const bool ok = yx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const bf16_t* src = ok ? (isx ? xb : db) + rel[i] : reinterpret_cast<const bf16_t*>(&g_zero_piece);
+      unsigned char* dst = isx ? (wi < XWI ? Xb + wi * 1024 : dump) : Xb + X_BYTES + wi * 1024;
+      ssa_glds16(src, dst);
+    }
+    if (++f_tx == tiles_x) {
+      f_tx = 0;
+      if (++f_ty == tiles_y) { f_ty = 0; ++f_b; }
+    }
+  };
+
+  // ---- fragment addresses (bytes inside a buffer): pixel row 8 * lh + lj (+ 4 for the upper half of the 8 pixels),
+  // 64-byte channel block  blk ^ (pixel & 3),  then 32 * lg + 8 * lq inside the block
+  const int li = lane & 15, lj = li >> 2, lq = li & 3, lg = (lane >> 4) & 1, lh = lane >> 5;
+  const int lrow = (8 * lh + lj) * 256 + lg * 32 + lq * 8;
+  int a_base[2], b_base[4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) a_base[m] = X_BYTES + lrow + (((wm * 2 + m) ^ lj) << 6);      // dy: 32 pixels per row
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b_base[r] = lrow + ((wn ^ ((lj + r) & 3)) << 6);              // x: pixel & 3 = (lj + r) & 3
+
+  f32x16_t acc[2][3];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+  if (t_begin < t_end) {
+    dma(0);
+    ssa_wait_vm_barrier<0, 0>();
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    if (t + 1 < t_end) dma(buf ^ 1);           // lands during this tile's MFMAs; the buffer was last read in tile t - 1
+    const unsigned char* Tb = smem + buf * BUF_BYTES;
+    // 16 pixels (half a tile row) per k-step; the fragments of k-step ks + 1 are read while the MFMAs of ks run
+    bf16x8_t af[2][2], bfr[2][3];
+    auto rd = [&](int ks, int slot) {
+      const int ty = ks >> 1, kp = (ks & 1) * 16;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) af[slot][m] = tr8(Tb + a_base[m] + (ty * TW + kp) * 256, 256);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bfr[slot][j] = tr8(Tb + b_base[(2 * ty + j) & 3] + (ty * XW + kp + j) * 256, 256);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          acc[m][j] = ssa_mfma32(af[ks & 1][m], bfr[ks & 1][j], acc[m][j]);
+      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+    ssa_wait_vm_barrier<0, 0>();               // the next tile has landed; everyone is done reading this one
+  }
+
+  float* out = partial + (long)bx * cout_pad * Kflat;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ci = ci0 + wn * 32 + (lane & 31);
+      if (ci >= Cin) continue;
+      const long kcol = (long)(kh * 3 + j) * Cin + ci;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[m][j][r];
+      }
+    }
+  }
+};
+
 bool head_shape_ok(const ssa_conv_desc* d, int cout_pad) {
   if (!d || d->KH != d->KW || (d->KH != 3 && d->KH != 1)) return false;
   if (d->stride != 1 || d->dil != 1 || d->pad != d->KH / 2 || d->transposed) return false;
@@ -236,6 +394,14 @@ HeadPlan head_plan(const ssa_conv_desc& d, int cout_pad) {
   return p;
 }
 
+void fill_args(WgradHeadArgs& a, const ssa_conv_desc& d, const HeadPlan& p, const void* x, const void* dy, int lddy,
+               int cout_pad, float* partial) {
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
+  a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = p.tpw; a.ci_tiles = p.ci_tiles;
+  a.G = p.G; a.wgs_y = p.wgs_y;
+}
+
 template <int KS>
 int launch_head(const ssa_conv_desc& d, const HeadPlan& p, const void* x, const void* dy, int lddy,
                 int cout_pad, float* partial, hipStream_t s) {
@@ -243,10 +409,7 @@ int launch_head(const ssa_conv_desc& d, const HeadPlan& p, const void* x, const 
   constexpr size_t lds = (size_t)4 * XW * trs(CX * 2) + (size_t)128 * trs(256);
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
   WgradHeadArgs a;
-  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
-  a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
-  a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = p.tpw; a.ci_tiles = p.ci_tiles;
-  a.G = p.G; a.wgs_y = p.wgs_y;
+  fill_args(a, d, p, x, dy, lddy, cout_pad, partial);
   return ssa::submit<ConvWgradHead<KS>>(a, p.G, p.wgs_y, lds, s);
 }
 
@@ -269,7 +432,11 @@ int ssa_conv2d_wgrad_head(const ssa_conv_desc* dp, const void* x, const void* dy
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) return SSA_EINVAL;
   const HeadPlan p = head_plan(*dp, cout_pad);
   if (nsplit != p.G) return SSA_EINVAL;
-  if (dp->KH == 3) return launch_head<3>(*dp, p, x, dy, lddy, cout_pad, partial, (hipStream_t)stream);
+  if (dp->KH == 3) {
+    WgradHeadArgs a;
+    fill_args(a, *dp, p, x, dy, lddy, cout_pad, partial);
+    return ssa::submit<ConvWgradHead3>(a, p.G, p.wgs_y, ConvWgradHead3::LDS, (hipStream_t)stream);
+  }
   return launch_head<1>(*dp, p, x, dy, lddy, cout_pad, partial, (hipStream_t)stream);
 }
 

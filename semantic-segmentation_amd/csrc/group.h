@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace ssa {
@@ -45,13 +46,18 @@ struct GroupTable {
   typename K::Args a[GroupLimits<K>::jobs];
 };
 
+// A kernel struct may declare  static constexpr int WPE  = waves per SIMD it must fit (second launch-bounds
+// parameter -> register budget 512 / WPE): two 8-wave workgroups per CU need WPE = 4, i.e. <= 128 registers.
+template <class K, class = void> struct WavesPerEu { static constexpr int value = 1; };
+template <class K> struct WavesPerEu<K, std::void_t<decltype(K::WPE)>> { static constexpr int value = K::WPE; };
+
 template <class K>
-__global__ __launch_bounds__(K::NT) void k_single(const typename K::Args a) {
+__global__ __launch_bounds__(K::NT, WavesPerEu<K>::value) void k_single(const typename K::Args a) {
   K::run(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 template <class K>
-__global__ __launch_bounds__(K::NT) void k_grouped(const GroupTable<K> t) {
+__global__ __launch_bounds__(K::NT, WavesPerEu<K>::value) void k_grouped(const GroupTable<K> t) {
   int j = 0;
 #pragma unroll 1
   while (j + 1 < t.n && (int)blockIdx.x >= t.end[j]) ++j;
