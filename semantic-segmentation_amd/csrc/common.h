@@ -22,6 +22,7 @@ __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return em
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
 __device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
 template <int VM, int LGKM = 0> __device__ __forceinline__ void ssa_wait_vm_barrier() { __syncthreads(); }
+__device__ __forceinline__ void ssa_glds16_untracked(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
 #else
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
@@ -36,6 +37,19 @@ __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) {
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+// The same DMA issued behind the compiler's back (inline assembly): the compiler's wait-count pass then knows nothing
+// of it.  For kernels that order their DMAs themselves with ssa_wait_vm_barrier<>: a tracked LDS DMA makes the pass
+// put  s_waitcnt vmcnt(0)  in front of every later ds_read_b64_tr_b16 (the transposing-read builtin counts as a
+// possible LDS writer) and in front of every use of a register-returning load -- i.e. it drains the DMA pipeline the
+// kernel is trying to keep full.  __syncthreads() does NOT wait for an untracked DMA.  Compiler-placed vmcnt waits for
+// its own loads stay correct: unknown operations in flight only make them wait longer.  M0 is written without the
+// compiler knowing (it rejects m0 as a clobber): a kernel uses EITHER this form OR ssa_glds16, never both -- the
+// compiler's own M0 uses on gfx950 are its LDS-DMA builtins only.
+__device__ __forceinline__ void ssa_glds16_untracked(const void* gsrc, void* lds_dst) {
+  const unsigned base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(base) : "memory");
 }
 // LDS written by some lanes of a wave, read by others of the SAME wave: the hardware runs a wave's LDS operations
 // in order, so only the compiler must not move the reads above the writes (the emulation runs lanes as

@@ -232,6 +232,7 @@ struct ConvWgradHead3 {
   static constexpr int X_BYTES = TH * XW * 256, D_BYTES = TH * TW * 256, BUF_BYTES = X_BYTES + D_BYTES;
   static constexpr int XWI = X_BYTES / 1024;           // 34 wave instructions fill the x image, 32 the dy image
   static constexpr int XI = (XWI + 7) / 8, DI = D_BYTES / 1024 / 8, NI = XI + DI;   // DMAs per wave and tile: 5 + 4
+  static_assert(NI == 9, "one DMA in front of the k loop and one behind each of its 8 steps");
   static constexpr size_t LDS = 2 * (size_t)BUF_BYTES + 1024;                        // + the dump block
   static __device__ __forceinline__ void run(const Args& a, const int bx_, const int by0_, const int /*gx*/) {
   const int w_ = xcd_order(by0_ * a.G + bx_, a.G * a.wgs_y);
@@ -279,21 +280,27 @@ struct ConvWgradHead3 {
     f_ty = r_ % tiles_y;
     f_b = r_ / tiles_y;
   }
-  auto dma = [&](int buf) {                    // both images of the tile (f_b, f_ty, f_tx) -> buffer buf; then advance
+  // the zero block's address, fetched once: left to itself the compiler reloads it from the GOT (s_load + a wait
+  // for lgkmcnt(0), i.e. for all fragment reads in flight) in front of every DMA inside the k loop
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(&g_zero_piece);
+#ifndef SSA_EMU
+  asm volatile("" : "+v"(zero_src));
+#endif
+  // DMA i (of NI) of the tile (f_b, f_ty, f_tx) -> buffer buf
+  auto dma = [&](int i, int buf) {
     const int x0 = f_tx * TW, y0 = f_ty * TH;
-    const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 + kh - 1) * W + (x0 - 1)) * ldx + ci0;
-    const bf16_t* db = dy + ((long)f_b * H * W + (long)y0 * W + x0) * lddy + co0;
+    const bool isx = i < XI;
+    const int wi = (isx ? i : i - XI) * 8 + wave;
+    const int oy = isx ? y0 + kh - 1 : y0, ox = isx ? x0 - 1 : x0;
+    const bf16_t* base = (isx ? x + ci0 : dy + co0) + ((long)f_b * H * W + (long)oy * W + ox) * (isx ? ldx : lddy);
+    const int iy = oy + (yx[i] >> 8), ix = ox + (yx[i] & 255);
+    const bool ok = yx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const bf16_t* src = ok ? base + rel[i] : zero_src;
     unsigned char* Xb = smem + buf * BUF_BYTES;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const bool isx = i < XI;
-      const int wi = (isx ? i : i - XI) * 8 + wave;
-      const int iy = (isx ? y0 + kh - 1 : y0) + (yx[i] >> 8), ix = (isx ? x0 - 1 : x0) + (yx[i] & 255);
-      const bool ok = yx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const bf16_t* src = ok ? (isx ? xb : db) + rel[i] : reinterpret_cast<const bf16_t*>(&g_zero_piece);
-      unsigned char* dst = isx ? (wi < XWI ? Xb + wi * 1024 : dump) : Xb + X_BYTES + wi * 1024;
-      ssa_glds16(src, dst);
-    }
+    unsigned char* dst = isx ? (wi < XWI ? Xb + wi * 1024 : dump) : Xb + X_BYTES + wi * 1024;
+    ssa_glds16_untracked(src, dst);
+  };
+  auto next_tile = [&]() {
     if (++f_tx == tiles_x) {
       f_tx = 0;
       if (++f_ty == tiles_y) { f_ty = 0; ++f_b; }
@@ -319,12 +326,18 @@ struct ConvWgradHead3 {
       for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
 
   if (t_begin < t_end) {
-    dma(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dma(i, 0);
+    next_tile();
     ssa_wait_vm_barrier<0, 0>();
   }
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
-    if (t + 1 < t_end) dma(buf ^ 1);           // lands during this tile's MFMAs; the buffer was last read in tile t - 1
+    // the next tile's DMAs (into the buffer last read in tile t - 1) are issued one per k-step BEHIND that k-step's
+    // MFMAs: an LDS DMA costs its wave 60..185 clocks of issue, which the six queued MFMAs (192 clocks) cover --
+    // nine of them in front of the loop were 0.5 us per tile during which the SIMD had no MFMA to run
+    const bool more = t + 1 < t_end;
+    if (more) dma(0, buf ^ 1);
     const unsigned char* Tb = smem + buf * BUF_BYTES;
     // 16 pixels (half a tile row) per k-step; the fragments of k-step ks + 1 are read while the MFMAs of ks run
     bf16x8_t af[2][2], bfr[2][3];
@@ -345,9 +358,12 @@ struct ConvWgradHead3 {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           acc[m][j] = ssa_mfma32(af[ks & 1][m], bfr[ks & 1][j], acc[m][j]);
+      if (more) dma(ks + 1, buf ^ 1);
       if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
+    if (more) next_tile();
     ssa_wait_vm_barrier<0, 0>();               // the next tile has landed; everyone is done reading this one
   }
 

@@ -90,6 +90,44 @@ __global__ __launch_bounds__(NT) void pixel_loss_kernel(const float* __restrict_
   block_acc2(lsum, lcnt, acc);
 }
 
+// Masked sigmoid BCE, dense logits: nothing couples the classes of a pixel, so the tile kernel's stage-in / per-pixel
+// pass / stage-out with three barriers is not needed -- every thread streams four consecutive elements (a float4,
+// possibly across a pixel boundary) and the label of their pixel(s).  The tile kernel spends its time in two expf, a
+// log1pf and a division per element (library routines of 20-40 instructions each: 102 us at 1024x1024x19, no faster
+// when merely streamed); here ONE exponential  e = exp(-|v|)  serves both terms,
+//     log(1 + exp(-|v|)) = log(1 + e)         sigmoid(v) = v >= 0 ? 1 / (1 + e) : e / (1 + e)
+// with the hardware exp2 / log2 / rcp (1 ulp-class; the loss changes in the 7th digit, tests/test_kernels_gpu.py's
+// tolerance for this op is 1e-4).  fp32 partial sum per float4, fp64 across them.
+__global__ __launch_bounds__(NT) void bce_stream_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                        unsigned n4, int C, double* __restrict__ acc,
+                                                        float* __restrict__ dlogits) {
+  double lsum = 0.0, lcnt = 0.0;
+  for (unsigned g = blockIdx.x * NT + threadIdx.x; g < n4; g += gridDim.x * NT) {
+    const float4 v4 = reinterpret_cast<const float4*>(logits)[g];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float d[4];
+    unsigned pix = (g * 4u) / (unsigned)C;
+    int c = (int)(g * 4u - pix * (unsigned)C);
+    long lab = labels[pix];
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c == C) { c = 0; ++pix; lab = labels[pix]; }
+      const bool valid = lab >= 0 && lab < C;
+      const float t = (c == lab) ? 1.f : 0.f;
+      const float e = __expf(-fabsf(v[k]));
+      const float r = __frcp_rn(1.f + e);
+      const float s = fmaxf(v[k], 0.f) - v[k] * t + __logf(1.f + e);
+      if (valid) { part += s; if (c == 0) lcnt += 1.0; }
+      d[k] = valid ? ((v[k] >= 0.f ? r : e * r) - t) : 0.f;
+      ++c;
+    }
+    lsum += (double)part;
+    if (dlogits) reinterpret_cast<float4*>(dlogits)[g] = make_float4(d[0], d[1], d[2], d[3]);
+  }
+  block_acc2(lsum, lcnt, acc);
+}
+
 __global__ void loss_finalize_kernel(const double* __restrict__ acc, double denom_add,
                                      float* __restrict__ loss) {
   loss[0] = (float)(acc[0] / (acc[1] + denom_add));
@@ -434,6 +472,14 @@ int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int 
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
+  const long n = P * C;
+  if (ld == C && n % 4 == 0 && n < (1L << 31) && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15u) == 0) {
+    // 1024 blocks = 4 per CU: every block ends in two fp64 atomics on the same two addresses, which serialise
+    hipLaunchKernelGGL(bce_stream_kernel, dim3(grid_for(n / 4, 1024)), dim3(NT), 0, s, logits, labels, (unsigned)(n / 4), C,
+                       acc, dlogits);
+    SSA_LAUNCH_CHECK();
+    return SSA_OK;
+  }
   {   // the [NT][C] fp32 tile exceeds the default 64 KB of dynamic LDS from 65 classes (Mapillary) on
     static size_t allowed = 64 * 1024;
     const size_t need = (size_t)NT * C * sizeof(float);

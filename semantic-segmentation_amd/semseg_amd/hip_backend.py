@@ -1592,6 +1592,69 @@ class BilinearGroupFn(torch.autograd.Function):
         return tuple(dxs)
 
 
+class UpsampleCatGroupFn(torch.autograd.Function):
+    """For each group g: cat([y0, up(y1), up(y2), ...], channels) with up = bilinear resize to y0's size
+    (align_corners=False).  The resize kernel writes straight into its channel slice of the concatenated buffer
+    (output leading dimension = total channels; y0 goes through the same kernel at scale 1, an exact copy) -- no
+    upsampled temporaries, no torch.cat pass over the 720-channel tensor (0.25 ms per step at 1024x1024).  Backward:
+    the resize's transposed kernel reads its slice of the incoming gradient in place; y0's gradient IS its slice."""
+
+    @staticmethod
+    def forward(ctx, counts, *xs):
+        outs, meta, k = [], [], 0
+        prep = [_pixels(x) for x in xs]
+        with group():
+            for n in counts:
+                g = prep[k:k + n]
+                B, Ho, Wo, _ = g[0][0].shape
+                Ct = sum(x.shape[3] for x, _ in g)
+                assert all(x.dtype == ACT_DTYPE for x, _ in g)
+                y = torch.empty((B, Ho, Wo, Ct), dtype=ACT_DTYPE, device=g[0][0].device)
+                off = 0
+                for x, ldx in g:
+                    _, Hi, Wi, C = x.shape
+                    assert off % 8 == 0, "channel slices must stay 16-byte aligned"
+                    check(lib().ssa_bilinear_fwd(_p(x), _dt(x), B, Hi, Wi, C, ldx, ctypes.c_void_p(y.data_ptr() + 2 * off),
+                                                 _dt(y), Ho, Wo, Ct, _s()), "ssa_bilinear_fwd")
+                    meta.append((B, Hi, Wi, C, Ho, Wo, off, Ct))
+                    off += C
+                outs.append(y)
+                k += n
+        ctx.counts, ctx.meta = counts, meta
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        dxs, k = [None], 0
+        prep = []
+        for dy in dys:
+            if dy is None:
+                prep.append(None)
+                continue
+            dy = dy if dy.dtype == ACT_DTYPE else dy.to(ACT_DTYPE)
+            dy, lddy = _pixels(dy)
+            if lddy % 8 or dy.data_ptr() % 16:
+                dy, lddy = dy.contiguous(), dy.shape[3]
+            prep.append((dy, lddy))
+        with group():
+            for gi, n in enumerate(ctx.counts):
+                for j in range(n):
+                    B, Hi, Wi, C, Ho, Wo, off, Ct = ctx.meta[k + j]
+                    if prep[gi] is None:
+                        dxs.append(None)
+                        continue
+                    dy, lddy = prep[gi]
+                    if j == 0 and (Hi, Wi) == (Ho, Wo):
+                        dxs.append(dy[..., off:off + C])      # identity resize: the gradient is the slice itself
+                        continue
+                    dx = torch.empty((B, Hi, Wi, C), dtype=ACT_DTYPE, device=dy.device)
+                    check(lib().ssa_bilinear_bwd(ctypes.c_void_p(dy.data_ptr() + 2 * off), _dt(dy), B, Ho, Wo, C, lddy,
+                                                 _p(dx), _dt(dx), Hi, Wi, C, _s()), "ssa_bilinear_bwd")
+                    dxs.append(dx)
+                k += n
+        return tuple(dxs)
+
+
 class BilinearFn:
     @staticmethod
     def apply(x, Ho, Wo, out_f32):

@@ -317,12 +317,7 @@ class HighResolutionNet(nn.Module):
         ys = self._run_stage(self.stage2, self._apply_transition(self.transition1, ys, 1))
         ys = self._run_stage(self.stage3, self._apply_transition(self.transition2, ys, self.stage2_cfg["NUM_BRANCHES"]))
         ys = self._run_stage(self.stage4, self._apply_transition(self.transition3, ys, self.stage3_cfg["NUM_BRANCHES"]))
-        P = len(xs)
-        sizes = [tuple(ys[0][p].shape[1:3]) for p in range(P)]
-        low = [(i, p) for i in range(1, len(ys)) for p in range(P)]
-        ups = B.bilinear([ys[i][p] for i, p in low], [sizes[p] for i, p in low]) if low else []
-        up = dict(zip(low, ups))
-        feats = [B.cat([ys[0][p]] + [up[(i, p)] for i in range(1, len(ys))]) for p in range(P)]
+        feats = B.upsample_cat([[ys[i][p] for i in range(len(ys))] for p in range(len(xs))])
         return None, None, (feats if multi else feats[0])
 
     def init_weights(self, pretrained=None):

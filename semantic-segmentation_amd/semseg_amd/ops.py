@@ -74,6 +74,15 @@ class BackendBase:
         sizes = size if _is_list(size[0]) or hasattr(size[0], "__len__") else [size] * len(x)
         return [self._bilinear(xi, s, out_f32) for xi, s in zip(x, sizes)]
 
+    def upsample_cat(self, groups):
+        """groups[p] = [y0, y1, ...] (NHWC): y1.. resized to y0's size (bilinear, align_corners=False) and all of them
+        concatenated on channels -- the head input of HighResolutionNet.forward (network/hrnetv2.py:418-431)."""
+        sizes = [tuple(g[0].shape[1:3]) for g in groups]
+        low = [(p, i) for p, g in enumerate(groups) for i in range(1, len(g))]
+        ups = self.bilinear([groups[p][i] for p, i in low], [sizes[p] for p, i in low]) if low else []
+        up = dict(zip(low, ups))
+        return [self.cat([g[0]] + [up[(p, i)] for i in range(1, len(g))]) for p, g in enumerate(groups)]
+
     def fan_out(self, tensors, counts):
         """tensors[i] is about to be consumed counts[i] times: returns counts[i] handles per tensor (the
         HIP backend sums their gradients with one grouped launch instead of autograd's adds)."""
@@ -219,6 +228,10 @@ class HipBackend(BackendBase):
             for i, y in zip(todo, ys):
                 outs[i] = y
         return outs if multi else outs[0]
+
+    def upsample_cat(self, groups):
+        counts = tuple(len(g) for g in groups)
+        return list(self.hb.UpsampleCatGroupFn.apply(counts, *[t for g in groups for t in g]))
 
     def max_pool3x3s2(self, x):
         return self.hb.MaxPool3x3s2Fn.apply(x)

@@ -373,3 +373,33 @@ def test_hr_module_lockstep_against_oracle():
         if cos < 0.98 or not 0.9 < ratio < 1.1:       # a wrong kernel / wiring gives cos ~ 0 for what it touches
             bad.append((n, cos, ratio))
     assert not bad, bad[:8]
+
+
+def test_upsample_cat_equals_resize_then_cat():
+    """UpsampleCatGroupFn (the resize kernel writes into its channel slice of the concatenated buffer) == BilinearGroupFn
+    followed by torch.cat, bit for bit, forward and backward -- two groups of different size (the scale passes)."""
+    hb = _hb()
+    shapes = [[(48, 32, 24), (96, 16, 12), (192, 8, 6), (384, 4, 3)], [(48, 16, 12), (96, 8, 6), (192, 4, 3), (384, 2, 2)]]
+    xs = [[_dev(_rand(1, C, H, W, seed=900 + 10 * g + i)) for i, (C, H, W) in enumerate(grp)] for g, grp in enumerate(shapes)]
+    gys = [_dev(_rand(1, 720, grp[0][1], grp[0][2], seed=950 + g)) for g, grp in enumerate(shapes)]
+
+    def run(fused):
+        leaves = [[x.clone().requires_grad_(True) for x in grp] for grp in xs]
+        if fused:
+            outs = hb.UpsampleCatGroupFn.apply(tuple(len(g) for g in leaves), *[t for g in leaves for t in g])
+        else:
+            outs = []
+            for grp in leaves:
+                size = tuple(grp[0].shape[1:3])
+                ups = hb.BilinearGroupFn.apply(tuple((size[0], size[1], False) for _ in grp[1:]), *grp[1:])
+                outs.append(torch.cat([grp[0]] + list(ups), dim=3))
+        torch.autograd.backward(list(outs), gys)
+        return [o.detach() for o in outs], [[t.grad for t in grp] for grp in leaves]
+
+    o_f, g_f = run(True)
+    o_r, g_r = run(False)
+    for a, b in zip(o_f, o_r):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for ga, gb in zip(g_f, g_r):
+        for a, b in zip(ga, gb):
+            assert torch.equal(a.contiguous(), b.contiguous())

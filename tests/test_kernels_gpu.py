@@ -572,9 +572,10 @@ def test_ocr_attention():
 
 
 # ----------------------------------------------------------------- fusion
-def test_scale_fusion_ops():
+@pytest.mark.parametrize("shape", [(2, 16, 20, 19), (1, 5, 7, 19), (1, 9, 30, 3), (1, 4, 70, 65)])
+def test_scale_fusion_ops(shape):
     hb = _hb()
-    B, H, W, C = 2, 16, 20, 19
+    B, H, W, C = shape      # ragged last block of the 256-pixel tile kernel; 65 classes: the wave-per-pixel kernel
     a = torch.rand(B, H, W, 1)
     lo = torch.randn(B, H, W, C)
     hi = torch.randn(B, H, W, C)

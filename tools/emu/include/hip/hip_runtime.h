@@ -108,6 +108,7 @@ static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v
 static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 static inline float rsqrtf(float x) { return 1.f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.f / a; }
 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
