@@ -431,10 +431,14 @@ class _GradArena:
         self.armed = False
         try:
             flush_wgrads()
+            _SINCE_REDUCE[0] = 0
+            if _GRAD_SINK[0] is not None and self.slots:
+                with _on_wgrad_stream():
+                    self.reduce_completed()
+            join_wgrads()
             if not self.slots:
                 return
             if _GRAD_SINK[0] is not None:
-                self.reduce_completed()
                 _GRAD_SINK[0].finish()
             dst, src = [], []
             for p, v, _, _ in self.slots.values():
@@ -720,7 +724,11 @@ _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel sta
 # queued layers that trigger a flush before the end of backward.  Measured (profiles/r02_notes.md, call X): 48 / 96 /
 # 192 / end-of-backward-only = 31.0 / 30.0 / 29.4 / 29.1 ms per step -- the more layers a flush carries, the better its
 # persistent-workgroup launches fill the chip; the queued (x, dy) pairs of a 1024x1024 step are a few GB of 288.
-_WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "100000"))
+# On their own stream (below) the flushes overlap the rest of backward instead of delaying it, and early flushes are
+# what gives the side stream something to run.  Measured (profiles/r03_notes.md, call S): stream off 23.30 ms; on with a
+# flush every 16 / 32 / 64 / 128 / 256 layers / at the end only = 23.93 / 23.39 / 23.11 / 22.94 / 22.75 / 23.32 ms.
+_WGRAD_SIDE = os.environ.get("SSA_WGRAD_STREAM", "1") != "0"
+_WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "256" if _WGRAD_SIDE else "100000"))
 # ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
 # range while backward goes on (a step queues ~640 layers: three exchanges, the last one short)
 _DDP_FLUSH_AT = int(os.environ.get("SSA_DDP_FLUSH_AT", "256"))
@@ -806,14 +814,58 @@ def _run_wgrad_jobs(jobs, strip):
                   "ssa_conv2d_wgrad_reduce")
 
 
-def flush_wgrads():
+# Weight gradients on a stream of their own.  Nothing in backward waits for a weight gradient (they end in the
+# gradient arena, read by the optimizer / the gradient exchange), while the chain that backward does wait for --
+# BatchNorm reduce -> apply -> data gradient, level after level -- is made of 10-30 us launches that fill a fraction of
+# the chip.  Flushed every SSA_WGRAD_FLUSH_AT layers onto a side stream (a parallel branch of the captured step,
+# joined before the gradients are published), the 6 ms of weight-gradient kernels run in the chain's shadow.
+_SIDE = {"stream": None, "pending": False}
+_SINCE_REDUCE = [0]        # layers flushed since the gradient sink was last handed a range
+
+
+def _side_stream():
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+@contextlib.contextmanager
+def _on_wgrad_stream():
+    """Work that must be ordered behind the weight gradients issued so far (the gradient exchange of their range)."""
+    if _SIDE["pending"]:
+        with torch.cuda.stream(_SIDE["stream"]):
+            yield
+    else:
+        yield
+
+
+def join_wgrads():
+    """The current stream waits for the weight gradients issued so far."""
+    if _SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+
+
+def flush_wgrads(join=False):
     """Issue the queued weight gradients (grouped) -- at the end of backward, when enough layers
-    are queued, and before anything reads a gradient slice."""
-    if not _WGRAD_Q:
-        return
-    jobs = list(_WGRAD_Q)
-    del _WGRAD_Q[:]
-    _run_wgrad_jobs(jobs, _WGRAD_STRIP)
+    are queued, and (join=True) before anything reads a gradient slice."""
+    if _WGRAD_Q:
+        jobs = list(_WGRAD_Q)
+        del _WGRAD_Q[:]
+        if _WGRAD_SIDE and jobs[0].x.is_cuda:
+            side = _side_stream()
+            side.wait_stream(torch.cuda.current_stream())     # every operand has been produced
+            with torch.cuda.stream(side):
+                _run_wgrad_jobs(jobs, _WGRAD_STRIP)
+            for j in jobs:                                    # their memory must not be recycled under the side stream
+                for t in (j.x, j.dy, j.xf, j.x2):
+                    if t is not None:
+                        t.record_stream(side)
+            _SIDE["pending"] = True
+        else:
+            _run_wgrad_jobs(jobs, _WGRAD_STRIP)
+    if join:
+        join_wgrads()
 
 
 def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, weight=None,
@@ -828,11 +880,15 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
         return j
     if weight is not None and _is_param(weight):
         _WGRAD_Q.append(job(_GRADS.slot(weight), True))
-        if len(_WGRAD_Q) >= _WGRAD_FLUSH_AT:
+        n = len(_WGRAD_Q)
+        exchange = _GRAD_SINK[0] is not None and n + _SINCE_REDUCE[0] >= _DDP_FLUSH_AT
+        if n >= _WGRAD_FLUSH_AT or exchange:
             flush_wgrads()
-        elif _GRAD_SINK[0] is not None and len(_WGRAD_Q) >= _DDP_FLUSH_AT:
-            flush_wgrads()
-            _GRADS.reduce_completed()
+            _SINCE_REDUCE[0] += n
+            if exchange:
+                with _on_wgrad_stream():
+                    _GRADS.reduce_completed()
+                _SINCE_REDUCE[0] = 0
         return None
     dw = torch.empty((Cout, Cin_real, k[0], k[1]), dtype=torch.float32, device=x.device)
     _run_wgrad_jobs([job(dw, False)], -1)

@@ -202,7 +202,7 @@ class HipBackend(BackendBase):
 
     def flush_backward(self):
         """Deferred backward work whose results another end-of-backward callback is about to read."""
-        self.hb.flush_wgrads()
+        self.hb.flush_wgrads(join=True)
 
     def sum_act(self, tensors, relu=True):
         multi = bool(tensors) and _is_list(tensors[0])

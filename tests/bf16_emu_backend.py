@@ -111,5 +111,21 @@ def traced(backend, sink):
 
     for name in TRACED:
         setattr(Traced, name, mk(name))
+    from semseg_amd.ops import BackendBase
+    if type(backend).upsample_cat is not BackendBase.upsample_cat:
+        # a backend with a fused resize + concatenate reports the resized slices of its output where the others
+        # report the outputs of their bilinear() call: same tensors, same order
+        fused = type(backend).upsample_cat
+
+        def upsample_cat(self, groups):
+            ys = fused(self, groups)
+            for g, y in zip(groups, ys):
+                off = g[0].shape[3]
+                for t in g[1:]:
+                    sink(counter[0], "bilinear", y[..., off:off + t.shape[3]])
+                    counter[0] += 1
+                    off += t.shape[3]
+            return ys
+        Traced.upsample_cat = upsample_cat
     backend.__class__ = Traced
     return backend

@@ -153,7 +153,7 @@ def test_train_step(setup):
     from bf16_emu_backend import Bf16EmuBackend
     sd, images, gts = setup
     lr, gr, sr = _run(OracleBackend(), sd, images, gts, True)
-    le, ge, _ = _run(Bf16EmuBackend(), sd, images, gts, True)
+    le, ge, se = _run(Bf16EmuBackend(), sd, images, gts, True)
     lh, gh, sh = _run(ops.HipBackend(), sd, images, gts, True, device="cuda")
     print("train loss hip %.6f emu %.6f oracle %.6f" % (lh, le, lr))
     assert abs(lh - lr) <= 2e-3 * abs(lr) + 2 * abs(le - lr)
@@ -178,9 +178,15 @@ def test_train_step(setup):
     assert not bad, bad[:5]
     assert vh[len(vh) // 2] >= ve[len(ve) // 2] - 0.05
     assert vh[len(vh) // 10] >= ve[len(ve) // 10] - 0.05
-    worst = max(float((sh[k] - sr[k]).abs().max() / (sr[k].abs().max() + 1e-12)) for k in sr)
-    print("running stats worst rel %.4g" % worst)
-    assert worst < 3e-2
+    # running statistics: 3 % of the largest entry, or twice what bf16 STORAGE alone does to the same statistic (the
+    # object-context BatchNorms see 2 x 19 region vectors per channel: their variance moves 2.3 % under the CPU bf16
+    # emulation, 1.7-3.8 % on the device depending on the kernel versions -- the same statistic tops both lists)
+    rel = {k: float((sh[k] - sr[k]).abs().max() / (sr[k].abs().max() + 1e-12)) for k in sr}
+    rel_e = {k: float((se[k] - sr[k]).abs().max() / (sr[k].abs().max() + 1e-12)) for k in sr}
+    top = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+    print("running stats worst rel %.4g (emu %.4g); the five worst: %s" % (top[0][1], max(rel_e.values()), [(k, round(v, 4), round(rel_e[k], 4)) for k, v in top]))
+    over = [(k, v, rel_e[k]) for k, v in rel.items() if v > max(3e-2, 2.0 * rel_e[k])]
+    assert not over, over[:5]
 
 
 def test_eval_nscale(setup):
