@@ -83,7 +83,8 @@ def test_teacher_forced_ops_at_1024():
     assert n_fwd > 100 and bwd_cmp > 1500
     if CROP >= 1024:
         fams = {n.split("<")[0] for n in names}
-        for f in ("ConvHaloGemm", "ConvWgradHead", "ConvTile", "ConvWgradTile", "ConvIgemm", "ConvWgradTr"):
+        for f in ("ConvHaloGemm3", "ConvHaloGemm1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile", "ConvIgemm",
+                  "ConvWgradTr"):
             assert f in fams, "dispatch class %s is not on the traced path" % f
         # the trunk levels' 3x3 convs: the 48-channel and the 96-channel-chunk instantiation behind one kernel,
         # forward (plain) and data gradient (fused epilogues)

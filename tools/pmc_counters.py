@@ -35,7 +35,9 @@ def inst(name):
 
 def family(i):
     f = re.sub(r"<.*", "", i)
-    return "ConvTile" if f in ("ConvTileAny", "ConvTilePAny", "ConvTileP") else f
+    if f in ("ConvTileAny", "ConvTilePAny", "ConvTileP"):
+        return "ConvTile"
+    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead"}.get(f, f)
 
 
 def main():
