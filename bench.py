@@ -413,6 +413,9 @@ def main():
                        "eager_ms_per_step": eager_ms,
                        "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)",
                        "library_launches_per_step": launches_per_step,
+                       # deferred weight gradients: flushed every N layers onto a side stream (a parallel branch of
+                       # the captured step); None = on the compute stream at the end of backward
+                       "wgrad_side_stream_flush_at": hb._WGRAD_FLUSH_AT if hb._WGRAD_SIDE else None,
                        "collectives_per_step": collectives_per_step,
                        # gradient exchange: ranges of the arena are all-reduced on a communication stream while backward
                        # runs; what no compute can hide is the LAST range -- estimate = its bytes x 2 (ring all-reduce
