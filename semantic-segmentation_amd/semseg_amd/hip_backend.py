@@ -544,7 +544,12 @@ _TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "500"))      # most workgroup
 # the critical path of latency-bound kernels (+5 us per conv2 launch, +15 us per conv1 data gradient, +0.6 ms in the
 # weight-gradient kernels) and the two coefficient launches per level cost 0.4 ms: 26.6 ms per step against 25.8 ms
 # with the BatchNorm passes materialised.  Kept, tested, off.
-_BLOCK_FOLD = os.environ.get("SSA_BLOCK_FOLD", "0") != "0"
+_BLOCK_FOLD = os.environ.get("SSA_BLOCK_FOLD", "0")      # "0" off, "1" forward and backward, "2" forward only (tests set bools)
+
+
+def _fold_mode():
+    v = _BLOCK_FOLD
+    return 2 if str(v) == "2" else (1 if v not in ("0", "", 0, False, None) else 0)
 
 
 def tile_p_supported(d):
@@ -1278,7 +1283,7 @@ def _block_descs(x_shape, w):
 def _block_fold_ok(x, ldx, w1, w2):
     """True if bn1 of this residual block can be folded into the neighbouring conv kernels: both convs, their data
     gradients and their weight gradients run on the halo-staged kernels that compute the folded operand."""
-    if not (_BLOCK_FOLD and _TILE_P and _WGRAD_TILE):
+    if not (_fold_mode() and _TILE_P and _WGRAD_TILE):
         return False
     C = w1.shape[0]
     if tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3) or C not in (48, 96, 192, 384):
@@ -1306,6 +1311,8 @@ class BasicBlockGroupFn(torch.autograd.Function):
              weight-gradient kernels recompute bn1's output / input gradient while they stage their operands.
     Unfolded form: conv1+stats, bn1, conv2+stats, bn2+add+relu forward; bn2 reduce, bn2 apply, conv2 data gradient
     (+ bn1 sums), bn1 apply, conv1 data gradient (+ g) backward.
+    SSA_BLOCK_FOLD=2: the folded FORWARD with the unfolded backward (which never needed bn1's output: its ReLU mask is
+    recomputed from bn1's input) -- only conv2's weight gradient recomputes bn1 + ReLU while it stages its operand.
     metas[i] = (BnMeta bn1, BnMeta bn2); tensors = (x, w1, g1, b1, w2, g2, b2) per problem."""
 
     @staticmethod
@@ -1320,6 +1327,7 @@ class BasicBlockGroupFn(torch.autograd.Function):
             ldxs.append(ldx)
         f32 = lambda t: t.detach().float()
         fold = all(_block_fold_ok(xs[i], ldxs[i], T[i][1], T[i][4]) for i in range(n))
+        fold_bwd = fold and _fold_mode() == 1
         descs = [_block_descs(tuple(xs[i].shape), T[i][1])[0] for i in range(n)]
         y1s = []
         with tile_strip(descs), group():
@@ -1370,14 +1378,14 @@ class BasicBlockGroupFn(torch.autograd.Function):
         for i in range(n):
             saved += [xs[i], y1s[i], a1s[i], y2s[i], outs[i], coef1[i], coef2[i], T[i][1], T[i][4], f32(T[i][2]), f32(T[i][5])]
         ctx.save_for_backward(*saved)
-        ctx.info = (ldxs, cnt1, wd1, cnt2, wd2, fold)
+        ctx.info = (ldxs, cnt1, wd1, cnt2, wd2, fold, fold_bwd)
         ctx.params = [(T[i][2], T[i][3], T[i][5], T[i][6]) for i in range(n)]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
         L = lib()
-        ldxs, cnt1, wd1, cnt2, wd2, fold = ctx.info
+        ldxs, cnt1, wd1, cnt2, wd2, fold_fwd, fold = ctx.info
         n = len(ldxs)
         S = [ctx.saved_tensors[11 * i:11 * i + 11] for i in range(n)]
         act = [i for i in range(n) if douts[i] is not None]
@@ -1487,14 +1495,16 @@ class BasicBlockGroupFn(torch.autograd.Function):
             x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
             dy2 = r2[k][0]
             C2, C1 = y2.shape[3], y1.shape[3]
-            if fold:
+            if fold_fwd:       # bn1's output was never written: the weight-gradient kernel recomputes it from y1
                 dw2 = _wgrad(y1, C1, tuple(y1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
                              w2.shape[0], w2.shape[1], weight=w2, xf_mode=1, xf=c1)
-                dw1 = _wgrad(x, ldxs[i], tuple(x.shape), da1[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
-                             w1.shape[0], w1.shape[1], weight=w1, xf_mode=2, xf=xf5[i], x2=y1, ldx2=C1)
             else:
                 dw2 = _wgrad(a1, a1.shape[3], tuple(a1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
                              w2.shape[0], w2.shape[1], weight=w2)
+            if fold:
+                dw1 = _wgrad(x, ldxs[i], tuple(x.shape), da1[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
+                             w1.shape[0], w1.shape[1], weight=w1, xf_mode=2, xf=xf5[i], x2=y1, ldx2=C1)
+            else:
                 dw1 = _wgrad(x, ldxs[i], tuple(x.shape), dy1s[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
                              w1.shape[0], w1.shape[1], weight=w1)
             base = 1 + 7 * i

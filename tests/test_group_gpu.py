@@ -225,8 +225,10 @@ def test_basic_block_group_equals_the_unfused_composition():
         check_close("param grad fused vs unfused", a, b, 2e-3, 5e-4)
 
 
-def test_folded_block_equals_the_unfolded_block():
-    """BasicBlockGroupFn with bn1 folded into conv2's operand staging, conv1's data gradient and both weight
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_folded_block_equals_the_unfolded_block(mode):
+    """(mode 2 = forward fold only: the data gradients are then the unfolded path's, bit for bit.)
+    BasicBlockGroupFn with bn1 folded into conv2's operand staging, conv1's data gradient and both weight
     gradients (csrc/conv_tile_p.hip, conv_wgrad_tile.hip XF variants) against the same node with the BatchNorm
     passes materialised (SSA_BLOCK_FOLD=0 path): same kernels otherwise, same inputs.  The forward is bit-identical
     (the staging transform is bn_apply's arithmetic); the backward differs by the regrouping
@@ -236,7 +238,7 @@ def test_folded_block_equals_the_unfolded_block():
     be = ops.HipBackend()
     level = [(48, 12, 72), (96, 9, 40), (192, 8, 34), (384, 6, 32)]
     res = []
-    for fold in (True, False):
+    for fold in (mode, "0"):
         saved = hb._BLOCK_FOLD
         hb._BLOCK_FOLD = fold
         try:
@@ -268,6 +270,8 @@ def test_folded_block_equals_the_unfolded_block():
     for (m0, v0), (m1, v1) in zip(rs0, rs1):
         assert torch.equal(m0, m1) and torch.equal(v0, v1)
     for k, (a, b) in enumerate(zip(dx0, dx1)):
+        if mode == "2":
+            assert torch.equal(a, b)
         check_close_robust("dx folded vs unfolded %d" % k, a.float(), b.float(), 1e-2, 2e-3)
     for i, (ga, gb) in enumerate(zip(g0, g1)):
         for a, b in zip(ga, gb):
