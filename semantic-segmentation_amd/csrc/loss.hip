@@ -208,19 +208,29 @@ __device__ __forceinline__ void tri_index(int e, int* i, int* j) {
   while (rem >= 9 - r) { rem -= 9 - r; ++r; }
   *i = r; *j = r + rem;
 }
+__host__ __device__ inline int gram_stride(int Wp) { return Wp + ((35 - Wp % 32) % 32); }
+
 __global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ ppr,
                                                       const float* __restrict__ pla, int Hp, int Wp,
                                                       double* __restrict__ gram) {
-  SSA_DYN_LDS(float, sm);  // la tile [GROWS+2][Wp], pr tile [GROWS+2][Wp]
+  SSA_DYN_LDS(float, sm);  // la tile [GROWS+2][S], pr tile [GROWS+2][S]
+  // row stride S = 3 (mod 32): at every step the 189 threads read the 9 neighbourhood offsets {0,1,2,S,S+1,S+2,2S,..}
+  // of the two tiles -- with S = Wp = 257 (1 mod 32) three of them share a bank, and the kernel, whose only traffic is
+  // these LDS reads, ran three times longer than it has to (110 us on the critical path of the loss)
+  const int S = gram_stride(Wp);
   const int bc = blockIdx.y;
   const int Hn = Hp - 2, Wn = Wp - 2;
   const int yb = blockIdx.x * GROWS;
   const int nrows = min(GROWS, Hn - yb);
   float* la = sm;
-  float* pr = sm + (GROWS + 2) * Wp;
+  float* pr = sm + (GROWS + 2) * S;
   const float* gla = pla + (long)bc * Hp * Wp + (long)yb * Wp;
   const float* gpr = ppr + (long)bc * Hp * Wp + (long)yb * Wp;
-  for (int i = threadIdx.x; i < (nrows + 2) * Wp; i += NT) { la[i] = gla[i]; pr[i] = gpr[i]; }
+  for (int i = threadIdx.x; i < (nrows + 2) * Wp; i += NT) {
+    const int r = i / Wp, c = i - r * Wp;
+    la[r * S + c] = gla[i];
+    pr[r * S + c] = gpr[i];
+  }
   __syncthreads();
   const int e = threadIdx.x;
   if (e >= NG) return;
@@ -231,11 +241,11 @@ __global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ 
   else if (e < 171) { ti = (e - 90) / 9; tj = (e - 90) % 9; ta = la; tb = pr; kind = 0; }
   else if (e < 180) { ti = e - 171; tj = 0; ta = la; tb = la; kind = 1; }
   else { ti = e - 180; tj = 0; ta = pr; tb = pr; kind = 1; }
-  const int oa = (ti / 3) * Wp + (ti % 3), ob = (tj / 3) * Wp + (tj % 3);
+  const int oa = (ti / 3) * S + (ti % 3), ob = (tj / 3) * S + (tj % 3);
   double acc = 0.0;
   for (int y = 0; y < nrows; ++y) {
-    const float* ra = ta + y * Wp + oa;
-    const float* rb = tb + y * Wp + ob;
+    const float* ra = ta + y * S + oa;
+    const float* rb = tb + y * S + ob;
     if (kind == 0) { for (int x = 0; x < Wn; ++x) acc += (double)ra[x] * (double)rb[x]; }
     else { for (int x = 0; x < Wn; ++x) acc += (double)ra[x]; }
   }
@@ -306,10 +316,54 @@ __device__ void tri_inv9(const double* L, double* Li) {
   }
 }
 
-__global__ void rmi_solve_kernel(const double* __restrict__ gram, int Hp, int Wp,
-                                 double* __restrict__ loss_bc, double* __restrict__ gmat) {
+// The same helpers for a workgroup of >= 81 threads, thread t owning element (t / 9, t % 9): every element is
+// computed by the same operations in the same order as in the single-thread versions above (bit-identical results);
+// the serial kernel spent 180-290 us of the step's critical path in dependent LDS round trips of ONE lane.
+__device__ __forceinline__ void pmat_mul9(const double* A, const double* B, double* C, bool tA, bool tB, int t) {
+  if (t < 81) {
+    const int i = t / 9, j = t - 9 * i;
+    double s = 0.0;
+    for (int k = 0; k < 9; ++k) s += (tA ? A[k * 9 + i] : A[i * 9 + k]) * (tB ? B[j * 9 + k] : B[k * 9 + j]);
+    C[t] = s;
+  }
+  __syncthreads();
+}
+__device__ bool pmat_inv9(const double* A, double* X, double* W, int* flag, int t) {
+  const int r = t / 9, k = t - 9 * r;
+  if (t < 81) { W[t] = A[t]; X[t] = (r == k) ? 1.0 : 0.0; }
+  __syncthreads();
+  for (int col = 0; col < 9; ++col) {
+    if (t == 0) {
+      int piv = col;
+      double best = fabs(W[col * 9 + col]);
+      for (int q = col + 1; q < 9; ++q) { const double v = fabs(W[q * 9 + col]); if (v > best) { best = v; piv = q; } }
+      flag[0] = best == 0.0 ? -1 : piv;
+    }
+    __syncthreads();
+    const int piv = flag[0];
+    if (piv < 0) return false;
+    if (piv != col && t < 9) {
+      double u = W[col * 9 + t]; W[col * 9 + t] = W[piv * 9 + t]; W[piv * 9 + t] = u;
+      u = X[col * 9 + t]; X[col * 9 + t] = X[piv * 9 + t]; X[piv * 9 + t] = u;
+    }
+    __syncthreads();
+    const double inv = 1.0 / W[col * 9 + col];
+    __syncthreads();
+    if (t < 9) { W[col * 9 + t] *= inv; X[col * 9 + t] *= inv; }
+    __syncthreads();
+    const double f = t < 81 ? W[r * 9 + col] : 0.0;
+    __syncthreads();
+    if (t < 81 && r != col && f != 0.0) { W[t] -= f * W[col * 9 + k]; X[t] -= f * X[col * 9 + k]; }
+    __syncthreads();
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(128) void rmi_solve_kernel(const double* __restrict__ gram, int Hp, int Wp,
+                                                        double* __restrict__ loss_bc, double* __restrict__ gmat) {
   __shared__ double S[11 * 81];
-  if (threadIdx.x != 0) return;
+  __shared__ int flag[2];
+  const int t = threadIdx.x;
   const int bc = blockIdx.x;
   const double* g = gram + (long)bc * NG;
   const double n = (double)(Hp - 2) * (double)(Wp - 2);
@@ -317,54 +371,61 @@ __global__ void rmi_solve_kernel(const double* __restrict__ gram, int Hp, int Wp
   double* T1 = S + 324; double* T2 = S + 405; double* M = S + 486; double* Lc = S + 567;
   double* Li = S + 648; double* GM = S + 729; double* T3 = S + 810;
   const double* sla = g + 171; const double* spr = g + 180;
-  int e = 0;
-  for (int i = 0; i < 9; ++i)
-    for (int j = i; j < 9; ++j, ++e) {
-      const double v = g[e] - sla[i] * sla[j] / n;
-      Cll[i * 9 + j] = v; Cll[j * 9 + i] = v;
-      const double w = g[45 + e] - spr[i] * spr[j] / n;
-      Cpp[i * 9 + j] = w; Cpp[j * 9 + i] = w;
-    }
-  for (int i = 0; i < 9; ++i)
-    for (int j = 0; j < 9; ++j) Clp[i * 9 + j] = g[90 + i * 9 + j] - sla[i] * spr[j] / n;
   double* out = gmat + (long)bc * (2 * 81 + 18);
-  for (int i = 0; i < 9; ++i) { out[162 + i] = sla[i] / n; out[171 + i] = spr[i] / n; }
+  if (t < 81) {
+    const int i = t / 9, j = t - 9 * i;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int e = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);          // index of (lo, hi) in the packed upper triangle
+    Cll[t] = g[e] - sla[lo] * sla[hi] / n;
+    Cpp[t] = g[45 + e] - spr[lo] * spr[hi] / n;
+    Clp[t] = g[90 + t] - sla[i] * spr[j] / n;
+  }
+  if (t < 9) { out[162 + t] = sla[t] / n; out[171 + t] = spr[t] / n; }
+  __syncthreads();
   // X = (Cpp + alpha I)^-1
-  for (int i = 0; i < 81; ++i) T1[i] = Cpp[i];
-  for (int i = 0; i < 9; ++i) T1[i * 9 + i] += kPosAlpha;
-  bool ok = mat_inv9(T1, X, T2);
+  if (t < 81) T1[t] = Cpp[t] + ((t / 9 == t % 9) ? kPosAlpha : 0.0);
+  __syncthreads();
+  bool ok = pmat_inv9(T1, X, T2, flag, t);
+  __syncthreads();
   // A = Cll - Clp X Clp^T ; M = A + alpha I
-  mat_mul9(Clp, X, T1, false, false);        // T1 = Clp X
-  mat_mul9(T1, Clp, T2, false, true);        // T2 = Clp X Clp^T
-  for (int i = 0; i < 81; ++i) M[i] = Cll[i] - T2[i];
-  for (int i = 0; i < 9; ++i) M[i * 9 + i] += kPosAlpha;
-  ok = ok && chol9(M, Lc);
-  if (!ok) {
-    loss_bc[bc] = __longlong_as_double(0x7ff8000000000000LL);
-    for (int i = 0; i < 162; ++i) out[i] = 0.0;
+  pmat_mul9(Clp, X, T1, false, false, t);        // T1 = Clp X
+  pmat_mul9(T1, Clp, T2, false, true, t);        // T2 = Clp X Clp^T
+  if (t < 81) M[t] = (Cll[t] - T2[t]) + ((t / 9 == t % 9) ? kPosAlpha : 0.0);
+  __syncthreads();
+  if (t == 0) {
+    const bool pd = ok && chol9(M, Lc);
+    flag[1] = pd ? 1 : 0;
+    if (pd) {
+      double loss = 0.0;
+      for (int i = 0; i < 9; ++i) loss += log(Lc[i * 9 + i] + 1e-8);
+      loss_bc[bc] = loss;  // = 0.5 * 2 * sum log(diag + 1e-8)
+      tri_inv9(Lc, Li);
+    } else {
+      loss_bc[bc] = __longlong_as_double(0x7ff8000000000000LL);
+    }
+  }
+  __syncthreads();
+  if (!flag[1]) {
+    for (int i = t; i < 162; i += blockDim.x) out[i] = 0.0;
     return;
   }
-  double loss = 0.0;
-  for (int i = 0; i < 9; ++i) loss += log(Lc[i * 9 + i] + 1e-8);
-  loss_bc[bc] = loss;  // = 0.5 * 2 * sum log(diag + 1e-8)
   // G_M = 0.5 * Li^T diag(w) Li, w_i = L_ii / (L_ii + 1e-8)
-  tri_inv9(Lc, Li);
-  for (int i = 0; i < 9; ++i)
-    for (int j = 0; j < 9; ++j) {
-      double s = 0.0;
-      for (int k = 0; k < 9; ++k) {
-        const double w = Lc[k * 9 + k] / (Lc[k * 9 + k] + 1e-8);
-        s += Li[k * 9 + i] * w * Li[k * 9 + j];
-      }
-      GM[i * 9 + j] = 0.5 * s;
+  if (t < 81) {
+    const int i = t / 9, j = t - 9 * i;
+    double s = 0.0;
+    for (int k = 0; k < 9; ++k) {
+      const double w = Lc[k * 9 + k] / (Lc[k * 9 + k] + 1e-8);
+      s += Li[k * 9 + i] * w * Li[k * 9 + j];
     }
+    GM[t] = 0.5 * s;
+  }
+  __syncthreads();
   // G_lp = -2 GM Clp X = -2 GM T1
-  mat_mul9(GM, T1, T2, false, false);
-  for (int i = 0; i < 81; ++i) out[i] = -2.0 * T2[i];
-  // G_pp = X Clp^T GM Clp X = T1^T GM T1
-  mat_mul9(GM, T1, T2, false, false);   // T2 = GM T1
-  mat_mul9(T1, T2, T3, true, false);    // T3 = T1^T GM T1
-  for (int i = 0; i < 81; ++i) out[81 + i] = T3[i];
+  pmat_mul9(GM, T1, T2, false, false, t);
+  if (t < 81) out[t] = -2.0 * T2[t];
+  // G_pp = X Clp^T GM Clp X = T1^T GM T1     (T2 = GM T1 already)
+  pmat_mul9(T1, T2, T3, true, false, t);
+  if (t < 81) out[81 + t] = T3[t];
 }
 
 __global__ void rmi_finalize_kernel(const double* __restrict__ loss_bc, int B, int C,
@@ -529,7 +590,7 @@ int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(gram, 0, sizeof(double) * NG * BC, s);
   if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)2 * (GROWS + 2) * Wp * sizeof(float);
+  const size_t lds = (size_t)2 * (GROWS + 2) * gram_stride(Wp) * sizeof(float);
   if (lds > 60000) return SSA_EUNSUPPORTED;
   hipLaunchKernelGGL(rmi_gram_kernel, dim3((Hp - 2 + GROWS - 1) / GROWS, BC), dim3(NT), lds, s,
                      pooled_pr, pooled_la, Hp, Wp, gram);
@@ -540,7 +601,7 @@ int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
 int ssa_rmi_solve(const double* gram, int BC, int Hp, int Wp, double* loss_bc, double* gmat,
                   void* stream) {
   if (!gram || !loss_bc || !gmat) return SSA_EINVAL;
-  hipLaunchKernelGGL(rmi_solve_kernel, dim3(BC), dim3(64), 0, (hipStream_t)stream, gram, Hp, Wp,
+  hipLaunchKernelGGL(rmi_solve_kernel, dim3(BC), dim3(128), 0, (hipStream_t)stream, gram, Hp, Wp,
                      loss_bc, gmat);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
