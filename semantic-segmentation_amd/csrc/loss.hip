@@ -213,29 +213,31 @@ __host__ __device__ inline int gram_stride(int Wp) { return Wp + ((35 - Wp % 32)
 __global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ ppr,
                                                       const float* __restrict__ pla, int Hp, int Wp,
                                                       double* __restrict__ gram) {
-  SSA_DYN_LDS(float, sm);  // la tile [GROWS+2][S], pr tile [GROWS+2][S]
+  SSA_DYN_LDS(double, smd);  // la tile [GROWS+2][S], pr tile [GROWS+2][S], converted to fp64 ONCE while staged
   // row stride S = 3 (mod 32): at every step the 189 threads read the 9 neighbourhood offsets {0,1,2,S,S+1,S+2,2S,..}
-  // of the two tiles -- with S = Wp = 257 (1 mod 32) three of them share a bank, and the kernel, whose only traffic is
-  // these LDS reads, ran three times longer than it has to (110 us on the critical path of the loss)
+  // of the two tiles -- with S = Wp = 257 (1 mod 32) three of them share a bank.  The tiles hold doubles: the inner
+  // loop is then one ds_read_b64 pair + one fp64 FMA per product instead of two float reads, two conversions and the
+  // FMA (fp64 runs at half rate; the kernel is 233 M products per call).  A float converts exactly, a product of two
+  // floats is exact in fp64: the sums are bit-identical to the float-tile version.
   const int S = gram_stride(Wp);
   const int bc = blockIdx.y;
   const int Hn = Hp - 2, Wn = Wp - 2;
   const int yb = blockIdx.x * GROWS;
   const int nrows = min(GROWS, Hn - yb);
-  float* la = sm;
-  float* pr = sm + (GROWS + 2) * S;
+  double* la = smd;
+  double* pr = smd + (GROWS + 2) * S;
   const float* gla = pla + (long)bc * Hp * Wp + (long)yb * Wp;
   const float* gpr = ppr + (long)bc * Hp * Wp + (long)yb * Wp;
   for (int i = threadIdx.x; i < (nrows + 2) * Wp; i += NT) {
     const int r = i / Wp, c = i - r * Wp;
-    la[r * S + c] = gla[i];
-    pr[r * S + c] = gpr[i];
+    la[r * S + c] = (double)gla[i];
+    pr[r * S + c] = (double)gpr[i];
   }
   __syncthreads();
   const int e = threadIdx.x;
   if (e >= NG) return;
   int ti, tj, kind;  // kind 0: a*b, 1: a only
-  const float *ta, *tb;
+  const double *ta, *tb;
   if (e < 45) { tri_index(e, &ti, &tj); ta = la; tb = la; kind = 0; }
   else if (e < 90) { tri_index(e - 45, &ti, &tj); ta = pr; tb = pr; kind = 0; }
   else if (e < 171) { ti = (e - 90) / 9; tj = (e - 90) % 9; ta = la; tb = pr; kind = 0; }
@@ -244,10 +246,10 @@ __global__ __launch_bounds__(NT) void rmi_gram_kernel(const float* __restrict__ 
   const int oa = (ti / 3) * S + (ti % 3), ob = (tj / 3) * S + (tj % 3);
   double acc = 0.0;
   for (int y = 0; y < nrows; ++y) {
-    const float* ra = ta + y * S + oa;
-    const float* rb = tb + y * S + ob;
-    if (kind == 0) { for (int x = 0; x < Wn; ++x) acc += (double)ra[x] * (double)rb[x]; }
-    else { for (int x = 0; x < Wn; ++x) acc += (double)ra[x]; }
+    const double* ra = ta + y * S + oa;
+    const double* rb = tb + y * S + ob;
+    if (kind == 0) { for (int x = 0; x < Wn; ++x) acc += ra[x] * rb[x]; }
+    else { for (int x = 0; x < Wn; ++x) acc += ra[x]; }
   }
   atomicAdd(&gram[(long)bc * NG + e], acc);
 }
@@ -590,7 +592,7 @@ int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(gram, 0, sizeof(double) * NG * BC, s);
   if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)2 * (GROWS + 2) * gram_stride(Wp) * sizeof(float);
+  const size_t lds = (size_t)2 * (GROWS + 2) * gram_stride(Wp) * sizeof(double);
   if (lds > 60000) return SSA_EUNSUPPORTED;
   hipLaunchKernelGGL(rmi_gram_kernel, dim3((Hp - 2 + GROWS - 1) / GROWS, BC), dim3(NT), lds, s,
                      pooled_pr, pooled_la, Hp, Wp, gram);
