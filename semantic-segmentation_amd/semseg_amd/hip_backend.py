@@ -423,6 +423,7 @@ class _GradArena:
 
     def abandon(self):
         self.armed = False
+        _FLUSH_NEXT[0] = _WGRAD_FLUSH_AT
         self.chunks = []
         self.slots = {}
         self.late = []
@@ -432,6 +433,7 @@ class _GradArena:
         try:
             flush_wgrads()
             _SINCE_REDUCE[0] = 0
+            _FLUSH_NEXT[0] = _WGRAD_FLUSH_AT
             if _GRAD_SINK[0] is not None and self.slots:
                 with _on_wgrad_stream():
                     self.reduce_completed()
@@ -734,6 +736,13 @@ _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel sta
 # flush every 16 / 32 / 64 / 128 / 256 layers / at the end only = 23.93 / 23.39 / 23.11 / 22.94 / 22.75 / 23.32 ms.
 _WGRAD_SIDE = os.environ.get("SSA_WGRAD_STREAM", "1") != "0"
 _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "256" if _WGRAD_SIDE else "100000"))
+# SSA_WGRAD_FLUSH_MIN < SSA_WGRAD_FLUSH_AT: every flush halves the interval of the next one down to that minimum, so
+# that little is left queued when backward ends (the remainder runs with nothing to hide behind: ~1 ms of exposed
+# weight-gradient kernels at the end of the step).  Measured (profiles/r03_notes.md, call Y): 256 -> 32: 22.78 / 22.91 ms,
+# 256 -> 64: 22.63, 256 -> 16: 22.92 against 22.44 / 22.49 without -- the small flushes cost more than the shorter tail
+# saves.  Default: no decay.
+_WGRAD_FLUSH_MIN = int(os.environ.get("SSA_WGRAD_FLUSH_MIN", "100000"))
+_FLUSH_NEXT = [_WGRAD_FLUSH_AT]
 # ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
 # range while backward goes on (a step queues ~640 layers: three exchanges, the last one short)
 _DDP_FLUSH_AT = int(os.environ.get("SSA_DDP_FLUSH_AT", "256"))
@@ -887,8 +896,9 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
         _WGRAD_Q.append(job(_GRADS.slot(weight), True))
         n = len(_WGRAD_Q)
         exchange = _GRAD_SINK[0] is not None and n + _SINCE_REDUCE[0] >= _DDP_FLUSH_AT
-        if n >= _WGRAD_FLUSH_AT or exchange:
+        if n >= _FLUSH_NEXT[0] or exchange:
             flush_wgrads()
+            _FLUSH_NEXT[0] = max(min(_WGRAD_FLUSH_MIN, _WGRAD_FLUSH_AT), _FLUSH_NEXT[0] // 2)
             _SINCE_REDUCE[0] += n
             if exchange:
                 with _on_wgrad_stream():
