@@ -423,7 +423,7 @@ class _GradArena:
 
     def abandon(self):
         self.armed = False
-        _FLUSH_NEXT[0] = _WGRAD_FLUSH_AT
+        _FLUSH_NEXT[0] = _WGRAD_FLUSH_FIRST
         self.chunks = []
         self.slots = {}
         self.late = []
@@ -433,7 +433,7 @@ class _GradArena:
         try:
             flush_wgrads()
             _SINCE_REDUCE[0] = 0
-            _FLUSH_NEXT[0] = _WGRAD_FLUSH_AT
+            _FLUSH_NEXT[0] = _WGRAD_FLUSH_FIRST
             if _GRAD_SINK[0] is not None and self.slots:
                 with _on_wgrad_stream():
                     self.reduce_completed()
@@ -742,7 +742,10 @@ _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "256" if _WGRAD_SIDE 
 # 256 -> 64: 22.63, 256 -> 16: 22.92 against 22.44 / 22.49 without -- the small flushes cost more than the shorter tail
 # saves.  Default: no decay.
 _WGRAD_FLUSH_MIN = int(os.environ.get("SSA_WGRAD_FLUSH_MIN", "100000"))
-_FLUSH_NEXT = [_WGRAD_FLUSH_AT]
+# SSA_WGRAD_FLUSH_FIRST: interval of the FIRST flush of a backward pass (the head's large weight gradients are queued
+# within its first ~25 layers)
+_WGRAD_FLUSH_FIRST = int(os.environ.get("SSA_WGRAD_FLUSH_FIRST", "0")) or _WGRAD_FLUSH_AT
+_FLUSH_NEXT = [_WGRAD_FLUSH_FIRST]
 # ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
 # range while backward goes on (a step queues ~640 layers: three exchanges, the last one short)
 _DDP_FLUSH_AT = int(os.environ.get("SSA_DDP_FLUSH_AT", "256"))
@@ -898,7 +901,8 @@ def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, C
         exchange = _GRAD_SINK[0] is not None and n + _SINCE_REDUCE[0] >= _DDP_FLUSH_AT
         if n >= _FLUSH_NEXT[0] or exchange:
             flush_wgrads()
-            _FLUSH_NEXT[0] = max(min(_WGRAD_FLUSH_MIN, _WGRAD_FLUSH_AT), _FLUSH_NEXT[0] // 2)
+            _FLUSH_NEXT[0] = max(min(_WGRAD_FLUSH_MIN, _WGRAD_FLUSH_AT), (_WGRAD_FLUSH_AT if _FLUSH_NEXT[0] == _WGRAD_FLUSH_FIRST != _WGRAD_FLUSH_AT
+                                                                             else _FLUSH_NEXT[0] // 2))
             _SINCE_REDUCE[0] += n
             if exchange:
                 with _on_wgrad_stream():
