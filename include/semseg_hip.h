@@ -128,26 +128,18 @@ int ssa_conv2d_tile_aux(const ssa_conv_desc* d, const void* x, const void* w_fra
                         const float* coef, int aux_mode, void* stream);
 
 /* Persistent, software-pipelined form of ssa_conv2d_tile / ssa_conv2d_tile_aux for the trunk's 48/96/192/384-channel
- * 3x3 convs (csrc/conv_tile_p.hip): a workgroup walks a strip of tiles of one (problem, n-block group) with the
- * filter resident / streamed as one continuous DMA pipeline, the next halo in flight during the MFMAs, BatchNorm
- * statistics in registers over the strip.  The neighbouring BatchNorm passes of network/hrnetv2.py:53-64 fold into
- * its operand staging:
- *   xf_mode 0: the input is staged as it is;
- *   xf_mode 1: staged input = relu(xf[0][c] * x + xf[1][c])          (xf: [2][Cin] fp32 = the first two rows of the
- *              [4][C] table ssa_bn_coef_train writes) -- bn1 + ReLU applied inside conv2, its output never stored;
- *   xf_mode 2: staged input = A[c] * (m ? x : 0) + B0[c] + C0[c] * x2,  m = [ma[c] * x2 + mb[c] > 0]
- *              (x = dz, the gradient w.r.t. the BatchNorm+ReLU output; x2 = that layer's input, pixel stride ldx2;
- *              xf: [5][Cin] fp32 = A, B0, C0, ma, mb from ssa_bn_bwd_coef) -- bn1's backward apply inside conv1's
- *              data gradient, its result never stored.
- * Pixels outside the image are zero AFTER the transform.  stats / aux / aux_mode / coef as ssa_conv2d_tile_aux
- * (aux_mode 0: none).  ssa_conv_tile_strip(units): work (in filter passes over one 128-pixel tile, 54 MFMAs per wave)
- * a workgroup of the calling thread's NEXT launches should carry -- the caller of a grouped level knows the level's
+ * 3x3 convs (csrc/conv_tile_p.hip): a workgroup walks a strip of tiles of one (problem, pair of n-blocks), the input
+ * in chunks of 48 channels, with the filter resident (48 channels) or streamed as one continuous LDS-DMA pipeline
+ * through a ring of three buffers, the next halo in flight during the MFMAs, a register-only epilogue (swapped MFMA
+ * operands + v_permlane32_swap) and the BatchNorm statistics in registers over the strip.
+ * stats / aux / aux_mode / coef as ssa_conv2d_tile_aux (aux_mode 0: none).
+ * ssa_conv_tile_strip(units): work (in units of one 128-pixel tile x one 48-channel chunk = 54 MFMAs per wave) a
+ * workgroup of the calling thread's NEXT launches should carry -- the caller of a grouped level knows the level's
  * total; 0 = derive from each problem alone.                                                                    */
 int ssa_conv2d_tile_p_supported(const ssa_conv_desc* d);
 int ssa_conv_tile_strip(int units);
-int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* x2, int ldx2, const float* xf,
-                      int xf_mode, const void* w_frag, const float* bias, void* y, double* stats,
-                      const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
+int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
+                      double* stats, const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
 
 /* Halo-chunk implicit GEMM for the large-channel 3x3 / 1x1 stride-1 "same" convs
  * of the OCR and attention heads (Cin >= 192, Cin % 48 == 0 or % 64 == 0):
@@ -246,16 +238,6 @@ int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit
 int ssa_conv2d_wgrad_tile(const ssa_conv_desc* d, const void* x, const void* dy,
                           int lddy, int cout_pad, int nsplit, float* partial,
                           void* stream);
-/* ssa_conv2d_wgrad_tile with a BatchNorm pass folded into the staging of one operand (csrc/conv_wgrad_tile.hip):
- *   xf_mode 1: x operand = relu(xf[0][ci]*x + xf[1][ci]), zero outside the image (xf: [2][Cin]) -- conv2's weight
- *              gradient from bn1's INPUT (network/hrnetv2.py:45-50), the normalised activation is never stored;
- *   xf_mode 2: dy operand = A*(m ? dy : 0) + B0 + C0*x2, m = [ma*x2 + mb > 0] (xf: [5][cout_pad] from
- *              ssa_bn_bwd_coef; x2 = the BatchNorm layer's input, pixel stride ldx2) -- conv1's weight gradient
- *              without a materialised bn1 backward.  48- and 96/192/384-channel layers; xf_mode 0 = plain.      */
-int ssa_conv2d_wgrad_tile_xf(const ssa_conv_desc* d, const void* x, const void* dy, int lddy, int cout_pad,
-                             int nsplit, float* partial, int xf_mode, const float* xf, const void* x2, int ldx2,
-                             void* stream);
-
 /* Weight gradient of the large-channel 3x3 / 1x1 stride-1 head convs (Cin >= 128,
  * >= 16 K pixels): 8-wave workgroups persistent over 128-pixel tiles hold a
  * 128(co) x 128(ci) x 3(kw) [3x3] or 128 x 256 [1x1] block of dW in MFMA
@@ -308,21 +290,6 @@ typedef struct ssa_bn_update_job {
   float momentum;
   int pad_;
 } ssa_bn_update_job;
-/* Coefficient tables of the BatchNorm passes that are folded into a convolution's operand staging
- * (ssa_conv2d_tile_p xf_mode 1 / 2, ssa_conv2d_wgrad_tile_xf) -- group-aware, one launch per trunk level:
- *   ssa_bn_coef_train: batch sums [nrep][2][C] fp64 (conv epilogue) + count -> coef[4][C] = scale, shift, mean,
- *     invstd; pass_stats ([2C+1] = mean, biased var, count; may be NULL) for ssa_bn_update_running_batched.
- *     Equals what ssa_bn_apply_train derives before it normalises (network/hrnetv2.py:45-46 bn1).
- *   ssa_bn_bwd_coef: backward sums [nrep][2][C] (sum m*dz, sum m*dz*xhat; ssa_conv2d_tile_aux mode 2) ->
- *     xf[5][C] = A, B0, C0, ma, mb with  dx = A*(m ? dz : 0) + B0 + C0*x,  m = [ma*x + mb > 0]  (the arithmetic of
- *     ssa_bn_bwd_apply with the ReLU mask recomputed from x), and the parameter gradients dbeta (+)= s1*scale,
- *     dgamma (+)= s2*scale (accumulate_param_grads: atomic adds into a shared buffer).                        */
-int ssa_bn_coef_train(const double* sums, int nrep, double count, int C, const float* gamma, const float* beta,
-                      float eps, float* coef, float* pass_stats, void* stream);
-int ssa_bn_bwd_coef(const double* sums, int nrep, double count, int C, const float* gamma, const float* coef,
-                    float* xf, float* dgamma, float* dbeta, float param_grad_scale, int accumulate_param_grads,
-                    void* stream);
-
 /* jobs_dev: device array of ssa_bn_update_job; one launch for all layers.     */
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels,
                                   void* stream);

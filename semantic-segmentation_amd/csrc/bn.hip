@@ -74,39 +74,59 @@ __device__ __forceinline__ void replica_sums(const double* __restrict__ sums, in
   *s2 = b;
 }
 
+// ---- the streaming passes -------------------------------------------------------------------------------------
+// Every pass gives a thread ROWS pixel rows of its channel group and issues ALL of their loads (up to 3 tensors x
+// ROWS x 16 bytes) before anything else -- also before the per-workgroup coefficient prologue, whose own (L2) loads
+// then fly together with the data: one memory round trip per workgroup instead of the three of round 3 (prologue,
+// then two batches of four rows behind `#pragma unroll 4`).  Rows past the end of the workgroup's range load the
+// range's first pixel (always valid) and are masked, so the loads are unconditional and issue back to back.  A level
+// of the trunk (7.4 M elements) is in flight in its entirety.
+template <int ROWS>
+struct RowSet {
+  unsigned ok;              // bit u: row u lies inside [p0, p1)
+  int off[ROWS];            // pixel offset of row u from p0 (0 for masked rows)
+  __device__ __forceinline__ void init(long p0, long p1, int pr, int RP, bool active) {
+    ok = 0;
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+      const long q = (long)pr + (long)u * RP;
+      const bool o = active && p0 + q < p1;
+      ok |= (o ? 1u : 0u) << u;
+      off[u] = o ? (int)q : 0;
+    }
+  }
+  __device__ __forceinline__ void load(const bf16_t* base, int ld, uint4 (&v)[ROWS]) const {
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (long)off[u] * ld);
+  }
+};
+
+template <int ROWS>
 __device__ __forceinline__ void bn_stats_body(const bf16_t* __restrict__ x, long P, int C,
-                                                      int ld, double* __restrict__ sums,
-                                                      long pix_per_block, const int bx) {
+                                              int ld, double* __restrict__ sums,
+                                              long pix_per_block, const int bx, const bool squares) {
   SSA_DYN_LDS(float, sh);
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
-  const int cg = t % VC, pr = t / VC;
+  const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  const long p0 = bx * pix_per_block;
-  const long p1 = min(P, p0 + pix_per_block);
-  if (active) {
-    const bf16_t* xp = x + cg * 8;
-    long p = p0 + pr;
-    for (; p + 3L * RP < p1; p += 4L * RP) {
-      uint4 v[4];
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);
+  for (long p0 = pb; p0 < pe; p0 += (long)RP * ROWS) {
+    RowSet<ROWS> rs;
+    rs.init(p0, pe, pr, RP, active);
+    uint4 v[ROWS];
+    rs.load(x + p0 * ld + cg * 8, ld, v);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(xp + (p + (long)u * RP) * ld);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float f[8];
-        unpack8(v[u], f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
-      }
-    }
-    for (; p < p1; p += RP) {
+    for (int u = 0; u < ROWS; ++u) {
+      const float keep = ((rs.ok >> u) & 1u) ? 1.f : 0.f;
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(xp + p * ld), f);
+      unpack8(v[u], f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
+      for (int j = 0; j < 8; ++j) { const float fk = f[j] * keep; s[j] += fk; if (squares) q[j] += fk * f[j]; }
     }
   }
   block_reduce_2x8(s, q, cg, C, active, sums, sh, bx);
@@ -143,6 +163,38 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (invstd_out) invstd_out[c] = (float)invstd;
 }
 
+// z = post * act(scale * x + shift + residual): the arithmetic shared by the eval and the training apply
+template <int ROWS>
+__device__ __forceinline__ void bn_apply_rows(const RowSet<ROWS>& rs, const uint4 (&v)[ROWS], const uint4 (&rv)[ROWS],
+                                              bool has_res, const float (&a)[8], const float (&b)[8], int relu,
+                                              const float* __restrict__ post, long pix_per_img, long p0, int C, int cg,
+                                              bf16_t* __restrict__ zb, int ldz) {
+#pragma unroll
+  for (int u = 0; u < ROWS; ++u) {
+    float f[8];
+    unpack8(v[u], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
+    if (has_res) {
+      float r[8];
+      unpack8(rv[u], r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
+    if (post) {
+      const float* pp = post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] *= pp[j];
+    }
+    if ((rs.ok >> u) & 1u) *reinterpret_cast<uint4*>(zb + (long)rs.off[u] * ldz) = pack8(f);
+  }
+}
+
+template <int ROWS>
 __device__ __forceinline__ void bn_apply_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
     bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ scale,
@@ -152,42 +204,32 @@ __device__ __forceinline__ void bn_apply_body(
   const int t = threadIdx.x;
   if (t >= NA) return;
   const int cg = t % VC, pr = t / VC;
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);
   float a[8], b[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { a[j] = scale[cg * 8 + j]; b[j] = shift[cg * 8 + j]; }
-  const long p0 = bx * pix_per_block;
-  const long p1 = min(P, p0 + pix_per_block);
-#pragma unroll 4
-  for (long p = p0 + pr; p < p1; p += RP) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
-    float f[8];
-    unpack8(v, f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
-    if (res) {
-      const uint4 rv = *reinterpret_cast<const uint4*>(res + p * ldr + cg * 8);
-      float r[8];
-      unpack8(rv, r);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] += r[j];
+  bool have_coef = false;
+  for (long p0 = pb; p0 < pe; p0 += (long)RP * ROWS) {
+    RowSet<ROWS> rs;
+    rs.init(p0, pe, pr, RP, true);
+    uint4 v[ROWS], rv[ROWS];
+    rs.load(x + p0 * ldx + cg * 8, ldx, v);
+    if (res) rs.load(res + p0 * ldr + cg * 8, ldr, rv);
+    if (!have_coef) {
+      const float4 a0 = *reinterpret_cast<const float4*>(scale + cg * 8), a1 = *reinterpret_cast<const float4*>(scale + cg * 8 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(shift + cg * 8), b1 = *reinterpret_cast<const float4*>(shift + cg * 8 + 4);
+      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+      have_coef = true;
     }
-    if (relu) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
-    }
-    if (post) {
-      const float* pp = post + (p / pix_per_img) * C + cg * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] *= pp[j];
-    }
-    *reinterpret_cast<uint4*>(z + p * ldz + cg * 8) = pack8(f);
+    bn_apply_rows<ROWS>(rs, v, rv, res != nullptr, a, b, relu, post, pix_per_img, p0, C, cg, z + p0 * ldz + cg * 8, ldz);
   }
 }
 
-// Training-mode apply with the finalize step fused in: every thread derives
-// scale/shift for its 8 channels from the fp64 sums (2 loads + a few fp64 ops per
-// channel), block 0 additionally publishes mean/invstd/scale/shift for the
-// backward pass, updates the running statistics and bumps num_batches_tracked.
+// Training-mode apply with the finalize step fused in: thread c derives scale/shift of channel c from the fp64
+// sums (the replica loads of all channels issue together, BEHIND the workgroup's data loads), block 0 additionally
+// publishes mean/invstd/scale/shift for the backward pass, updates the running statistics and bumps
+// num_batches_tracked.
+template <int ROWS>
 __device__ __forceinline__ void bn_apply_train_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
     bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, int nrep,
@@ -199,7 +241,16 @@ __device__ __forceinline__ void bn_apply_train_body(
   SSA_DYN_LDS(float, sh);                 // [2C]: scale, shift for this launch
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
-  // every workgroup derives the per-channel coefficients once (thread c -> channel c)
+  const bool active = t < NA;
+  const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);
+  // ---- the first chunk's loads, then the coefficient prologue while they are in flight
+  RowSet<ROWS> rs;
+  rs.init(pb, pe, pr, RP, active);
+  uint4 v[ROWS], rv[ROWS];
+  rs.load(x + pb * ldx + cg * 8, ldx, v);
+  if (res) rs.load(res + pb * ldr + cg * 8, ldr, rv);
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     replica_sums(sums, nrep, C, c, &s1, &s2);
@@ -233,40 +284,44 @@ __device__ __forceinline__ void bn_apply_train_body(
     if (pass_stats) pass_stats[2 * C] = (float)count;
   }
   __syncthreads();
-  if (t >= NA) return;
-  const int cg = t % VC, pr = t / VC;
+  if (!active) return;
   float a[8], b[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { a[j] = sh[cg * 8 + j]; b[j] = sh[C + cg * 8 + j]; }
-  const long p0 = bx * pix_per_block;
-  const long p1 = min(P, p0 + pix_per_block);
-#pragma unroll 4
-  for (long p = p0 + pr; p < p1; p += RP) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + p * ldx + cg * 8);
-    float f[8];
-    unpack8(v, f);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
-    if (res) {
-      const uint4 rv = *reinterpret_cast<const uint4*>(res + p * ldr + cg * 8);
-      float r[8];
-      unpack8(rv, r);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] += r[j];
-    }
-    if (relu) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
-    }
-    if (post) {
-      const float* pp = post + (p / pix_per_img) * C + cg * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] *= pp[j];
-    }
-    *reinterpret_cast<uint4*>(z + p * ldz + cg * 8) = pack8(f);
+  {
+    const float4 a0 = *reinterpret_cast<const float4*>(sh + cg * 8), a1 = *reinterpret_cast<const float4*>(sh + cg * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sh + C + cg * 8), b1 = *reinterpret_cast<const float4*>(sh + C + cg * 8 + 4);
+    a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+    b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+  }
+  for (long p0 = pb;;) {
+    bn_apply_rows<ROWS>(rs, v, rv, res != nullptr, a, b, relu, post, pix_per_img, p0, C, cg, z + p0 * ldz + cg * 8, ldz);
+    p0 += (long)RP * ROWS;
+    if (p0 >= pe) break;
+    rs.init(p0, pe, pr, RP, true);
+    rs.load(x + p0 * ldx + cg * 8, ldx, v);
+    if (res) rs.load(res + p0 * ldr + cg * 8, ldr, rv);
   }
 }
 
+// masked gradient g = post * dz where the ReLU let it through (mask from z, or recomputed from x)
+__device__ __forceinline__ void bn_bwd_mask(float (&g)[8], const float (&xv)[8], const uint4& zraw, bool use_z, int relu,
+                                            bool mask_from_x, const float (&ma)[8], const float (&mb)[8],
+                                            const float* __restrict__ pp) {
+  if (pp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= pp[j];
+  }
+  if (relu && mask_from_x) {          // z = relu(scale*x + shift), z not read
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
+  } else if (relu && use_z) {
+    float zv[8];
+    unpack8(zraw, zv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+  }
+}
+
+template <int ROWS>
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
@@ -277,48 +332,50 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
-  const int cg = t % VC, pr = t / VC;
+  const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
+  const bool use_z = relu && !mscale;
   float sg[8], sgx[8], mu[8], is[8], ma[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; ma[j] = 0.f; mb[j] = 0.f; }
-  if (active) {
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);
+  bool have_coef = false;
+  for (long p0 = pb; p0 < pe; p0 += (long)RP * ROWS) {
+    RowSet<ROWS> rs;
+    rs.init(p0, pe, pr, RP, active);
+    uint4 gv[ROWS], xr[ROWS], zr[ROWS];
+    rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
+    rs.load(x + p0 * ldx + cg * 8, ldx, xr);
+    if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
+    if (!have_coef) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
-    if (mscale) {
+      for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
+      if (mscale) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
+      }
+      have_coef = true;
     }
-    const long p0 = bx * pix_per_block;
-    const long p1 = min(P, p0 + pix_per_block);
-  #pragma unroll 4
-  for (long p = p0 + pr; p < p1; p += RP) {
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
       float g[8], xv[8];
-      unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
-      unpack8(*reinterpret_cast<const uint4*>(x + p * ldx + cg * 8), xv);
-      if (post) {
-        const float* pp = post + (p / pix_per_img) * C + cg * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] *= pp[j];
-      }
-      if (relu && mscale) {          // ReLU mask recomputed from x: z = relu(scale*x + shift), z not read
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
-      } else if (relu) {
-        float zv[8];
-        unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
-      }
+      unpack8(gv[u], g);
+      unpack8(xr[u], xv);
+      const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
+      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp);
+      const float keep = ((rs.ok >> u) & 1u) ? 1.f : 0.f;      // masked rows re-read the chunk's first pixel
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        sg[j] += g[j];
-        sgx[j] += g[j] * (xv[j] - mu[j]) * is[j];
+        const float gk = g[j] * keep;
+        sg[j] += gk;
+        sgx[j] += gk * (xv[j] - mu[j]) * is[j];
       }
     }
   }
   block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, bx, nrep);
 }
 
+template <int ROWS>
 __device__ __forceinline__ void bn_bwd_apply_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
@@ -328,9 +385,21 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
     const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg, const int bx) {
-  SSA_DYN_LDS(float, sh);                 // [5C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N
+  SSA_DYN_LDS(float, sh);                 // [7C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N, mask scale, mask shift
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
+  const bool active = t < NA;
+  const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
+  const bool use_z = relu && !mscale;
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);
+  // ---- the first chunk's loads, then the coefficient prologue while they are in flight
+  RowSet<ROWS> rs;
+  rs.init(pb, pe, pr, RP, active);
+  uint4 gv[ROWS], xr[ROWS], zr[ROWS];
+  rs.load(dz + pb * lddz + cg * 8, lddz, gv);
+  rs.load(x + pb * ldx + cg * 8, ldx, xr);
+  if (use_z) rs.load(z + pb * ldz + cg * 8, ldz, zr);
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     replica_sums(sums, nrep, C, c, &s1, &s2);
@@ -340,6 +409,8 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     sh[2 * C + c] = (gamma ? gamma[c] : 1.f) * is_;
     sh[3 * C + c] = (float)(s1 / count);
     sh[4 * C + c] = (float)(s2 / count);
+    sh[5 * C + c] = mscale ? mscale[c] : 0.f;
+    sh[6 * C + c] = mscale ? mshift[c] : 0.f;
     if (bx == 0) {
       // accumulate_pg: the gradient buffer is shared by every pass over this layer (cleared once
       // per step); passes grouped into one launch add concurrently, hence the atomics
@@ -353,108 +424,39 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     }
   }
   __syncthreads();
-  if (t >= NA) return;
-  const int cg = t % VC, pr = t / VC;
+  if (!active) return;
   float mu[8], is[8], a[8], c1[8], c2[8], ma[8], mb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = cg * 8 + j;
-    ma[j] = mscale ? mscale[c] : 0.f;
-    mb[j] = mscale ? mshift[c] : 0.f;
-    mu[j] = sh[c];
-    is[j] = sh[C + c];
-    a[j] = sh[2 * C + c];
-    c1[j] = sh[3 * C + c];
-    c2[j] = sh[4 * C + c];
+  {
+    auto ld8 = [&](int row, float (&o)[8]) {
+      const float4 v0 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8), v1 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8 + 4);
+      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+    };
+    ld8(0, mu); ld8(1, is); ld8(2, a); ld8(3, c1); ld8(4, c2); ld8(5, ma); ld8(6, mb);
   }
-  const long p0 = bx * pix_per_block;
-  const long p1 = min(P, p0 + pix_per_block);
-#pragma unroll 4
-  for (long p = p0 + pr; p < p1; p += RP) {
-    float g[8], xv[8];
-    unpack8(*reinterpret_cast<const uint4*>(dz + p * lddz + cg * 8), g);
-    unpack8(*reinterpret_cast<const uint4*>(x + p * ldx + cg * 8), xv);
-    if (post) {
-      const float* pp = post + (p / pix_per_img) * C + cg * 8;
+  for (long p0 = pb;;) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] *= pp[j];
+    for (int u = 0; u < ROWS; ++u) {
+      float g[8], xv[8];
+      unpack8(gv[u], g);
+      unpack8(xr[u], xv);
+      const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
+      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp);
+      const bool ok = (rs.ok >> u) & 1u;
+      if (dres && ok) *reinterpret_cast<uint4*>(dres + (p0 + rs.off[u]) * lddres + cg * 8) = pack8(g);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (xv[j] - mu[j]) * is[j];
+        o[j] = a[j] * (g[j] - c1[j] - xh * c2[j]);
+      }
+      if (ok) *reinterpret_cast<uint4*>(dx + (p0 + rs.off[u]) * lddx + cg * 8) = pack8(o);
     }
-    if (relu && mscale) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
-    } else if (relu) {
-      float zv[8];
-      unpack8(*reinterpret_cast<const uint4*>(z + p * ldz + cg * 8), zv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
-    }
-    if (dres) *reinterpret_cast<uint4*>(dres + p * lddres + cg * 8) = pack8(g);
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (xv[j] - mu[j]) * is[j];
-      o[j] = a[j] * (g[j] - c1[j] - xh * c2[j]);
-    }
-    *reinterpret_cast<uint4*>(dx + p * lddx + cg * 8) = pack8(o);
-  }
-}
-
-// Coefficient tables for the BatchNorm passes that are folded into a convolution's operand staging
-// (csrc/conv_tile_p.hip, conv_wgrad_tile.hip) -- the prologue of bn_apply_train_body / bn_bwd_apply_body as
-// kernels of their own, one workgroup of 256 channels each.
-//   forward: batch sums -> coef[4][C] = scale, shift, mean, invstd (+ pass_stats for the deferred running-statistics
-//            update, exactly what block 0 of bn_apply_train_body publishes)
-//   backward: (sum m*dz, sum m*dz*xhat) -> xf[5][C] = A, B0, C0, ma, mb with
-//            dy = A*(m ? dz : 0) + B0 + C0*x  ==  gamma*invstd * (m*dz - s1/N - xhat * s2/N),  m = [ma*x + mb > 0]
-//            and the parameter gradients dbeta += s1, dgamma += s2 (scaled for data-parallel averaging)
-__device__ __forceinline__ void bn_coef_train_body(const double* __restrict__ sums, int nrep, double count, int C,
-                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                   float eps, float* __restrict__ coef, float* __restrict__ pass_stats,
-                                                   const int bx) {
-  const int c = bx * NT + threadIdx.x;
-  if (c == 0 && pass_stats) pass_stats[2 * C] = (float)count;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  replica_sums(sums, nrep, C, c, &s1, &s2);
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  const double g = gamma ? (double)gamma[c] : 1.0;
-  const double b = beta ? (double)beta[c] : 0.0;
-  coef[c] = (float)(g * invstd);
-  coef[C + c] = (float)(b - mean * g * invstd);
-  coef[2 * C + c] = (float)mean;
-  coef[3 * C + c] = (float)invstd;
-  if (pass_stats) {
-    pass_stats[c] = (float)mean;
-    pass_stats[C + c] = (float)var;
-  }
-}
-
-__device__ __forceinline__ void bn_bwd_coef_body(const double* __restrict__ sums, int nrep, double count, int C,
-                                                 const float* __restrict__ gamma, const float* __restrict__ coef,
-                                                 float* __restrict__ xf, float* __restrict__ dgamma,
-                                                 float* __restrict__ dbeta, float param_grad_scale, int accumulate_pg,
-                                                 const int bx) {
-  const int c = bx * NT + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  replica_sums(sums, nrep, C, c, &s1, &s2);
-  const float mu = coef[2 * C + c], is_ = coef[3 * C + c];
-  const float a = (gamma ? gamma[c] : 1.f) * is_;
-  const float c1 = (float)(s1 / count), c2 = (float)(s2 / count);
-  xf[c] = a;
-  xf[C + c] = a * (c2 * is_ * mu - c1);
-  xf[2 * C + c] = -a * c2 * is_;
-  xf[3 * C + c] = coef[c];
-  xf[4 * C + c] = coef[C + c];
-  if (accumulate_pg) {
-    if (dbeta) unsafeAtomicAdd(&dbeta[c], (float)(s1 * param_grad_scale));
-    if (dgamma) unsafeAtomicAdd(&dgamma[c], (float)(s2 * param_grad_scale));
-  } else {
-    if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
-    if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
+    p0 += (long)RP * ROWS;
+    if (p0 >= pe) break;
+    rs.init(p0, pe, pr, RP, true);
+    rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
+    rs.load(x + p0 * ldx + cg * 8, ldx, xr);
+    if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
   }
 }
 
@@ -466,56 +468,36 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
   if (dgamma) dgamma[c] = (float)sums[C + c];
 }
 
-__device__ __forceinline__ void colsum_body(const bf16_t* __restrict__ x, long P, int C,
-                                                    int ld, double* __restrict__ sums,
-                                                    long pix_per_block, const int bx) {
-  SSA_DYN_LDS(float, sh);
-  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
-  const int t = threadIdx.x;
-  const bool active = t < NA;
-  const int cg = t % VC, pr = t / VC;
-  float s[8], q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-  const long p0 = bx * pix_per_block;
-  const long p1 = min(P, p0 + pix_per_block);
-  if (active) {
-  #pragma unroll 4
-  for (long p = p0 + pr; p < p1; p += RP) {
-      float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(x + p * ld + cg * 8), f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += f[j];
-    }
-  }
-  block_reduce_2x8(s, q, cg, C, active, sums, sh, bx);
-}
 
-
-// ---- group-aware wrappers (group.h): one launch for all the BatchNorm calls of a depth level
+// ---- group-aware wrappers (group.h): one launch for all the BatchNorm calls of a depth level.  ROWS = pixel rows
+// per thread and chunk (one instantiation per pass and build, so that a level's problems share a launch)
+template <int ROWS>
 struct BnStatsK {
   struct Args { const bf16_t* x; double* sums; long P, ppb; int C, ld; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_stats_body(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx);
+    bn_stats_body<ROWS>(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx, true);
   }
 };
+template <int ROWS>
 struct ColsumK {
   struct Args { const bf16_t* x; double* sums; long P, ppb; int C, ld; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    colsum_body(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx);
+    bn_stats_body<ROWS>(a.x, a.P, a.C, a.ld, a.sums, a.ppb, bx, false);
   }
 };
+template <int ROWS>
 struct BnApplyK {
   struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const float* scale; const float* shift;
                 const float* post; long P, pix_per_img, ppb; int ldx, ldr, ldz, C, relu; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_apply_body(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.scale, a.shift, a.relu, a.post,
-                  a.pix_per_img, a.ppb, bx);
+    bn_apply_body<ROWS>(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.scale, a.shift, a.relu, a.post,
+                        a.pix_per_img, a.ppb, bx);
   }
 };
+template <int ROWS>
 struct BnApplyTrainK {
   struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const double* sums; const float* gamma;
                 const float* beta; float* running_mean; float* running_var; long* nbt; float* coef;
@@ -523,21 +505,23 @@ struct BnApplyTrainK {
                 int ldx, ldr, ldz, C, nrep, relu; float momentum, eps; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_apply_train_body(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.gamma,
-                        a.beta, a.running_mean, a.running_var, a.nbt, a.momentum, a.eps, a.coef,
-                        a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, bx);
+    bn_apply_train_body<ROWS>(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.gamma,
+                              a.beta, a.running_mean, a.running_var, a.nbt, a.momentum, a.eps, a.coef,
+                              a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, bx);
   }
 };
+template <int ROWS>
 struct BnBwdReduceK {
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
                 const float* post; double* sums; const float* mscale; const float* mshift;
                 long P, pix_per_img, ppb; int ldx, lddz, ldz, C, relu, nrep; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_bwd_reduce_body(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
-                       a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, bx);
+    bn_bwd_reduce_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
+                             a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, bx);
   }
 };
+template <int ROWS>
 struct BnBwdApplyK {
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; bf16_t* dx; bf16_t* dres;
                 const float* gamma; const float* mean; const float* invstd; const double* sums;
@@ -546,27 +530,9 @@ struct BnBwdApplyK {
                 float param_grad_scale; int accumulate_pg; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_bwd_apply_body(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
-                      a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
-                      a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, bx);
-  }
-};
-
-struct BnCoefTrainK {
-  struct Args { const double* sums; const float* gamma; const float* beta; float* coef; float* pass_stats;
-                double count; int C, nrep; float eps; };
-  static constexpr int NT = ::NT;
-  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_coef_train_body(a.sums, a.nrep, a.count, a.C, a.gamma, a.beta, a.eps, a.coef, a.pass_stats, bx);
-  }
-};
-struct BnBwdCoefK {
-  struct Args { const double* sums; const float* gamma; const float* coef; float* xf; float* dgamma; float* dbeta;
-                double count; int C, nrep; float param_grad_scale; int accumulate_pg; };
-  static constexpr int NT = ::NT;
-  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_bwd_coef_body(a.sums, a.nrep, a.count, a.C, a.gamma, a.coef, a.xf, a.dgamma, a.dbeta, a.param_grad_scale,
-                     a.accumulate_pg, bx);
+    bn_bwd_apply_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
+                            a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
+                            a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, bx);
   }
 };
 
@@ -606,50 +572,59 @@ __global__ __launch_bounds__(128) void bn_update_running_kernel(const BnUpdateJo
   j.running_var[c] = (float)rv;
 }
 
-struct Grid { int blocks; long ppb; };
-// rows_per_thread pixel rows per thread; at most max_blocks workgroups (the
-// reducing kernels end in 2C fp64 atomics per workgroup, so they get a lower cap).
+struct Grid { int blocks; long ppb; int rows; };
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
-Grid plan_grid(long P, int C, int rows_per_thread = -1, long max_blocks = 16384) {
-  static const int apply_rows = env_int("SSA_BN_ROWS_APPLY", 8);   // grouped launches: 2 -> 8 rows, -1.2 ms/step
-  if (rows_per_thread < 0) rows_per_thread = apply_rows;
+int norm_rows(int r) { return r <= 2 ? 2 : (r <= 4 ? 4 : 8); }
+// `rows` pixel rows per thread (2, 4 or 8: the instantiation) in one chunk per workgroup; at most max_blocks
+// workgroups, beyond which a workgroup walks several chunks (the reducing kernels end in 2C fp64 atomics per
+// workgroup, so they get a lower cap).
+Grid plan_grid(long P, int C, int rows, long max_blocks = 16384) {
   const int VC = C >> 3;
   const int RP = active_threads(VC) / VC;
-  long ppb = (long)RP * rows_per_thread;
+  const long chunk = (long)RP * rows;
+  long ppb = chunk;
   long blocks = (P + ppb - 1) / ppb;
   if (blocks > max_blocks) {
-    blocks = max_blocks;
-    ppb = (P + blocks - 1) / blocks;
-    ppb = (ppb + RP - 1) / RP * RP;
+    ppb = (P + max_blocks - 1) / max_blocks;
+    ppb = (ppb + chunk - 1) / chunk * chunk;
     blocks = (P + ppb - 1) / ppb;
   }
   if (blocks < 1) blocks = 1;
-  return {(int)blocks, ppb};
+  return {(int)blocks, ppb, rows};
 }
+// Rows per thread of the three pass families (SSA_BN_ROWS_*: 2 / 4 / 8; sweep in profiles/r04_notes.md)
+int apply_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_APPLY", 4)); return r; }
+int bwd_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_BWD", 4)); return r; }
+int reduce_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_REDUCE", 8)); return r; }
 Grid plan_reduce_grid(long P, int C) {
-  static const int rows = env_int("SSA_BN_ROWS_REDUCE", 8), cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
-  return plan_grid(P, C, rows, cap);
+  static const int cap = env_int("SSA_BN_REDUCE_BLOCKS", 2048);
+  return plan_grid(P, C, reduce_rows(), cap);
 }
+// submit<K<ROWS>> for the planned row count
+#define SSA_BN_SUBMIT(K, g, a, lds, s)                                              \
+  ((g).rows == 2 ? ssa::submit<K<2>>(K<2>::Args a, (g).blocks, 1, lds, s)            \
+   : (g).rows == 4 ? ssa::submit<K<4>>(K<4>::Args a, (g).blocks, 1, lds, s)          \
+                   : ssa::submit<K<8>>(K<8>::Args a, (g).blocks, 1, lds, s))
 
 bool ok_c(int C) { return C > 0 && C % 8 == 0 && C <= 2048; }
+bool ok_p(long P) { return P > 0 && P < (1L << 31); }     // pixel indices are 32-bit inside a chunk
 
 }  // namespace
 
 extern "C" {
 
 int ssa_bn_stats(const void* x, long P, int C, int ld, double* sums, int zero_sums, void* stream) {
-  if (!x || !sums || !ok_c(C) || ld % 8 || P <= 0) return SSA_EINVAL;
+  if (!x || !sums || !ok_c(C) || !ok_p(P) || ld % 8) return SSA_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (zero_sums) {
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
-  BnStatsK::Args a{(const bf16_t*)x, sums, P, g.ppb, C, ld};
-  return ssa::submit<BnStatsK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s);
+  return SSA_BN_SUBMIT(BnStatsK, g, ({(const bf16_t*)x, sums, P, g.ppb, C, ld}), 16 * (NT + 1) * sizeof(float), s);
 }
 
 int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma, const float* beta,
@@ -668,12 +643,11 @@ int ssa_bn_finalize(const double* sums, double count, int C, const float* gamma,
 int ssa_bn_apply(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz, long P,
                  int C, const float* scale, const float* shift, int relu, const float* post,
                  long pix_per_img, void* stream) {
-  if (!x || !z || !scale || !shift || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8))
+  if (!x || !z || !scale || !shift || !ok_c(C) || !ok_p(P) || ldx % 8 || ldz % 8 || (residual && ldr % 8))
     return SSA_EINVAL;
-  const Grid g = plan_grid(P, C);
-  BnApplyK::Args a{(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, scale, shift, post, P, pix_per_img,
-                   g.ppb, ldx, ldr, ldz, C, relu};
-  return ssa::submit<BnApplyK>(a, g.blocks, 1, 0, (hipStream_t)stream);
+  const Grid g = plan_grid(P, C, apply_rows());
+  return SSA_BN_SUBMIT(BnApplyK, g, ({(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, scale, shift, post, P,
+                                      pix_per_img, g.ppb, ldx, ldr, ldz, C, relu}), 0, (hipStream_t)stream);
 }
 
 int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, void* z, int ldz,
@@ -682,29 +656,14 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
                        long* num_batches_tracked, float momentum, float eps, float* coef,
                        float* pass_stats, int relu, const float* post, long pix_per_img,
                        void* stream) {
-  if (!x || !z || !sums || !coef || !ok_c(C) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
+  if (!x || !z || !sums || !coef || !ok_c(C) || !ok_p(P) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
-  const Grid g = plan_grid(P, C);
-  BnApplyTrainK::Args a{(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta, running_mean,
-                        running_var, num_batches_tracked, coef, pass_stats, post, count, P, pix_per_img, g.ppb,
-                        ldx, ldr, ldz, C, nrep, relu, momentum, eps};
-  return ssa::submit<BnApplyTrainK>(a, g.blocks, 1, 2 * C * sizeof(float), (hipStream_t)stream);
-}
-
-int ssa_bn_coef_train(const double* sums, int nrep, double count, int C, const float* gamma, const float* beta,
-                      float eps, float* coef, float* pass_stats, void* stream) {
-  if (!sums || !coef || C <= 0 || nrep < 1 || count <= 0) return SSA_EINVAL;
-  BnCoefTrainK::Args a{sums, gamma, beta, coef, pass_stats, count, C, nrep, eps};
-  return ssa::submit<BnCoefTrainK>(a, (C + NT - 1) / NT, 1, 0, (hipStream_t)stream);
-}
-
-int ssa_bn_bwd_coef(const double* sums, int nrep, double count, int C, const float* gamma, const float* coef,
-                    float* xf, float* dgamma, float* dbeta, float param_grad_scale, int accumulate_param_grads,
-                    void* stream) {
-  if (!sums || !coef || !xf || C <= 0 || nrep < 1 || count <= 0) return SSA_EINVAL;
-  BnBwdCoefK::Args a{sums, gamma, coef, xf, dgamma, dbeta, count, C, nrep, param_grad_scale, accumulate_param_grads};
-  return ssa::submit<BnBwdCoefK>(a, (C + NT - 1) / NT, 1, 0, (hipStream_t)stream);
+  const Grid g = plan_grid(P, C, apply_rows());
+  return SSA_BN_SUBMIT(BnApplyTrainK, g, ({(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta,
+                                           running_mean, running_var, num_batches_tracked, coef, pass_stats, post, count,
+                                           P, pix_per_img, g.ppb, ldx, ldr, ldz, C, nrep, relu, momentum, eps}),
+                       2 * C * sizeof(float), (hipStream_t)stream);
 }
 
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {
@@ -720,7 +679,7 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
                       long P, int C, const float* mean, const float* invstd, int relu,
                       const float* post, long pix_per_img, double* sums, int nrep, int zero_sums,
                       const float* mask_scale, const float* mask_shift, void* stream) {
-  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || (relu && !z && !mask_scale) || nrep < 1 ||
+  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale) || nrep < 1 ||
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
@@ -730,9 +689,9 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
-  BnBwdReduceK::Args a{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums, mask_scale,
-                       mask_shift, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep};
-  return ssa::submit<BnBwdReduceK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s);
+  return SSA_BN_SUBMIT(BnBwdReduceK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums,
+                                          mask_scale, mask_shift, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep}),
+                       16 * (NT + 1) * sizeof(float), s);
 }
 
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
@@ -741,15 +700,15 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
                      double count, int relu, const float* post, long pix_per_img, float* dgamma,
                      float* dbeta, float param_grad_scale, const float* mask_scale,
                      const float* mask_shift, int accumulate_param_grads, void* stream) {
-  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || (relu && !z && !mask_scale) || nrep < 1 ||
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale) || nrep < 1 ||
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
-  const Grid g = plan_grid(P, C);
-  BnBwdApplyK::Args a{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres, gamma, mean,
-                      invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift, count, P, pix_per_img, g.ppb,
-                      ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale, accumulate_param_grads};
-  return ssa::submit<BnBwdApplyK>(a, g.blocks, 1, 5 * C * sizeof(float), (hipStream_t)stream);
+  const Grid g = plan_grid(P, C, bwd_rows());
+  return SSA_BN_SUBMIT(BnBwdApplyK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres,
+                                         gamma, mean, invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift, count, P,
+                                         pix_per_img, g.ppb, ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale,
+                                         accumulate_param_grads}), 7 * C * sizeof(float), (hipStream_t)stream);
 }
 
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {
@@ -762,14 +721,14 @@ int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, v
 
 int ssa_colsum_bf16(const void* x, long P, int C, int ld, float* out, double* scratch2c,
                     void* stream) {
-  if (!x || !out || !scratch2c || !ok_c(C) || ld % 8) return SSA_EINVAL;
+  if (!x || !out || !scratch2c || !ok_c(C) || !ok_p(P) || ld % 8) return SSA_EINVAL;
   if (ssa::group_state().depth > 0) return SSA_EINVAL;   // three dependent launches: not inside a group bracket
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(scratch2c, 0, sizeof(double) * 2 * C, s);
   if (e != hipSuccess) return (int)e;
   const Grid g = plan_reduce_grid(P, C);
-  ColsumK::Args a{(const bf16_t*)x, scratch2c, P, g.ppb, C, ld};
-  if (int rc = ssa::submit<ColsumK>(a, g.blocks, 1, 16 * (NT + 1) * sizeof(float), s)) return rc;
+  if (int rc = SSA_BN_SUBMIT(ColsumK, g, ({(const bf16_t*)x, scratch2c, P, g.ppb, C, ld}), 16 * (NT + 1) * sizeof(float), s))
+    return rc;
   hipLaunchKernelGGL(d2f_kernel, dim3((C + 127) / 128), dim3(128), 0, s, scratch2c, out, C);
   SSA_LAUNCH_CHECK();
   return SSA_OK;

@@ -23,6 +23,9 @@ __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { em
 __device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
 template <int VM, int LGKM = 0> __device__ __forceinline__ void ssa_wait_vm_barrier() { __syncthreads(); }
 __device__ __forceinline__ void ssa_glds16_untracked(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
+__device__ __forceinline__ void ssa_glds16_untracked_sv(const void* sbase, unsigned voff, void* lds_dst) {
+  emu::global_load_lds16(reinterpret_cast<const unsigned char*>(sbase) + voff, lds_dst);
+}
 #else
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
@@ -50,6 +53,14 @@ __device__ __forceinline__ void ssa_glds16_untracked(const void* gsrc, void* lds
   const unsigned base = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(base) : "memory");
+}
+// The same with the address as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): a kernel that
+// issues many DMAs per stage keeps one VGPR per fragment and one scalar add per stage instead of a 64-bit scalar
+// address computation per DMA (which the compiler hoists and then spills).
+__device__ __forceinline__ void ssa_glds16_untracked_sv(const void* sbase, unsigned voff, void* lds_dst) {
+  const unsigned base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(base) : "memory");
 }
 // LDS written by some lanes of a wave, read by others of the SAME wave: the hardware runs a wave's LDS operations
 // in order, so only the compiler must not move the reads above the writes (the emulation runs lanes as

@@ -1,35 +1,29 @@
 // Persistent, software-pipelined halo-tile convolution for the 3x3 stride-1 convs of the HRNetV2 trunk
-// (network/hrnetv2.py:31-66), forward and data gradient, with the neighbouring BatchNorm
-// passes folded into its operand staging and its epilogue (gfx950 / MI355X).
+// (network/hrnetv2.py:31-66), forward and data gradient (gfx950 / MI355X).
 //
-// conv_tile.hip gives every 128-pixel tile a workgroup of its own: ~1,500 workgroups per trunk level,
-// each of which lives ~10 us (load the halo, DMA 54 KB of filter from L2, barrier, 0.7-3 us of MFMA,
-// LDS-staged epilogue, 128 fp64 atomics) -- 0.13 of the HBM roof (profiles/r02_trace_step.txt).  Here
-//   * a workgroup is PERSISTENT over a strip of consecutive tiles of one (problem, n-block group):
-//     the grid is ~2 workgroups per CU whatever the problem sizes (strip length from the level's total
-//     work, ssa_conv_tile_strip);
-//   * the 48-channel instantiation keeps its whole filter slice (54 KB) resident in LDS for the strip
-//     -- one DMA burst per workgroup instead of one per tile (81 MB -> 27 MB of L2 traffic per level);
-//     the 96-channel-chunk instantiation (96/192/384 channels) streams 3-tap filter stages through a
-//     double buffer as ONE continuous DMA pipeline across chunks and tiles (stage s+1 is in flight during
-//     the MFMAs of stage s, also over a tile boundary);
-//   * the next tile's (or channel chunk's) halo is fetched into registers during the current MFMAs;
-//   * the epilogue is wave-local: a wave owns one 32-pixel tile row x all output channels of the
-//     workgroup, stages its accumulators through its own LDS slice and stores whole pixel rows -- no
-//     block barrier between the MFMAs and the stores; BatchNorm statistics stay in registers over the
-//     strip: one set of fp64 atomics per workgroup instead of one per tile.
-//   * XCD-aware order: consecutive strips (which share halo rows) and the n-block groups of a strip
-//     (which share the whole halo) go to the same XCD's L2.
-//
-// Folded BatchNorm (what network/hrnetv2.py:53-64 runs as separate passes over HBM):
-//   XF 1 (forward): the staged input is  relu(scale[c] * x + shift[c])  -- bn1 + ReLU applied while conv2's
-//         halo passes through registers; bn1's output is never written.
-//   XF 2 (backward): the staged input is BatchNorm+ReLU's data gradient computed from (dz, x):
-//         dy = A[c] * (m ? dz : 0) + B0[c] + C0[c] * x,  m = [ma[c] * x + mb[c] > 0]  (table from
-//         ssa_bn_bwd_coef) -- bn1's backward apply while conv1's data-gradient halo is staged.
-//   epilogue (as conv_tile.hip): BatchNorm batch statistics of the bf16 outputs; aux_mode 1: + residual
-//         gradient; aux_mode 2: bn1's backward sums from (x tile, dz).
-// Out-of-image halo pixels are zero AFTER the transform (the conv pads the transformed activation).
+// A workgroup (4 waves) is PERSISTENT over a strip of consecutive 128-pixel tiles (4 rows x 32) of one (problem,
+// pair of 32-channel n-blocks); the input is processed in chunks of 48 channels: a "unit" = one (tile, chunk) =
+// the 6x34-pixel halo image of 48 channels staged in LDS once + 54 MFMAs (32x32x16) per wave.
+//   * the 48-channel instantiation keeps its whole filter slice (54 KB) RESIDENT in LDS for the strip;
+//     the streamed instantiation (96 / 192 / 384 channels) runs the filter as ONE continuous LDS-DMA pipeline over
+//     stages of 3 taps (18 KB) through a ring of THREE buffers: stage s issues the DMAs of stage s + 2 and ends in
+//     `s_waitcnt vmcnt(K) ; s_barrier` with K counted, so two stages of filter are in flight while one is multiplied
+//     (round 3 had two buffers behind __syncthreads(), whose vmcnt(0) made every 18-MFMA stage wait one L2 round
+//     trip for its successor AND for the next halo's loads: 8,600 clocks per unit against 2,200 of MFMA);
+//   * the next unit's halo is fetched into registers behind the current unit's DMAs, and no barrier of the loop
+//     waits for it (the barriers wait on LDS traffic only: `s_waitcnt lgkmcnt(0) ; s_barrier`);
+//   * the MFMA operands are SWAPPED (filter fragment as A, pixel fragment as B): the accumulator of a lane then
+//     holds one PIXEL's channels (4 consecutive channels per register quad), so the epilogue packs to bf16 in
+//     registers, completes 16-byte pieces with v_permlane32_swap and stores straight to HBM -- no LDS staging, no
+//     barrier between the MFMAs and the stores (round 3: 64 ds_write_b16 + re-read per lane and tile, 1,300-2,000
+//     clocks per unit);
+//   * BatchNorm statistics of the bf16-rounded outputs stay in registers over the strip (a lane owns 16 channels
+//     per n-block), are reduced over the 32 pixel lanes with DPP adds once per strip and leave as one fp64 atomic
+//     per channel and workgroup;
+//   * XCD-aware order: consecutive strips (which share halo rows) and the n-block groups of a strip (which share
+//     the whole halo) go to the same XCD's L2.
+// Epilogues (as conv_tile.hip): BatchNorm batch statistics; aux_mode 1: + residual gradient; aux_mode 2: bn1's
+// backward sums from (x tile, dz).  (Round 3's BatchNorm-in-the-staging fold was measured slower and is gone.)
 #include "common.h"
 #include "group.h"
 #include <stdlib.h>
@@ -39,21 +33,16 @@ namespace {
 
 constexpr int kStatReplicas = 8;   // as conv_tile.hip (ssa_bn_stat_replicas)
 
-// -DSSA_TILE_TIMING (tools/tilebench.py --timing; never in the product build): wave 0 of workgroup 0 writes
-// s_memtime stamps of every phase of its first iterations to the `coef` pointer (reinterpreted, XF 0 / aux 0 only)
 #ifdef SSA_TILE_TIMING
-// (stamps go to spare LDS during the loop -- a global store would sit in the vmcnt queue every barrier waits for -- and
-// are copied out at the end)
 #define SSA_STAMP(k) do { if (tdbg && it < 24) { tlds[it * 8 + (k)] = (long)__builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define SSA_STAMP(k) do { } while (0)
 #endif
 
 struct TilePArgs {
-  const bf16_t* x; const bf16_t* x2; const float* xf;     // staged input; XF 2: the layer input x; transform table
-  const uint4* wfrag; const float* bias; bf16_t* y; double* stats;
+  const bf16_t* x; const uint4* wfrag; bf16_t* y; double* stats;
   const bf16_t* aux; const float* coef;                    // epilogue tile; [4][Cout] table of aux_mode 2
-  int ldx, ldx2, Cin, ldy, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux, aux_mode;
+  int ldx, Cin, ldy, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux;
   int total_tiles, tiles_per_wg, ngroups, nwg;
   int variant;
 };
@@ -64,66 +53,101 @@ __device__ __forceinline__ int xcd_order(int v, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
-template <int NB, int TPC, int CST>
-__device__ __forceinline__ void stage_filter(const uint4* __restrict__ wfrag, int nb0, int nb_total,
-                                             int ksteps_total, int csteps_total, int cc, int tap0,
-                                             unsigned char* dst, int wave, int lane) {
-  constexpr int PER_NB = TPC * CST;
-  constexpr int NFRAG = NB * PER_NB;
-#pragma unroll
-  for (int f = 0; f < (NFRAG + 3) / 4; ++f) {
-    const int fi = f * 4 + wave;               // wave-uniform
-    if (fi < NFRAG) {
-      const int nb = fi / PER_NB, rem = fi - nb * PER_NB;
-      const int tl = rem / CST, j = rem - tl * CST;
-      const int nbg = min(nb0 + nb, nb_total - 1);   // n-blocks past the end re-read the last one (never stored)
-      const uint4* src = wfrag + ((long)nbg * ksteps_total + (tap0 + tl) * csteps_total + cc * CST + j) * 64 + lane;
-      ssa_glds16(src, dst + (size_t)fi * 1024);
-    }
-  }
+// workgroup barrier that waits for this wave's LDS traffic only (vector-memory loads / stores / DMAs stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+#ifdef SSA_EMU
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
-template <int CK, int NB, int TPC, int XF, int AUXM>
+// lanes l and l + 32 exchange: afterwards (a, b) of a lane < 32 = (own a, partner's a), of a lane >= 32 =
+// (partner's b, own b)   [v_permlane32_swap: rows 2-3 of the first operand <-> rows 0-1 of the second]
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+#ifdef SSA_EMU
+  const unsigned pa = __shfl_xor(a, 32, 64), pb = __shfl_xor(b, 32, 64);
+  if ((threadIdx.x & 63) < 32) b = pa; else a = pb;
+#else
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+#endif
+}
+
+// sum over the 32 lanes of this lane's half of the wave; valid in lanes 16-31 / 48-63 afterwards
+__device__ __forceinline__ float half_sum32(float v) {
+#ifdef SSA_EMU
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#else
+#define SSA_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
+  SSA_DPP_ADD(0xB1, 0xf);     // quad_perm [1,0,3,2]
+  SSA_DPP_ADD(0x4E, 0xf);     // quad_perm [2,3,0,1]
+  SSA_DPP_ADD(0x141, 0xf);    // row_half_mirror
+  SSA_DPP_ADD(0x140, 0xf);    // row_mirror
+  SSA_DPP_ADD(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+#undef SSA_DPP_ADD
+  return v;
+#endif
+}
+
+template <int NB, int TPC, int AUXM>
 struct ConvTileP {
   static constexpr bool AUX = AUXM != 0;
   typedef TilePArgs Args;
   static constexpr int NT = 256;
+  static constexpr int CK = 48;                      // input channels per unit
   static constexpr int TW = 32, TH = 4;
   static constexpr int HW_ = TW + 2, HH_ = TH + 2, NPIX = HH_ * HW_;
   static constexpr int PSB = CK * 2 + 16;            // halo pixel stride (bytes): an odd number of 16-byte slots
   static constexpr int CP = CK / 8;                  // 16-byte pieces per halo pixel
   static constexpr int NA = (NT / CP) * CP;          // staging threads: thread t always moves channel group t % CP
   static constexpr int RP = NA / CP;                 // halo pixels per staging pass
-  static constexpr int IT = (NPIX + RP - 1) / RP;
+  static constexpr int IT = (NPIX + RP - 1) / RP;    // halo loads per thread and unit
   static constexpr int CST = CK / 16;
   static constexpr int TAPS = 9, NSTAGE = TAPS / TPC, STAGE_KS = TPC * CST;
-  static constexpr int STAGE_BYTES = NB * STAGE_KS * 1024;
+  static constexpr int NFRAG = NB * STAGE_KS;        // 1 KiB filter fragments per stage
+  static constexpr int ND = (NFRAG + 3) / 4;         // DMAs per wave and stage (the last ones duplicated: every wave issues ND)
+  static constexpr int STAGE_BYTES = NFRAG * 1024;
   static constexpr bool RESIDENT = NSTAGE == 1;      // the whole filter slice stays in LDS for the strip
-  static constexpr int NBUF = RESIDENT ? 1 : 2;
-  static constexpr int HALO_BYTES = (NPIX * PSB + 1023) / 1024 * 1024;
-  static constexpr int LDC = NB * 32 + 8;            // wave-local output staging: row stride (elements)
-  static constexpr int CPR = NB * 4;                 // 16-byte pieces per staged output row
-  static constexpr int CS_WAVE = 32 * LDC * 2;       // bytes per wave
-  static constexpr int EIT = 32 * CPR / 64;          // output pieces per lane and tile
+  static constexpr int NBUF = RESIDENT ? 1 : 3;
+  static constexpr int HALO_RAW = NPIX * PSB;
+  static constexpr int HALO_BYTES = (HALO_RAW + 1023) / 1024 * 1024;
+  static constexpr int NAUX = NB * 2;                // 16-byte epilogue pieces per lane and tile
   static constexpr size_t LDS = (size_t)HALO_BYTES + (size_t)NBUF * STAGE_BYTES;
   static_assert(NSTAGE * TPC == TAPS, "taps per stage must divide the tap count");
-  static_assert(4 * CS_WAVE <= (RESIDENT ? HALO_BYTES : STAGE_BYTES), "output staging does not fit");
+  static_assert(HALO_BYTES - HALO_RAW >= 2 * NB * 32 * 4, "coefficient table of aux_mode 2 does not fit behind the halo image");
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(4 * 2 * NB * 32 * 4 <= HALO_RAW, "statistics reduction does not fit");
+
+  // DMA of one filter stage into dst: ND fragments per wave.  voff[f] = byte offset of this lane's piece of fragment
+  // f of the wave relative to the stage's first k-step (tile- and stage-invariant, computed once per workgroup);
+  // sbase = the filter + the stage's (chunk, first tap) k-step offset (wave-uniform)
+  static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND],
+                                                      unsigned char* dst, int wave) {
+#pragma unroll
+    for (int f = 0; f < ND; ++f) {
+      const int fi = min(f * 4 + wave, NFRAG - 1);      // wave-uniform; the last fragments are issued twice
+      ssa_glds16_untracked_sv(sbase, voff[f], dst + (size_t)fi * 1024);
+    }
+  }
 
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
     const bf16_t* __restrict__ x = a.x;
-    const bf16_t* __restrict__ x2 = a.x2;
-    const float* __restrict__ xf = a.xf;
     const uint4* __restrict__ wfrag = a.wfrag;
-    const float* __restrict__ bias = a.bias;
     bf16_t* __restrict__ y = a.y;
     double* __restrict__ stats = a.stats;
     const bf16_t* __restrict__ aux = a.aux;
     const float* __restrict__ coef = a.coef;
-    const int ldx = a.ldx, ldx2 = a.ldx2, Cin = a.Cin, ldy = a.ldy, H = a.H, W = a.W, Cout = a.Cout;
+    const int ldx = a.ldx, Cin = a.Cin, ldy = a.ldy, H = a.H, W = a.W, Cout = a.Cout;
     const int nb_total = a.nb_total, tiles_x = a.tiles_x, tiles_y = a.tiles_y, ldaux = a.ldaux;
     SSA_DYN_LDS(unsigned char, smem);
     unsigned char* Bs = smem + HALO_BYTES;
+    float* ctab = reinterpret_cast<float*>(smem + HALO_RAW);      // aux_mode 2: [2][NB*32] mask scale / shift
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -136,18 +160,17 @@ struct ConvTileP {
     const int csteps_total = Cin / 16;
     const int ksteps_total = TAPS * csteps_total;
     const int n_iter = (t_end - t_begin) * nchunk;
+    if (n_iter <= 0) return;
 
     // ---- staging role of this thread: channel group cg of halo pixels prow, prow + RP, ...
     const bool stg = tid < NA;
     const int cg = tid % CP, prow = tid / CP;
     uint4 v[IT];
-    uint4 v2[XF == 2 ? IT : 1];
     unsigned okmask = 0;                       // bit i: piece i lies inside the image
-
     // tile-invariant part of this thread's pieces: halo coordinates (hy << 8 | hx, 0xffff: no such piece) and the
     // element offset relative to the tile's first halo pixel; invalid lanes load the tile's own first pixel instead
-    // (always inside the image) and are zeroed at staging time -- ten unconditional loads issue back to back
-    int hyx[IT], rel[IT], rel2[XF == 2 ? IT : 1];
+    // (always inside the image) and are zeroed at staging time -- the loads issue back to back, unconditionally
+    int hyx[IT], rel[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int pix = prow + i * RP;
@@ -155,9 +178,8 @@ struct ConvTileP {
       const bool have = stg && pix < NPIX;
       hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
       rel[i] = (hy * W + hx) * ldx;
-      if constexpr (XF == 2) rel2[i] = (hy * W + hx) * ldx2;
     }
-    const int rel_c = (W + 1) * ldx, rel2_c = (W + 1) * ldx2;     // halo pixel (1, 1) = output pixel (0, 0) of the tile
+    const int rel_c = (W + 1) * ldx;                               // halo pixel (1, 1) = output pixel (0, 0) of the tile
     // tile walk without divisions: (image, tile row, tile column) of the tile whose halo is fetched next
     int f_b, f_ty, f_tx;
     {
@@ -171,14 +193,12 @@ struct ConvTileP {
     auto fetch = [&](int cc) {
       const int x0 = f_tx * TW, y0 = f_ty * TH;
       const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + cc * CK + cg * 8;
-      const bf16_t* xb2 = XF == 2 ? x2 + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx2 + cc * CK + cg * 8 : nullptr;
       okmask = 0;
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
-        if constexpr (XF == 2) v2[i] = *reinterpret_cast<const uint4*>(xb2 + (ok ? rel2[i] : rel2_c));
         okmask |= (ok ? 1u : 0u) << i;
       }
     };
@@ -188,131 +208,77 @@ struct ConvTileP {
         if (++*ty == tiles_y) { *ty = 0; ++*b; }
       }
     };
-    // registers -> (transform) -> LDS halo image of channel chunk cc
-    auto stage = [&](int cc) {
-      if constexpr (XF == 1) {
-        float sc[8], sh[8];
-        if (stg) {
-          const float* t0 = xf + cc * CK + cg * 8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { sc[j] = t0[j]; sh[j] = t0[Cin + j]; }
-        }
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-          if ((okmask >> i) & 1u) {
-            float f[8];
-            unpack8(v[i], f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
-            v[i] = pack8(f);
-          } else {
-            v[i] = make_uint4(0, 0, 0, 0);
-          }
-        }
-      } else if constexpr (XF == 0) {
-#pragma unroll
-        for (int i = 0; i < IT; ++i)
-          if (!((okmask >> i) & 1u)) v[i] = make_uint4(0, 0, 0, 0);
-      } else if constexpr (XF == 2) {
-        // two passes of four channels: 20 coefficient registers live at a time instead of 40
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float cA[4], cB[4], cC[4], ma[4], mb[4];
-          if (stg) {
-            const float* t0 = xf + cc * CK + cg * 8 + h * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              cA[j] = t0[j]; cB[j] = t0[Cin + j]; cC[j] = t0[2 * Cin + j]; ma[j] = t0[3 * Cin + j]; mb[j] = t0[4 * Cin + j];
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < IT; ++i) {
-            if ((okmask >> i) & 1u) {
-              const unsigned g0 = h ? v[i].z : v[i].x, g1 = h ? v[i].w : v[i].y;
-              const unsigned x0_ = h ? v2[i].z : v2[i].x, x1_ = h ? v2[i].w : v2[i].y;
-              float g[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
-                            __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
-              const float xv[4] = {__uint_as_float(x0_ << 16), __uint_as_float(x0_ & 0xffff0000u),
-                                   __uint_as_float(x1_ << 16), __uint_as_float(x1_ & 0xffff0000u)};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float gm = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
-                g[j] = gm * cA[j] + (cB[j] + cC[j] * xv[j]);
-              }
-              const unsigned p0 = f2bf_pair(g[0], g[1]), p1 = f2bf_pair(g[2], g[3]);
-              if (h) { v[i].z = p0; v[i].w = p1; } else { v[i].x = p0; v[i].y = p1; }
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < IT; ++i)
-          if (!((okmask >> i) & 1u)) v[i] = make_uint4(0, 0, 0, 0);
-      }
+    // registers -> LDS halo image (pixels outside the image are zero)
+    auto stage = [&]() {
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int pix = prow + i * RP;
-        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = v[i];
+        const uint4 o = ((okmask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
+        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = o;
       }
     };
 
-    // ---- epilogue role of this lane: output piece (row idx / CPR of the wave's tile row, channel group lane % CPR)
-    const int ecp = lane % CPR;
-    const int en = nb0 * 32 + ecp * 8;                  // first output channel of this lane's pieces
-    const bool en_ok = en < Cout;
-    float S[AUXM == 1 ? 1 : 8], Q[AUXM == 1 ? 1 : 8];  // statistics of this lane's 8 channels over the strip
+    // ---- epilogue role of this lane: pixel (wave's tile row, column lane & 31); after the exchange it holds, per
+    // n-block nb and m = 0, 1, the 16-byte piece of channels  nb0*32 + nb*32 + 16*m + 8*(lane >> 5) .. + 7
+    const int eh = lane >> 5, epx = lane & 31;
+    const int ech = nb0 * 32 + 8 * eh;                            // first channel of piece (nb 0, m 0)
+    float S[AUXM == 1 ? 1 : NAUX * 8], Q[AUXM == 1 ? 1 : NAUX * 8];  // statistics of this lane's channels over the strip
 #pragma unroll
-    for (int j = 0; j < (AUXM == 1 ? 1 : 8); ++j) { S[j] = 0.f; Q[j] = 0.f; }
-    float ema[AUXM == 2 ? 8 : 1], emb[AUXM == 2 ? 8 : 1];
+    for (int j = 0; j < (AUXM == 1 ? 1 : NAUX * 8); ++j) { S[j] = 0.f; Q[j] = 0.f; }
     if constexpr (AUXM == 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { ema[j] = 0.f; emb[j] = 0.f; }
-      if (en_ok) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { ema[j] = coef[en + j]; emb[j] = coef[Cout + en + j]; }
+      for (int i = tid; i < 2 * NB * 32; i += NT) {
+        const int k = i / (NB * 32), c = nb0 * 32 + i - k * (NB * 32);
+        ctab[i] = c < Cout ? coef[k * Cout + c] : 0.f;
       }
     }
-    uint4 auxv[AUX ? EIT : 1];
+    uint4 auxv[AUX ? NAUX : 1];
 
-    const int a_off = (wave * HW_ + (lane & 31)) * PSB + (lane >> 5) * 16;   // MFMA A rows = the wave's tile row
+    const int a_off = (wave * HW_ + (lane & 31)) * PSB + (lane >> 5) * 16;   // pixel fragment rows = the wave's tile row
 
     f32x16_t acc[NB];
 
-    if (n_iter <= 0) return;
 #ifdef SSA_TILE_TIMING
-    long* tdbg = (AUXM == 0 && XF == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
+    long* tdbg = (AUXM == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
     long* tlds = reinterpret_cast<long*>(smem + LDS);          // 1.5 KB past the kernel's own LDS (the timing build asks for it)
 #endif
-    // ---- prologue: first halo into registers, the filter (slice / first stage) on its way into LDS
+    // ---- prologue: the filter (slice / first two stages) on its way into LDS, first halo into registers
+    unsigned voff[ND];
+    {
+      constexpr int PER_NB = TPC * CST;
+#pragma unroll
+      for (int f = 0; f < ND; ++f) {
+        const int fi = min(f * 4 + wave, NFRAG - 1);
+        const int nb = fi / PER_NB, rem = fi - nb * PER_NB;
+        const int tl = rem / CST, j = rem - tl * CST;
+        const int nbg = min(nb0 + nb, nb_total - 1);       // n-blocks past the end re-read the last one (never stored)
+        voff[f] = (unsigned)(((nbg * ksteps_total + tl * csteps_total + j) * 64 + lane) * 16);
+      }
+    }
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(wfrag);
+    auto stage_base = [&](int cc_, int tap0) { return wbytes + (long)(tap0 * csteps_total + cc_ * CST) * 1024; };
+    stage_filter(stage_base(0, 0), voff, Bs, wave);
+    if constexpr (!RESIDENT) stage_filter(stage_base(0, TPC), voff, Bs + STAGE_BYTES, wave);
     fetch(0);
-    stage_filter<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, 0, 0, Bs, wave, lane);
     int s = 0;                                         // global filter-stage counter (streamed variant)
     int cc = 0;
     for (int it = 0; it < n_iter; ++it) {
-      // everyone is past the barrier that ended the previous iteration: the halo image is free
+      // everyone is past the barrier that ended the previous unit's MFMAs: the halo image is free
       SSA_STAMP(0);
-      stage(cc);
+      if constexpr (RESIDENT) {
+        if (it > 0) lds_barrier();
+      }
+      stage();
       SSA_STAMP(1);
-      __syncthreads();                                 // halo image + filter stage s (slice) landed
+      if (it == 0) ssa_wait_vm_barrier<RESIDENT ? 0 : ND, 0>();   // + the filter slice / stage 0 landed
+      else lds_barrier();                                         // halo image visible
       SSA_STAMP(2);
       const bool last_chunk = cc + 1 == nchunk;
       int ccn = cc + 1;
-      if (last_chunk) { ccn = 0; advance(&f_b, &f_ty, &f_tx); }
-      if (it + 1 < n_iter) fetch(ccn);                 // next halo: in flight during this iteration's MFMAs
+      if (last_chunk) { ccn = 0; if (it + 1 < n_iter) advance(&f_b, &f_ty, &f_tx); }
       const int b_ = c_b, x0 = c_tx * TW, y0 = c_ty * TH;
-      if constexpr (AUX) {
-        if (last_chunk) {
-          const bf16_t* ab = aux + (long)b_ * H * W * ldaux;
-#pragma unroll
-          for (int i = 0; i < EIT; ++i) {
-            const int idx = lane + i * 64;
-            const int row = idx / CPR;
-            const int oy = y0 + wave, ox = x0 + row;
-            auxv[i] = make_uint4(0, 0, 0, 0);
-            if (oy < H && ox < W && en_ok)
-              auxv[i] = *reinterpret_cast<const uint4*>(ab + ((long)oy * W + ox) * ldaux + en);
-          }
-        }
-      }
+      const int oy = y0 + wave, ox = x0 + epx;
+      const bool pix_ok = oy < H && ox < W;
+      const long opix = (long)b_ * H * W + (long)min(oy, H - 1) * W + min(ox, W - 1);
       if (cc == 0) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -323,18 +289,28 @@ struct ConvTileP {
 #pragma unroll
       for (int st = 0; st < NSTAGE; ++st) {
         if constexpr (!RESIDENT) {
-          // stage s+1 of the continuous filter stream: the next taps, the next chunk, or the next tile's first stage
-          const bool more = st + 1 < NSTAGE || it + 1 < n_iter;
-          if (more) {
-            const int cc1 = st + 1 < NSTAGE ? cc : ccn;
-            const int tap1 = st + 1 < NSTAGE ? (st + 1) * TPC : 0;
-            stage_filter<NB, TPC, CST>(wfrag, nb0, nb_total, ksteps_total, csteps_total, cc1, tap1,
-                                       Bs + ((s + 1) & 1) * STAGE_BYTES, wave, lane);
+          // stage s + 2 of the continuous filter stream (past the end of the strip: a stage nobody reads)
+          const int cc2 = st == 0 ? cc : ccn;
+          const int tap2 = ((st + 2) % NSTAGE) * TPC;
+          stage_filter(stage_base(cc2, tap2), voff, Bs + ((s + 2) % 3) * STAGE_BYTES, wave);
+        }
+        if (st == 0) {
+          // next unit's halo (the last unit re-reads its own: the count of loads in flight stays fixed) and this
+          // tile's epilogue operand: in flight during the MFMAs, behind the DMAs
+          fetch(ccn);
+          if constexpr (AUX) {
+            if (last_chunk) {
+              const bf16_t* ab = aux + opix * ldaux + ech;
+#pragma unroll
+              for (int p = 0; p < NAUX; ++p) {
+                const int cb = ech + (p >> 1) * 32 + (p & 1) * 16;
+                auxv[p] = *reinterpret_cast<const uint4*>(ab + (cb < Cout ? (p >> 1) * 32 + (p & 1) * 16 : 0));
+              }
+            }
           }
         }
-        const unsigned char* Bc = Bs + (RESIDENT ? 0 : (s & 1) * STAGE_BYTES) + lane * 16;
+        const unsigned char* Bc = Bs + (RESIDENT ? 0 : (s % 3) * STAGE_BYTES) + lane * 16;
         // fragments of k-step ksl + RD - 1 are read while the MFMAs of k-step ksl run: a ring of RD register sets
-        // (left to itself the compiler reads two k-steps, waits, multiplies, and only then reads the next two)
         constexpr int RD = 4;
         bf16x8_t ra[RD], rb[RD][NB];
         auto rd_frag = [&](int ksl) {
@@ -352,71 +328,83 @@ struct ConvTileP {
         for (int ksl = 0; ksl < STAGE_KS; ++ksl) {
           if (ksl + RD - 1 < STAGE_KS) rd_frag(ksl + RD - 1);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[nb] = ssa_mfma32(ra[ksl % RD], rb[ksl % RD][nb], acc[nb]);
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = ssa_mfma32(rb[ksl % RD][nb], ra[ksl % RD], acc[nb]);   // D[channel][pixel]
           if (ksl + RD - 1 < STAGE_KS) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NB, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
         }
         if (st == 0) SSA_STAMP(4);
-        __syncthreads();        // stage s+1 landed; buffer s & 1 (and, after the last stage, the halo image) is free
+        if constexpr (!RESIDENT) {
+          // stage s + 1 landed (everything issued before this stage's own DMAs / loads); buffer s % 3 and, after the
+          // last stage, the halo image are free
+          if (st == 0) {
+            if (AUX && last_chunk) ssa_wait_vm_barrier<ND + IT + NAUX, 0>();
+            else ssa_wait_vm_barrier<ND + IT, 0>();
+          } else {
+            ssa_wait_vm_barrier<ND, 0>();
+          }
+          ++s;
+        }
         if (st == 0) SSA_STAMP(5);
-        if constexpr (!RESIDENT) ++s;
       }
       SSA_STAMP(6);
       if (last_chunk) {
-        // ---- wave-local epilogue: (+bias) -> bf16 -> this wave's LDS slice -> whole pixel rows
-        // slice: inside the halo image (resident filter) / inside the filter buffer just consumed (streamed)
-        unsigned char* Cw = (RESIDENT ? smem : Bs + ((s - 1) & 1) * STAGE_BYTES) + wave * CS_WAVE;
-        bf16_t* Cs = reinterpret_cast<bf16_t*>(Cw);
+        // ---- epilogue in registers: bf16 pairs -> 16-byte pieces by lane exchange -> HBM
+        bf16_t* yb = y + opix * ldy + ech;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const int col = nb * 32 + (lane & 31);
-          const int n = nb0 * 32 + col;
-          const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+          unsigned w[4][2];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            Cs[row * LDC + col] = f2bf(acc[nb][r] + bv);
+          for (int g = 0; g < 4; ++g) {
+            float f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = acc[nb][g * 4 + j];
+            w[g][0] = f2bf_pair(f[0], f[1]);
+            w[g][1] = f2bf_pair(f[2], f[3]);
           }
-        }
-        ssa_wave_sync();
-        const int oy = y0 + wave;
-        bf16_t* yb = y + ((long)b_ * H * W + (long)oy * W) * ldy + en;
 #pragma unroll
-        for (int i = 0; i < EIT; ++i) {
-          const int idx = lane + i * 64;
-          const int row = idx / CPR;
-          const int ox = x0 + row;
-          const bool ok = oy < H && ox < W && en_ok;
-          uint4 o = *reinterpret_cast<const uint4*>(Cw + row * (LDC * 2) + ecp * 16);
-          if constexpr (AUX) {
-            float f[8], xv[8];
-            unpack8(o, f);
-            unpack8(auxv[i], xv);
+          for (int m = 0; m < 2; ++m) {
+            swap32(w[2 * m][0], w[2 * m + 1][0]);
+            swap32(w[2 * m][1], w[2 * m + 1][1]);
+            uint4 o = make_uint4(w[2 * m][0], w[2 * m][1], w[2 * m + 1][0], w[2 * m + 1][1]);
+            const int p = nb * 2 + m;
+            const int coff = nb * 32 + m * 16;
+            const bool ok = pix_ok && ech + coff < Cout;
             if constexpr (AUXM == 1) {
+              float f[8], xv[8];
+              unpack8(o, f);
+              unpack8(auxv[p], xv);
 #pragma unroll
               for (int j = 0; j < 8; ++j) f[j] += xv[j];
               o = pack8(f);
             } else if constexpr (AUXM == 2) {
+              float f[8], xv[8];
+              unpack8(o, f);
+              unpack8(auxv[p], xv);
+              const float4 ma0 = *reinterpret_cast<const float4*>(ctab + coff + 8 * eh);
+              const float4 ma1 = *reinterpret_cast<const float4*>(ctab + coff + 8 * eh + 4);
+              const float4 mb0 = *reinterpret_cast<const float4*>(ctab + NB * 32 + coff + 8 * eh);
+              const float4 mb1 = *reinterpret_cast<const float4*>(ctab + NB * 32 + coff + 8 * eh + 4);
+              const float ma[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
+              const float mb[8] = {mb0.x, mb0.y, mb0.z, mb0.w, mb1.x, mb1.y, mb1.z, mb1.w};
               if (ok) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float gm = (xv[j] * ema[j] + emb[j]) > 0.f ? f[j] : 0.f;
-                S[j] += gm;
-                Q[j] += gm * xv[j];
+                for (int j = 0; j < 8; ++j) {
+                  const float gm = (xv[j] * ma[j] + mb[j]) > 0.f ? f[j] : 0.f;
+                  S[p * 8 + j] += gm;
+                  Q[p * 8 + j] += gm * xv[j];
+                }
               }
-              }
-            }
-          } else {
-            if (stats != nullptr && ok) {
-              float f[8];
-              unpack8(o, f);
+            } else {
+              if (stats != nullptr && ok) {
+                float f[8];
+                unpack8(o, f);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) { S[j] += f[j]; Q[j] += f[j] * f[j]; }
+                for (int j = 0; j < 8; ++j) { S[p * 8 + j] += f[j]; Q[p * 8 + j] += f[j] * f[j]; }
+              }
             }
+            if (ok) *reinterpret_cast<uint4*>(yb + coff) = o;
           }
-          if (ok) *reinterpret_cast<uint4*>(yb + (long)ox * ldy) = o;
         }
-        if constexpr (RESIDENT) __syncthreads();       // the slices live in the halo image the next tile overwrites
       }
       SSA_STAMP(7);
       if (last_chunk) advance(&c_b, &c_ty, &c_tx);
@@ -427,25 +415,24 @@ struct ConvTileP {
     if (tdbg)
       for (int i = 0; i < 24 * 8; ++i) tdbg[i] = i < n_iter * 8 ? tlds[i] : 0;
 #endif
-    // ---- statistics of the strip: lanes -> wave -> workgroup -> one fp64 atomic per channel
-    if constexpr (AUXM == 1) return;          // residual add: no statistics (stats is NULL by contract)
-    if (stats != nullptr) {
+    // ---- statistics of the strip: 32 pixel lanes -> wave -> workgroup -> one fp64 atomic per channel
+    if constexpr (AUXM == 1) {
+      return;          // residual add: no statistics (stats is NULL by contract)
+    } else {
+      if (stats == nullptr) return;
 #pragma unroll
-      for (int off = CPR; off < 64; off <<= 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          S[j] += __shfl_xor(S[j], off, 64);
-          Q[j] += __shfl_xor(Q[j], off, 64);
-        }
-      }
-      __syncthreads();                                 // every wave is done with its LDS slice
+      for (int j = 0; j < NAUX * 8; ++j) { S[j] = half_sum32(S[j]); Q[j] = half_sum32(Q[j]); }
+      __syncthreads();                                 // every wave is done with the halo image / the filter DMAs
       float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][NB*32]
-      if (lane < CPR) {
+      if (epx == 31) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          red[(wave * 2 + 0) * NB * 32 + lane * 8 + j] = S[j];
-          red[(wave * 2 + 1) * NB * 32 + lane * 8 + j] = Q[j];
-        }
+        for (int p = 0; p < NAUX; ++p)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = (p >> 1) * 32 + (p & 1) * 16 + 8 * eh + j;
+            red[(wave * 2 + 0) * NB * 32 + c] = S[p * 8 + j];
+            red[(wave * 2 + 1) * NB * 32 + c] = Q[p * 8 + j];
+          }
       }
       __syncthreads();
       double* st = stats + (long)(strip % kStatReplicas) * 2 * Cout;
@@ -459,10 +446,8 @@ struct ConvTileP {
             qv += red[(w * 2 + 1) * NB * 32 + tid];
           }
           double sd = (double)sv, qd = (double)qv;
-          if constexpr (AUX) {
-            // aux_mode 2 accumulated sum(m*dz*x); the consumer wants sum(m*dz*xhat), xhat = (x - mean) * invstd
-            if constexpr (AUXM == 2) qd = (double)coef[3 * Cout + n] * (qd - (double)coef[2 * Cout + n] * sd);
-          }
+          // aux_mode 2 accumulated sum(m*dz*x); the consumer wants sum(m*dz*xhat), xhat = (x - mean) * invstd
+          if constexpr (AUXM == 2) qd = (double)coef[3 * Cout + n] * (qd - (double)coef[2 * Cout + n] * sd);
           atomicAdd(&st[n], sd);
           atomicAdd(&st[Cout + n], qd);
         }
@@ -471,14 +456,14 @@ struct ConvTileP {
   }
 };
 
-// The two instantiations a trunk level uses behind ONE kernel (as conv_tile.hip's ConvTileAny): 48 channels
-// (both n-blocks per workgroup, resident filter) and the streamed 96-channel-chunk one (96 / 192 / 384 channels).
-template <int XF, int AUXM>
+// The two instantiations a trunk level uses behind ONE kernel: 48 input channels (resident filter) and the streamed
+// one (96 / 192 / 384 input channels in chunks of 48), both two n-blocks (64 output channels) per workgroup.
+template <int AUXM>
 struct ConvTilePAny {
   typedef TilePArgs Args;
   static constexpr int NT = 256;
-  typedef ConvTileP<48, 2, 9, XF, AUXM> V0;
-  typedef ConvTileP<96, 1, 3, XF, AUXM> V1;
+  typedef ConvTileP<2, 9, AUXM> V0;
+  typedef ConvTileP<2, 3, AUXM> V1;
 #ifdef SSA_TILE_TIMING
   static constexpr size_t LDS = (V0::LDS > V1::LDS ? V0::LDS : V1::LDS) + 1536;
 #else
@@ -492,11 +477,11 @@ struct ConvTilePAny {
 
 static thread_local int g_strip_units = 0;     // work units (54 MFMAs per wave) per workgroup, 0 = per problem
 
-template <int XF, int AUXM>
+template <int AUXM>
 int launch_p(const ssa_conv_desc& d, const TilePArgs& a0, hipStream_t s) {
   TilePArgs a = a0;
-  const int nchunk = d.Cin == 48 ? 1 : d.Cin / 96;
-  const int NB = d.Cin == 48 ? 2 : 1;
+  const int nchunk = d.Cin / 48;
+  constexpr int NB = 2;
   a.variant = d.Cin == 48 ? 0 : 1;
   a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + 31) / 32;
@@ -509,13 +494,13 @@ int launch_p(const ssa_conv_desc& d, const TilePArgs& a0, hipStream_t s) {
     const long total = (long)a.total_tiles * a.ngroups * nchunk;
     units = (int)((total + 511) / 512);
   }
-  if (units > 16) units = 16;
+  if (units > 32) units = 32;
   int tpw = units / nchunk;
   if (tpw < 1) tpw = 1;
   const int nstrips = (a.total_tiles + tpw - 1) / tpw;
   a.tiles_per_wg = (a.total_tiles + nstrips - 1) / nstrips;
   a.nwg = ((a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg) * a.ngroups;
-  return ssa::submit<ConvTilePAny<XF, AUXM>>(a, a.nwg, 1, ConvTilePAny<XF, AUXM>::LDS, s);
+  return ssa::submit<ConvTilePAny<AUXM>>(a, a.nwg, 1, ConvTilePAny<AUXM>::LDS, s);
 }
 
 }  // namespace
@@ -533,39 +518,29 @@ int ssa_conv_tile_strip(int units) {
   return SSA_OK;
 }
 
-int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* x2, int ldx2, const float* xf,
-                      int xf_mode, const void* w_frag, const float* bias, void* y, double* stats,
-                      const void* aux, int ldaux, const float* coef, int aux_mode, void* stream) {
+int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias, void* y,
+                      double* stats, const void* aux, int ldaux, const float* coef, int aux_mode, void* stream) {
   if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
-  if (!ssa_conv2d_tile_p_supported(dp)) return SSA_EUNSUPPORTED;
+  if (!ssa_conv2d_tile_p_supported(dp) || bias) return SSA_EUNSUPPORTED;   // the trunk convs have no bias (hrnetv2.py:31-34)
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
     return SSA_EINVAL;
-  if (xf_mode < 0 || xf_mode > 2 || aux_mode < 0 || aux_mode > 2) return SSA_EINVAL;
-  if (xf_mode && (!xf || (reinterpret_cast<uintptr_t>(xf) & 15u))) return SSA_EINVAL;
-  if (xf_mode == 2 && (!x2 || ldx2 % 8 || (reinterpret_cast<uintptr_t>(x2) & 15u) ||
-                       (long)dp->H * dp->W * ldx2 >= (1L << 31)))
-    return SSA_EINVAL;
+  if (aux_mode < 0 || aux_mode > 2) return SSA_EINVAL;
   if (aux_mode && (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u))) return SSA_EINVAL;
   if (aux_mode == 2 && (!coef || !stats)) return SSA_EINVAL;
   if (aux_mode == 1 && stats) return SSA_EINVAL;
+  if (dp->ldy % 8) return SSA_EINVAL;
   const ssa_conv_desc& d = *dp;
   TilePArgs a;
-  a.x = (const bf16_t*)x; a.x2 = (const bf16_t*)x2; a.xf = xf; a.wfrag = (const uint4*)w_frag; a.bias = bias;
+  a.x = (const bf16_t*)x; a.wfrag = (const uint4*)w_frag;
   a.y = (bf16_t*)y; a.stats = stats; a.aux = (const bf16_t*)aux; a.coef = coef;
-  a.ldx = d.ldx; a.ldx2 = ldx2; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
-  a.ldaux = ldaux; a.aux_mode = aux_mode;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
+  a.ldaux = ldaux;
   a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = a.variant = 0;
   hipStream_t s = (hipStream_t)stream;
-  // instantiated combinations: every transform without an epilogue tile; the residual add with and without the
-  // BatchNorm-backward transform (conv1's data gradient); the BatchNorm-backward sums on a plain input (conv2's)
-  switch (aux_mode * 3 + xf_mode) {
-    case 0: return launch_p<0, 0>(d, a, s);
-    case 1: return launch_p<1, 0>(d, a, s);
-    case 2: return launch_p<2, 0>(d, a, s);
-    case 3: return launch_p<0, 1>(d, a, s);
-    case 5: return launch_p<2, 1>(d, a, s);
-    case 6: return launch_p<0, 2>(d, a, s);
-    default: return SSA_EUNSUPPORTED;
+  switch (aux_mode) {
+    case 0: return launch_p<0>(d, a, s);
+    case 1: return launch_p<1>(d, a, s);
+    default: return launch_p<2>(d, a, s);
   }
 }
 

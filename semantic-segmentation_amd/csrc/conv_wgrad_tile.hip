@@ -51,18 +51,10 @@ __device__ __forceinline__ bf16x8_t tr_read8(const unsigned char* p, int stride_
 
 struct WgradTileArgs {
   const bf16_t* x; const bf16_t* dy; float* partial;
-  const bf16_t* x2; const float* xf;       // XF 2: the BatchNorm layer's input (congruent with dy); transform table
-  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, n_parts, ldx2;
+  int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, n_parts;
 };
 
-// XF: BatchNorm folded into the operand staging (see conv_tile_p.hip).
-//   XF 1: the x operand is  relu(xf[0][ci] * x + xf[1][ci])  (zero outside the image) -- conv2's weight gradient reads
-//         bn1's INPUT and recomputes bn1 + ReLU on the fly, the activation itself is never stored;
-//   XF 2: the dy operand is BatchNorm+ReLU's data gradient  A*(m ? dz : 0) + B0 + C0*x2,  m = [ma*x2 + mb > 0]
-//         (table xf[5][Cout] from ssa_bn_bwd_coef; dy = dz, x2 = the layer's input) -- conv1's weight gradient without
-//         a materialised bn1 backward.
-// The transformed operand is staged with a fixed channel group per thread, so its coefficients are read once per tile.
-template <int CX, int MB, int NBW, int XF = 0>
+template <int CX, int MB, int NBW>
 struct ConvWgradTile {
   typedef WgradTileArgs Args;
   static constexpr int NT = 256;
@@ -72,9 +64,6 @@ struct ConvWgradTile {
   float* __restrict__ partial = a.partial;
   const int ldx = a.ldx, Cin = a.Cin, lddy = a.lddy, cout_pad = a.cout_pad, B = a.B, H = a.H, W = a.W;
   const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, tiles_per_wg = a.tiles_per_wg, n_parts = a.n_parts;
-  const bf16_t* __restrict__ x2 = a.x2;
-  const float* __restrict__ xf = a.xf;
-  const int ldx2 = a.ldx2;
   constexpr int TW = 32, TH = 4, HW_ = TW + 2, HH_ = TH + 2;
   constexpr int SX = tr_stride_bytes(CX * 2), SD = tr_stride_bytes(MB * 64);
   constexpr int HALO_BYTES = HH_ * HW_ * SX;
@@ -133,29 +122,9 @@ struct ConvWgradTile {
   const int t_begin = bx * tiles_per_wg;
   const int t_end = min(total_tiles, t_begin + tiles_per_wg);
   constexpr int XN = HH_ * HW_ * XP, DN = TH * TW * DP;
-  constexpr int XI = XF == 1 ? 1 : (XN + 255) / 256, DI = XF == 2 ? 1 : (DN + 255) / 256;
+  constexpr int XI = (XN + 255) / 256, DI = (DN + 255) / 256;
   uint4 xv[XI], dv[DI];
-  // transformed operand (XF): thread t always moves channel group t % pieces-per-pixel, pixels t / ppp + i * RP
-  constexpr int XNA = (256 / XP) * XP, XRP = XNA / XP, XQ = XF == 1 ? (HH_ * HW_ + XRP - 1) / XRP : 1;
-  constexpr int DNA = (256 / DP) * DP, DRP = DNA / DP, DQ = XF == 2 ? (TH * TW + DRP - 1) / DRP : 1;
-  uint4 xq[XQ], dq[DQ], dq2[DQ];
-  unsigned xmask = 0, dmask = 0;               // untransformed operands: bit i = piece i lies inside the image
-  unsigned qok = 0;                            // bit i: piece i of the transformed operand lies inside the image
-  const int xcg = tid % XP, xpr = tid / XP, dcg = tid % DP, dpr = tid / DP;
-  float* Tb = reinterpret_cast<float*>(smem + HALO_BYTES + TH * TW * SD);   // [2][CX] (XF 1) / [5][MB*32] (XF 2)
-  if constexpr (XF == 1) {
-    for (int i = tid; i < 2 * CX; i += 256) {
-      const int k = i / CX, c = i - k * CX;
-      Tb[i] = ci_base + c < Cin ? xf[k * Cin + ci_base + c] : 0.f;
-    }
-    __syncthreads();
-  } else if constexpr (XF == 2) {
-    for (int i = tid; i < 5 * MB * 32; i += 256) {
-      const int k = i / (MB * 32), c = i - k * (MB * 32);
-      Tb[i] = co0 + c < cout_pad ? xf[k * cout_pad + co0 + c] : 0.f;
-    }
-    __syncthreads();
-  }
+  unsigned xmask = 0, dmask = 0;               // bit i = piece i lies inside the image
   // tile-invariant part of every piece this thread moves: packed (row, column) inside the
   // tile, element offset relative to the tile origin, LDS byte offset (-1: no such piece).
   // Kept in registers when there are few pieces per thread (C <= 96); recomputed per tile
@@ -195,130 +164,41 @@ struct ConvWgradTile {
     const int x0 = tx_i * TW, y0 = ty_i * TH;
     const bf16_t* xb = x + ((long)b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + ci_base;
     const bf16_t* db = dy + ((long)b * H * W + (long)y0 * W + x0) * lddy + co0;
-    if constexpr (XF == 1) {
-      qok = 0;
+    // every lane loads (pieces outside the image read the tile's first output pixel and are zeroed when they
+    // are staged): a select on the loaded value made the compiler wait for each batch of loads inside this
+    // function -- the "prefetch" of the next tile then stalled for a full memory latency, twice per tile
+    xmask = 0;
 #pragma unroll
-      for (int i = 0; i < XQ; ++i) {
-        const int pix = xpr + i * XRP;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = tid < XNA && pix < HH_ * HW_ && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xq[i] = *reinterpret_cast<const uint4*>(xb + (ok ? (hy * W + hx) * ldx + xcg * 8 : (W + 1) * ldx));
-        qok |= (ok ? 1u : 0u) << i;
-      }
-    } else {
-      // every lane loads (pieces outside the image read the tile's first output pixel and are zeroed when they
-      // are staged): a select on the loaded value made the compiler wait for each batch of loads inside this
-      // function -- the "prefetch" of the next tile then stalled for a full memory latency, twice per tile
-      xmask = 0;
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        int rc, go, lo;
-        if constexpr (PRE) { rc = x_rc_[i]; go = x_go_[i]; lo = x_lo_[i]; } else { x_piece(i, &rc, &go, &lo); }
-        const int iy = y0 - 1 + (rc >> 8), ix = x0 - 1 + (rc & 255);
-        const bool ok = lo >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xv[i] = *reinterpret_cast<const uint4*>(xb + (ok ? go : (W + 1) * ldx));
-        xmask |= (ok ? 1u : 0u) << i;
-      }
+    for (int i = 0; i < XI; ++i) {
+      int rc, go, lo;
+      if constexpr (PRE) { rc = x_rc_[i]; go = x_go_[i]; lo = x_lo_[i]; } else { x_piece(i, &rc, &go, &lo); }
+      const int iy = y0 - 1 + (rc >> 8), ix = x0 - 1 + (rc & 255);
+      const bool ok = lo >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      xv[i] = *reinterpret_cast<const uint4*>(xb + (ok ? go : (W + 1) * ldx));
+      xmask |= (ok ? 1u : 0u) << i;
     }
-    if constexpr (XF == 2) {
-      const bf16_t* x2b = x2 + ((long)b * H * W + (long)y0 * W + x0) * ldx2 + co0;
-      qok = 0;
+    dmask = 0;
 #pragma unroll
-      for (int i = 0; i < DQ; ++i) {
-        const int pix = dpr + i * DRP;
-        const int ty = pix / TW, tx = pix - ty * TW;
-        const bool ok = tid < DNA && pix < TH * TW && y0 + ty < H && x0 + tx < W && co0 + dcg * 8 < cout_pad;
-        dq[i] = *reinterpret_cast<const uint4*>(db + (ok ? (ty * W + tx) * lddy + dcg * 8 : 0));
-        dq2[i] = *reinterpret_cast<const uint4*>(x2b + (ok ? (ty * W + tx) * ldx2 + dcg * 8 : 0));
-        qok |= (ok ? 1u : 0u) << i;
-      }
-    } else {
-      dmask = 0;
-#pragma unroll
-      for (int i = 0; i < DI; ++i) {
-        int rc, go, lo;
-        if constexpr (PRE) { rc = d_rc_[i]; go = d_go_[i]; lo = d_lo_[i]; } else { d_piece(i, &rc, &go, &lo); }
-        const bool ok = lo >= 0 && y0 + (rc >> 8) < H && x0 + (rc & 255) < W;
-        dv[i] = *reinterpret_cast<const uint4*>(db + (ok ? go : 0));
-        dmask |= (ok ? 1u : 0u) << i;
-      }
+    for (int i = 0; i < DI; ++i) {
+      int rc, go, lo;
+      if constexpr (PRE) { rc = d_rc_[i]; go = d_go_[i]; lo = d_lo_[i]; } else { d_piece(i, &rc, &go, &lo); }
+      const bool ok = lo >= 0 && y0 + (rc >> 8) < H && x0 + (rc & 255) < W;
+      dv[i] = *reinterpret_cast<const uint4*>(db + (ok ? go : 0));
+      dmask |= (ok ? 1u : 0u) << i;
     }
   };
   auto stage = [&]() {
-    if constexpr (XF == 1) {
-      float sc[8], sh[8];
-      if (tid < XNA) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = Tb[xcg * 8 + j]; sh[j] = Tb[CX + xcg * 8 + j]; }
-      }
-#pragma unroll
-      for (int i = 0; i < XQ; ++i) {
-        if ((qok >> i) & 1u) {
-          float f[8];
-          unpack8(xq[i], f);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * sc[j] + sh[j], 0.f);
-          xq[i] = pack8(f);
-        } else {
-          xq[i] = make_uint4(0, 0, 0, 0);
-        }
-        const int pix = xpr + i * XRP;
-        if (tid < XNA && pix < HH_ * HW_) *reinterpret_cast<uint4*>(Xs + pix * SX + xcg * 16) = xq[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < XI; ++i) {
-        int lo;
-        if constexpr (PRE) { lo = x_lo_[i]; } else { int rc, go; x_piece(i, &rc, &go, &lo); }
-        if (lo >= 0) *reinterpret_cast<uint4*>(Xs + lo) = ((xmask >> i) & 1u) ? xv[i] : make_uint4(0, 0, 0, 0);
-      }
+    for (int i = 0; i < XI; ++i) {
+      int lo;
+      if constexpr (PRE) { lo = x_lo_[i]; } else { int rc, go; x_piece(i, &rc, &go, &lo); }
+      if (lo >= 0) *reinterpret_cast<uint4*>(Xs + lo) = ((xmask >> i) & 1u) ? xv[i] : make_uint4(0, 0, 0, 0);
     }
-    if constexpr (XF == 2) {
-      // two passes of four channels (20 coefficient registers live at a time)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float cA[4], cB[4], cC[4], ma[4], mb[4];
-        if (tid < DNA) {
-          const float* t0 = Tb + dcg * 8 + h * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            cA[j] = t0[j]; cB[j] = t0[MB * 32 + j]; cC[j] = t0[2 * MB * 32 + j]; ma[j] = t0[3 * MB * 32 + j];
-            mb[j] = t0[4 * MB * 32 + j];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < DQ; ++i) {
-          if ((qok >> i) & 1u) {
-            const unsigned g0 = h ? dq[i].z : dq[i].x, g1 = h ? dq[i].w : dq[i].y;
-            const unsigned u0 = h ? dq2[i].z : dq2[i].x, u1 = h ? dq2[i].w : dq2[i].y;
-            float g[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
-                          __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
-            const float xv_[4] = {__uint_as_float(u0 << 16), __uint_as_float(u0 & 0xffff0000u),
-                                  __uint_as_float(u1 << 16), __uint_as_float(u1 & 0xffff0000u)};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float gm = (xv_[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
-              g[j] = gm * cA[j] + (cB[j] + cC[j] * xv_[j]);
-            }
-            const unsigned p0 = f2bf_pair(g[0], g[1]), p1 = f2bf_pair(g[2], g[3]);
-            if (h) { dq[i].z = p0; dq[i].w = p1; } else { dq[i].x = p0; dq[i].y = p1; }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < DQ; ++i) {
-        const int pix = dpr + i * DRP;
-        if (tid < DNA && pix < TH * TW)
-          *reinterpret_cast<uint4*>(Ds + pix * SD + dcg * 16) = ((qok >> i) & 1u) ? dq[i] : make_uint4(0, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < DI; ++i) {
-        const int piece = tid + i * 256;
-        if (piece < DN)
-          *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = ((dmask >> i) & 1u) ? dv[i] : make_uint4(0, 0, 0, 0);
-      }
+    for (int i = 0; i < DI; ++i) {
+      const int piece = tid + i * 256;
+      if (piece < DN)
+        *reinterpret_cast<uint4*>(Ds + (piece / DP) * SD + (piece % DP) * 16) = ((dmask >> i) & 1u) ? dv[i] : make_uint4(0, 0, 0, 0);
     }
   };
   if (t_begin < t_end) fetch(t_begin);
@@ -413,21 +293,18 @@ constexpr size_t wgrad_tile_lds(int cx, int mb) {
   return (size_t)6 * 34 * tr_stride_bytes(cx * 2) + (size_t)128 * tr_stride_bytes(mb * 64);
 }
 
-struct XfArgs { int mode; const float* xf; const void* x2; int ldx2; };
-
-template <int CX, int MB, int NBW, int XF = 0>
+template <int CX, int MB, int NBW>
 int launch(const ssa_conv_desc& d, const Plan& p, const void* x, const void* dy, int lddy, int cout_pad,
-           int G, int tiles_per_wg, float* partial, hipStream_t s, const XfArgs& xa = XfArgs{0, nullptr, nullptr, 0}) {
-  constexpr size_t lds = wgrad_tile_lds(CX, MB) + (XF == 1 ? 2 * CX * 4 : XF == 2 ? 5 * MB * 32 * 4 : 0);
+           int G, int tiles_per_wg, float* partial, hipStream_t s) {
+  constexpr size_t lds = wgrad_tile_lds(CX, MB);
   static_assert(lds <= 160 * 1024, "does not fit in LDS");
   WgradTileArgs a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
-  a.x2 = (const bf16_t*)xa.x2; a.xf = xa.xf; a.ldx2 = xa.ldx2;
   a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
   a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = tiles_per_wg; a.n_parts = p.n_parts;
   // (Measured and rejected, profiles/r02_notes.md call P: the 48- and 96-channel instantiations behind one
   // kernel, as conv_tile.hip's ConvTileAny -- no gain here, a flush's launches are 60-160 us each.)
-  return ssa::submit<ConvWgradTile<CX, MB, NBW, XF>>(a, G, p.n_parts * p.co_parts, lds, s);
+  return ssa::submit<ConvWgradTile<CX, MB, NBW>>(a, G, p.n_parts * p.co_parts, lds, s);
 }
 
 bool shape_ok(const ssa_conv_desc* d) {
@@ -479,29 +356,6 @@ int ssa_conv2d_wgrad_tile(const ssa_conv_desc* dp, const void* x, const void* dy
       if (p.cx == 96) return launch<96, 3, 9>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
       return launch<192, 6, 6>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
   }
-}
-
-int ssa_conv2d_wgrad_tile_xf(const ssa_conv_desc* dp, const void* x, const void* dy, int lddy, int cout_pad,
-                             int nsplit, float* partial, int xf_mode, const float* xf, const void* x2, int ldx2,
-                             void* stream) {
-  if (xf_mode == 0) return ssa_conv2d_wgrad_tile(dp, x, dy, lddy, cout_pad, nsplit, partial, stream);
-  Plan p;
-  if (!dp || !x || !dy || !partial || nsplit < 1 || !xf || (xf_mode != 1 && xf_mode != 2)) return SSA_EINVAL;
-  if (!shape_ok(dp) || !make_plan(dp->Cin, cout_pad, &p) || lddy % 8) return SSA_EUNSUPPORTED;
-  if (p.cx != 48 && p.cx != 96) return SSA_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15u) return SSA_EINVAL;
-  if (xf_mode == 2 && (!x2 || ldx2 % 8 || (reinterpret_cast<uintptr_t>(x2) & 15u))) return SSA_EINVAL;
-  const ssa_conv_desc& d = *dp;
-  const long tiles = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
-  const int tpw = (int)((tiles + nsplit - 1) / nsplit);
-  hipStream_t s = (hipStream_t)stream;
-  const XfArgs xa{xf_mode, xf, x2, ldx2};
-  if (p.cx == 48) {
-    if (xf_mode == 1) return launch<48, 2, 14, 1>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s, xa);
-    return launch<48, 2, 14, 2>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s, xa);
-  }
-  if (xf_mode == 1) return launch<96, 3, 9, 1>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s, xa);
-  return launch<96, 3, 9, 2>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s, xa);
 }
 
 }  // extern "C"

@@ -60,7 +60,7 @@ _SIGS = {
     "ssa_bn_stat_replicas": ([], c_int),
     "ssa_conv2d_tile_p_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv_tile_strip": ([c_int], c_int),
-    "ssa_conv2d_tile_p": ([POINTER(ConvDesc), _P, _P, c_int, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
+    "ssa_conv2d_tile_p": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
     "ssa_conv2d_halo_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
@@ -68,7 +68,6 @@ _SIGS = {
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_tile_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_tile": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
-    "ssa_conv2d_wgrad_tile_xf": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P], c_int),
     "ssa_conv2d_wgrad_head_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_head": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, c_int, _P], c_int),
@@ -78,8 +77,6 @@ _SIGS = {
     "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_int, c_double, _P, _P, _P, _P,
                             _P, c_float, c_float, _P, _P, c_int, _P, c_long, _P], c_int),
     "ssa_bn_update_running_batched": ([_P, c_int, c_int, _P], c_int),
-    "ssa_bn_coef_train": ([_P, c_int, c_double, c_int, _P, _P, c_float, _P, _P, _P], c_int),
-    "ssa_bn_bwd_coef": ([_P, c_int, c_double, c_int, _P, _P, _P, _P, _P, c_float, c_int, _P], c_int),
     "ssa_pack_filters_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_pack_tile_channels": ([c_int, c_int], c_int),
     "ssa_conv2d_dgrad_s2": ([c_int] * 9 + [_P, _P, _P, _P, _P], c_int),

@@ -422,8 +422,12 @@ class _GradArena:
                 c[2] = c[1]
 
     def abandon(self):
+        """After a backward pass that raised: forget its half-filled slices AND the bookkeeping the next pass's
+        exchange boundaries are derived from (otherwise this rank's first exchange would fire after a different
+        number of layers than on the other ranks and the reduce_range sizes would no longer match across ranks)."""
         self.armed = False
-        _FLUSH_NEXT[0] = _WGRAD_FLUSH_FIRST
+        _SINCE_REDUCE[0] = 0
+        join_wgrads()                 # the side stream's launches of the abandoned pass are ordered before what follows
         self.chunks = []
         self.slots = {}
         self.late = []
@@ -433,7 +437,6 @@ class _GradArena:
         try:
             flush_wgrads()
             _SINCE_REDUCE[0] = 0
-            _FLUSH_NEXT[0] = _WGRAD_FLUSH_FIRST
             if _GRAD_SINK[0] is not None and self.slots:
                 with _on_wgrad_stream():
                     self.reduce_completed()
@@ -521,8 +524,8 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
     _note(2.0 * P * d.Cout * d.Cin * d.KH * d.KW,
           _conv_bytes(P, d.Cin, P, d.Cout, (d.KH, d.KW), 4 if d.out_f32 else 2) + (2.0 * P * d.Cout if mode else 0.0))
     L = lib()
-    if not halo and tile_p_supported(d):
-        check(L.ssa_conv2d_tile_p(ctypes.byref(d), _p(x), None, 0, None, 0, _p(wfrag), _p(bias), _p(y), _p(stats),
+    if not halo and bias is None and tile_p_supported(d):
+        check(L.ssa_conv2d_tile_p(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats),
                                   _p(aux), ldaux, _p(coef), mode, _s()), "ssa_conv2d_tile_p")
     elif mode:
         check(L.ssa_conv2d_tile_aux(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _p(aux), ldaux,
@@ -541,37 +544,17 @@ def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs
 _TILE_P = os.environ.get("SSA_TILE_P", "1") != "0"
 _TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "500"))      # most workgroups a grouped level may launch (< 2 per CU)
-# bn1 folded into conv2's operand staging / conv1's gradients (BasicBlockGroupFn).  Measured on MI355X (profiles/
-# r03_notes.md, calls A and E): 32 BnApplyTrain + 32 BnBwdApply launches less (-1.1 ms), but the staging transforms sit on
-# the critical path of latency-bound kernels (+5 us per conv2 launch, +15 us per conv1 data gradient, +0.6 ms in the
-# weight-gradient kernels) and the two coefficient launches per level cost 0.4 ms: 26.6 ms per step against 25.8 ms
-# with the BatchNorm passes materialised.  Kept, tested, off.
-_BLOCK_FOLD = os.environ.get("SSA_BLOCK_FOLD", "0")      # "0" off, "1" forward and backward, "2" forward only (tests set bools)
-
-
-def _fold_mode():
-    v = _BLOCK_FOLD
-    return 2 if str(v) == "2" else (1 if v not in ("0", "", 0, False, None) else 0)
-
 
 def tile_p_supported(d):
     return _TILE_P and bool(lib().ssa_conv2d_tile_p_supported(ctypes.byref(d)))
 
 
-def _tile_p_units(d):
-    """Work of one problem in filter passes over a 128-pixel tile (54 MFMAs per wave)."""
-    tiles = d.B * ((d.W + 31) // 32) * ((d.H + 3) // 4)
-    nb = (d.Cout + 31) // 32
-    if d.Cin == 48:
-        return tiles * ((nb + 1) // 2)
-    return tiles * nb * (d.Cin // 96)
-
-
 def _tile_p_wgs(d, units):
-    """Workgroups ssa_conv2d_tile_p launches for this problem at `units` per workgroup (mirror of launch_p)."""
+    """Workgroups ssa_conv2d_tile_p launches for this problem at `units` (one 128-pixel tile x one 48-channel chunk
+    of the input x two n-blocks: 54 MFMAs per wave) per workgroup (mirror of launch_p, csrc/conv_tile_p.hip)."""
     tiles = d.B * ((d.W + 31) // 32) * ((d.H + 3) // 4)
     nb = (d.Cout + 31) // 32
-    groups, nchunk = ((nb + 1) // 2, 1) if d.Cin == 48 else (nb, d.Cin // 96)
+    groups, nchunk = (nb + 1) // 2, d.Cin // 48
     tpw = max(1, units // nchunk)
     nstrips = -(-tiles // tpw)
     tpw = -(-tiles // nstrips)
@@ -588,8 +571,8 @@ def tile_strip(descs):
     if not ds:
         yield
         return
-    units = 16
-    for u in range(1, 17):
+    units = 32
+    for u in range(1, 33):
         if sum(_tile_p_wgs(d, u) for d in ds) <= _TILE_P_WGS:
             units = u
             break
@@ -599,17 +582,6 @@ def tile_strip(descs):
         yield
     finally:
         L.ssa_conv_tile_strip(0)
-
-
-def _tile_p(d, x, wfrag, bias, stats, xf=None, xf_mode=0, x2=None, ldx2=0, aux=None, ldaux=0, coef=None, aux_mode=0):
-    """One launch (possibly queued) of the persistent halo-tile conv; see include/semseg_hip.h."""
-    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=ACT_DTYPE, device=x.device)
-    P = d.B * d.Ho * d.Wo
-    extra = (2.0 * P * d.Cin if xf_mode == 2 else 0.0) + (2.0 * P * d.Cout if aux_mode else 0.0)
-    _note(2.0 * P * d.Cout * d.Cin * 9, _conv_bytes(P, d.Cin, P, d.Cout, (3, 3)) + extra)
-    check(lib().ssa_conv2d_tile_p(ctypes.byref(d), _p(x), _p(x2), ldx2, _p(xf), xf_mode, _p(wfrag), _p(bias), _p(y),
-                                  _p(stats), _p(aux), ldaux, _p(coef), aux_mode, _s()), "ssa_conv2d_tile_p")
-    return y
 
 
 # conv output data_ptr -> (BN partial sums [nrep][2][C], nrep): handed from the conv epilogue to
@@ -736,16 +708,7 @@ _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel sta
 # flush every 16 / 32 / 64 / 128 / 256 layers / at the end only = 23.93 / 23.39 / 23.11 / 22.94 / 22.75 / 23.32 ms.
 _WGRAD_SIDE = os.environ.get("SSA_WGRAD_STREAM", "1") != "0"
 _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "256" if _WGRAD_SIDE else "100000"))
-# SSA_WGRAD_FLUSH_MIN < SSA_WGRAD_FLUSH_AT: every flush halves the interval of the next one down to that minimum, so
-# that little is left queued when backward ends (the remainder runs with nothing to hide behind: ~1 ms of exposed
-# weight-gradient kernels at the end of the step).  Measured (profiles/r03_notes.md, call Y): 256 -> 32: 22.78 / 22.91 ms,
-# 256 -> 64: 22.63, 256 -> 16: 22.92 against 22.44 / 22.49 without -- the small flushes cost more than the shorter tail
-# saves.  Default: no decay.
-_WGRAD_FLUSH_MIN = int(os.environ.get("SSA_WGRAD_FLUSH_MIN", "100000"))
-# SSA_WGRAD_FLUSH_FIRST: interval of the FIRST flush of a backward pass (the head's large weight gradients are queued
-# within its first ~25 layers)
-_WGRAD_FLUSH_FIRST = int(os.environ.get("SSA_WGRAD_FLUSH_FIRST", "0")) or _WGRAD_FLUSH_AT
-_FLUSH_NEXT = [_WGRAD_FLUSH_FIRST]
+# (Measured and removed, profiles/r03_notes.md calls Y, Z: a decaying flush interval and an early first flush.)
 # ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
 # range while backward goes on (a step queues ~640 layers: three exchanges, the last one short)
 _DDP_FLUSH_AT = int(os.environ.get("SSA_DDP_FLUSH_AT", "256"))
@@ -754,14 +717,13 @@ _WGRAD_Q = []
 
 class _WJob:
     __slots__ = ("x", "ldx", "geom_in", "dy", "lddy", "cout_pad", "geom_out", "k", "stride", "pad", "dil",
-                 "Cout", "Cin_real", "target", "accumulate", "kind", "nsplit", "ws", "desc", "xf_mode", "xf", "x2", "ldx2")
+                 "Cout", "Cin_real", "target", "accumulate", "kind", "nsplit", "ws", "desc")
 
 
 def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, target, accumulate):
     j = _WJob()
     j.x, j.ldx, j.geom_in, j.dy, j.lddy, j.cout_pad, j.geom_out = x, ldx, geom_in, dy, lddy, cout_pad, geom_out
     j.k, j.stride, j.pad, j.dil, j.Cout, j.Cin_real, j.target, j.accumulate = k, stride, pad, dil, Cout, Cin_real, target, accumulate
-    j.xf_mode, j.xf, j.x2, j.ldx2 = 0, None, None, 0
     return j
 
 
@@ -779,14 +741,7 @@ def _run_wgrad_jobs(jobs, strip):
         nsplit, ws = ctypes.c_int(0), ctypes.c_size_t(0)
         al = j.x.data_ptr() % 16 == 0 and j.dy.data_ptr() % 16 == 0
         d.cfg = -1
-        if j.xf_mode:
-            # an operand is a folded BatchNorm pass (BasicBlockGroupFn): only the halo-staged kernel computes it
-            d.cfg = strip
-            assert al and j.lddy % 8 == 0, "folded weight-gradient operand needs 16-byte aligned dense pixels"
-            check(L.ssa_conv2d_wgrad_tile_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)),
-                  "ssa_conv2d_wgrad_tile_plan")
-            j.kind = "tile_xf"
-        elif al and L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
+        if al and L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
             j.kind = "head"
         else:
             d.cfg = strip
@@ -814,14 +769,9 @@ def _run_wgrad_jobs(jobs, strip):
                 Ho, Wo = j.geom_out
                 _note(2.0 * B * Ho * Wo * j.Cout * j.Cin_real * j.k[0] * j.k[1],
                       2.0 * B * (H * W * Cin + Ho * Wo * j.Cout) + 4.0 * j.Cout * Cin * j.k[0] * j.k[1])
-                if j.kind == "tile_xf":
-                    check(L.ssa_conv2d_wgrad_tile_xf(ctypes.byref(j.desc), _p(j.x), _p(j.dy), j.lddy, j.cout_pad, j.nsplit,
-                                                     ctypes.c_void_p(partial.data_ptr() + off), j.xf_mode, _p(j.xf),
-                                                     _p(j.x2), j.ldx2, _s()), "ssa_conv2d_wgrad_tile_xf")
-                else:
-                    fn, name = fns[j.kind]
-                    check(fn(ctypes.byref(j.desc), _p(j.x), _p(j.dy), j.lddy, j.cout_pad, j.nsplit,
-                             ctypes.c_void_p(partial.data_ptr() + off), _s()), name)
+                fn, name = fns[j.kind]
+                check(fn(ctypes.byref(j.desc), _p(j.x), _p(j.dy), j.lddy, j.cout_pad, j.nsplit,
+                         ctypes.c_void_p(partial.data_ptr() + off), _s()), name)
                 off += j.ws
     with group():
         for js, partial in plan:
@@ -875,9 +825,8 @@ def flush_wgrads(join=False):
             with torch.cuda.stream(side):
                 _run_wgrad_jobs(jobs, _WGRAD_STRIP)
             for j in jobs:                                    # their memory must not be recycled under the side stream
-                for t in (j.x, j.dy, j.xf, j.x2):
-                    if t is not None:
-                        t.record_stream(side)
+                for t in (j.x, j.dy):
+                    t.record_stream(side)
             _SIDE["pending"] = True
         else:
             _run_wgrad_jobs(jobs, _WGRAD_STRIP)
@@ -885,24 +834,18 @@ def flush_wgrads(join=False):
         join_wgrads()
 
 
-def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, weight=None,
-           xf_mode=0, xf=None, x2=None, ldx2=0):
+def _wgrad(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, weight=None):
     """dW[Cout, Cin_real, KH, KW] fp32 = sum_p dy[p, co] * patch(x)[p, (kh,kw,ci)].
     weight = an nn.Parameter: queued, accumulated into its gradient-arena slice, returns None
-    (the gradient is published at the end of backward).  Otherwise computed now and returned.
-    xf_mode 1 / 2: one operand is a BatchNorm pass folded into the kernel's staging (ssa_conv2d_wgrad_tile_xf)."""
+    (the gradient is published at the end of backward).  Otherwise computed now and returned."""
     def job(target, accumulate):
-        j = _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, target, accumulate)
-        j.xf_mode, j.xf, j.x2, j.ldx2 = xf_mode, xf, x2, ldx2
-        return j
+        return _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, dil, Cout, Cin_real, target, accumulate)
     if weight is not None and _is_param(weight):
         _WGRAD_Q.append(job(_GRADS.slot(weight), True))
         n = len(_WGRAD_Q)
         exchange = _GRAD_SINK[0] is not None and n + _SINCE_REDUCE[0] >= _DDP_FLUSH_AT
-        if n >= _FLUSH_NEXT[0] or exchange:
+        if n >= _WGRAD_FLUSH_AT or exchange:
             flush_wgrads()
-            _FLUSH_NEXT[0] = max(min(_WGRAD_FLUSH_MIN, _WGRAD_FLUSH_AT), (_WGRAD_FLUSH_AT if _FLUSH_NEXT[0] == _WGRAD_FLUSH_FIRST != _WGRAD_FLUSH_AT
-                                                                             else _FLUSH_NEXT[0] // 2))
             _SINCE_REDUCE[0] += n
             if exchange:
                 with _on_wgrad_stream():
@@ -1294,44 +1237,20 @@ def _block_descs(x_shape, w):
     return fwd, bwd
 
 
-def _block_fold_ok(x, ldx, w1, w2):
-    """True if bn1 of this residual block can be folded into the neighbouring conv kernels: both convs, their data
-    gradients and their weight gradients run on the halo-staged kernels that compute the folded operand."""
-    if not (_fold_mode() and _TILE_P and _WGRAD_TILE):
-        return False
-    C = w1.shape[0]
-    if tuple(w1.shape) != (C, C, 3, 3) or tuple(w2.shape) != (C, C, 3, 3) or C not in (48, 96, 192, 384):
-        return False
-    if x.shape[3] != C or ldx != C or x.data_ptr() % 16:
-        return False
-    fwd, bwd = _block_descs(tuple(x.shape), w1)
-    if not (tile_p_supported(fwd) and tile_p_supported(bwd)):
-        return False
-    ns, ws = ctypes.c_int(0), ctypes.c_size_t(0)
-    return lib().ssa_conv2d_wgrad_tile_plan(ctypes.byref(fwd), C, ctypes.byref(ns), ctypes.byref(ws)) == 0
-
-
 class BasicBlockGroupFn(torch.autograd.Function):
     """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x), training mode, 3x3 stride-1 convs without
     bias, for N independent problems (branches x scale passes); network/hrnetv2.py:37-66.
 
-    Folded form (SSA_BLOCK_FOLD=1; every problem of the level must qualify, `_block_fold_ok`):
-    forward  conv1 (+ bn1 statistics) -> bn1 coefficients -> conv2 whose operand staging applies bn1 + ReLU
-             (+ bn2 statistics) -> bn2 + residual + ReLU: 3 grouped passes over HBM and one coefficient launch;
-             bn1's output is never written.
-    backward bn2 reduce, bn2 apply (-> dy2, g) -> conv2 data gradient whose epilogue accumulates bn1's backward
-             sums -> bn1 backward coefficients (+ its parameter gradients) -> conv1 data gradient whose staging
-             applies bn1's backward and whose epilogue adds g: bn1's input gradient is never written either; the
-             weight-gradient kernels recompute bn1's output / input gradient while they stage their operands.
-    Unfolded form: conv1+stats, bn1, conv2+stats, bn2+add+relu forward; bn2 reduce, bn2 apply, conv2 data gradient
-    (+ bn1 sums), bn1 apply, conv1 data gradient (+ g) backward.
-    SSA_BLOCK_FOLD=2: the folded FORWARD with the unfolded backward (which never needed bn1's output: its ReLU mask is
-    recomputed from bn1's input) -- only conv2's weight gradient recomputes bn1 + ReLU while it stages its operand.
+    forward  conv1 (+ bn1 statistics in its epilogue), bn1 + ReLU, conv2 (+ bn2 statistics), bn2 + residual + ReLU;
+    backward bn2 reduce, bn2 apply (-> dy2 and g, the identity branch's gradient), conv2 data gradient whose epilogue
+             accumulates bn1's backward sums, bn1 apply, conv1 data gradient whose epilogue adds g: five grouped launches,
+             no bn1 reduce pass, no autograd add for the residual.
+    (Round 3 also carried a form with bn1 folded into the convs' operand staging; it measured slower -- the transform
+    lengthens latency-bound kernels -- and was removed in round 4.)
     metas[i] = (BnMeta bn1, BnMeta bn2); tensors = (x, w1, g1, b1, w2, g2, b2) per problem."""
 
     @staticmethod
     def forward(ctx, metas, *tensors):
-        L = lib()
         n = len(metas)
         T = [tensors[7 * i:7 * i + 7] for i in range(n)]
         xs, ldxs = [], []
@@ -1340,51 +1259,18 @@ class BasicBlockGroupFn(torch.autograd.Function):
             xs.append(x)
             ldxs.append(ldx)
         f32 = lambda t: t.detach().float()
-        fold = all(_block_fold_ok(xs[i], ldxs[i], T[i][1], T[i][4]) for i in range(n))
-        fold_bwd = fold and _fold_mode() == 1
         descs = [_block_descs(tuple(xs[i].shape), T[i][1])[0] for i in range(n)]
         y1s = []
         with tile_strip(descs), group():
             for i in range(n):
                 y1s.append(_conv_fwd(xs[i], ldxs[i], T[i][1], None, 1, 1, 1, False, True)[0])
-        if fold:
-            g1s, b1s = [f32(T[i][2]) for i in range(n)], [f32(T[i][3]) for i in range(n)]
-            stats1 = [_PENDING_STATS.pop(y.data_ptr()) for y in y1s]
-            wd1 = [_sync_world(m[0].sync) for m in metas]
-            cnt1 = [float(y.shape[0] * y.shape[1] * y.shape[2]) for y in y1s]
-            sync_ids = [i for i in range(n) if wd1[i]]
-            if sync_ids:
-                _allreduce_sums([stats1[i][0] for i in sync_ids])
-                for i in sync_ids:
-                    cnt1[i] *= wd1[i]
-            coef1 = []
-            with group():
-                for i in range(n):
-                    C = y1s[i].shape[3]
-                    m = metas[i][0]
-                    assert m.pass_stats is not None or m.running_mean is None, "folded bn1 needs deferred running statistics"
-                    coef = torch.empty((4, C), dtype=torch.float32, device=y1s[i].device)
-                    check(L.ssa_bn_coef_train(_p(stats1[i][0]), stats1[i][1], cnt1[i], C, _p(g1s[i]), _p(b1s[i]),
-                                              float(m.eps), _p(coef), _p(m.pass_stats), _s()), "ssa_bn_coef_train")
-                    coef1.append(coef)
-            y2s = []
-            with tile_strip(descs), group():
-                for i in range(n):
-                    C = y1s[i].shape[3]
-                    wp, _ = _packed_filter(T[i][4], 2, C, 0)
-                    st = _ARENA.take(stat_replicas() * 2 * C, y1s[i].device)
-                    y2 = _tile_p(descs[i], y1s[i], wp, None, st, xf=coef1[i], xf_mode=1)
-                    _PENDING_STATS[y2.data_ptr()] = (st, stat_replicas())
-                    y2s.append(y2)
-            a1s = [None] * n
-        else:
-            a1s, coef1, cnt1, wd1 = _bn_train_fwd(y1s, [y.shape[3] for y in y1s], [m[0] for m in metas],
-                                                  [f32(T[i][2]) for i in range(n)], [f32(T[i][3]) for i in range(n)],
-                                                  [None] * n, [None] * n)
-            y2s = []
-            with tile_strip(descs), group():
-                for i in range(n):
-                    y2s.append(_conv_fwd(a1s[i], a1s[i].shape[3], T[i][4], None, 1, 1, 1, False, True)[0])
+        a1s, coef1, cnt1, wd1 = _bn_train_fwd(y1s, [y.shape[3] for y in y1s], [m[0] for m in metas],
+                                              [f32(T[i][2]) for i in range(n)], [f32(T[i][3]) for i in range(n)],
+                                              [None] * n, [None] * n)
+        y2s = []
+        with tile_strip(descs), group():
+            for i in range(n):
+                y2s.append(_conv_fwd(a1s[i], a1s[i].shape[3], T[i][4], None, 1, 1, 1, False, True)[0])
         outs, coef2, cnt2, wd2 = _bn_train_fwd(y2s, [y.shape[3] for y in y2s], [m[1] for m in metas],
                                                [f32(T[i][5]) for i in range(n)], [f32(T[i][6]) for i in range(n)],
                                                [(xs[i], ldxs[i]) for i in range(n)], [None] * n)
@@ -1392,14 +1278,13 @@ class BasicBlockGroupFn(torch.autograd.Function):
         for i in range(n):
             saved += [xs[i], y1s[i], a1s[i], y2s[i], outs[i], coef1[i], coef2[i], T[i][1], T[i][4], f32(T[i][2]), f32(T[i][5])]
         ctx.save_for_backward(*saved)
-        ctx.info = (ldxs, cnt1, wd1, cnt2, wd2, fold, fold_bwd)
+        ctx.info = (ldxs, cnt1, wd1, cnt2, wd2)
         ctx.params = [(T[i][2], T[i][3], T[i][5], T[i][6]) for i in range(n)]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        L = lib()
-        ldxs, cnt1, wd1, cnt2, wd2, fold_fwd, fold = ctx.info
+        ldxs, cnt1, wd1, cnt2, wd2 = ctx.info
         n = len(ldxs)
         S = [ctx.saved_tensors[11 * i:11 * i + 11] for i in range(n)]
         act = [i for i in range(n) if douts[i] is not None]
@@ -1431,96 +1316,51 @@ class BasicBlockGroupFn(torch.autograd.Function):
                     da1[i] = _conv_dgrad(shp, w2, dy2, C, C, 1, 1, 1, tuple(y2.shape[1:3]), aux=y1, ldaux=y1.shape[3],
                                          coef=c1, mode=2, stats=sums1[i])
                 else:
-                    assert not fold
                     sums1[i] = None
                     da1[i] = _conv_dgrad(shp, w2, dy2, C, C, 1, 1, 1, tuple(y2.shape[1:3]))
         need_dx = [i for i in act if ctx.needs_input_grad[1 + 7 * i]]
         dxs = {}
         r1 = {}
-        xf5 = {}
-        if fold:
-            # ---- bn1's backward as a coefficient table: dy1 = A*(m ? da1 : 0) + B0 + C0*y1 is computed by its consumers
-            sync = [i for i in act if wd1[i]]
-            if sync:
-                _allreduce_sums([sums1[i] for i in sync])
-            with group():
-                for i in act:
-                    x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
-                    C = y1.shape[3]
-                    gp, bp = ctx.params[i][0], ctx.params[i][1]
-                    pscale = 1.0 / wd1[i] if wd1[i] else 1.0
-                    if _is_param(gp) and _is_param(bp):
-                        pg_g, pg_b, acc = _GRADS.slot(gp), _GRADS.slot(bp), 1
-                        r1[i] = (None, None)
-                    else:
-                        pg = torch.empty((2, C), dtype=torch.float32, device=y1.device)
-                        pg_g, pg_b, acc = pg[0], pg[1], 0
-                        r1[i] = (pg[0], pg[1])
-                    t = torch.empty((5, C), dtype=torch.float32, device=y1.device)
-                    check(L.ssa_bn_bwd_coef(_p(sums1[i]), stat_replicas(), cnt1[i], C, _p(g1), _p(c1), _p(t), _p(pg_g),
-                                            _p(pg_b), pscale, acc, _s()), "ssa_bn_bwd_coef")
-                    xf5[i] = t
-            # ---- conv1 data gradient: bn1's backward in its operand staging, the identity branch's gradient in its epilogue
-            with tile_strip(descs_bwd), group():
-                for k, i in enumerate(act):
-                    if i not in need_dx:
-                        continue
-                    x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
-                    gres = r2[k][1]
-                    C = y1.shape[3]
-                    assert gres.data_ptr() % 16 == 0 and gres.shape[3] == C
-                    wpt, _ = _packed_filter(w1, 3, 0, C)
-                    dxs[i] = _tile_p(descs_bwd[k], da1[i], wpt, None, None, xf=xf5[i], xf_mode=2, x2=y1, ldx2=C,
-                                     aux=gres, ldaux=C, aux_mode=1)
-        else:
-            # ---- bn1 (+ ReLU, mask recomputed from y1)
-            jobs1 = []
-            for i in act:
-                x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
-                C = y1.shape[3]
-                jobs1.append(dict(x=y1, ldx=C, dz=da1[i], lddz=C, z=None, coef=c1, g=g1, gamma_param=ctx.params[i][0],
-                                  beta_param=ctx.params[i][1], relu=True, pst=None, training=True, world=wd1[i],
-                                  count=cnt1[i], has_res=False, mask_from_x=True, sums=sums1[i]))
-            rb = _bn_bwd(jobs1)          # (dy1, None, dgamma, dbeta)
-            dy1s = {}
+        # ---- bn1 (+ ReLU, mask recomputed from y1)
+        jobs1 = []
+        for i in act:
+            x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+            C = y1.shape[3]
+            jobs1.append(dict(x=y1, ldx=C, dz=da1[i], lddz=C, z=None, coef=c1, g=g1, gamma_param=ctx.params[i][0],
+                              beta_param=ctx.params[i][1], relu=True, pst=None, training=True, world=wd1[i],
+                              count=cnt1[i], has_res=False, mask_from_x=True, sums=sums1[i]))
+        rb = _bn_bwd(jobs1)          # (dy1, None, dgamma, dbeta)
+        dy1s = {}
+        for k, i in enumerate(act):
+            dy1s[i] = rb[k][0]
+            r1[i] = (rb[k][2], rb[k][3])
+        # ---- conv1 data gradient + the identity branch's gradient
+        late_add = []
+        with tile_strip(descs_bwd), group():
             for k, i in enumerate(act):
-                dy1s[i] = rb[k][0]
-                r1[i] = (rb[k][2], rb[k][3])
-            # ---- conv1 data gradient + the identity branch's gradient
-            late_add = []
-            with tile_strip(descs_bwd), group():
-                for k, i in enumerate(act):
-                    if i not in need_dx:
-                        continue
-                    x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
-                    dy1, gres = dy1s[i], r2[k][1]
-                    C = y1.shape[3]
-                    shp = tuple(x.shape)
-                    if gres.data_ptr() % 16 == 0 and dgrad_tile_ok(shp, w1, 1, 1, 1, tuple(y1.shape[1:3])):
-                        dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]), aux=gres, ldaux=gres.shape[3],
-                                             mode=1)
-                    else:
-                        dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]))
-                        late_add.append((i, gres))
-            for i, gres in late_add:
-                dxs[i] = _add_bf16(dxs[i], gres)
+                if i not in need_dx:
+                    continue
+                x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
+                dy1, gres = dy1s[i], r2[k][1]
+                C = y1.shape[3]
+                shp = tuple(x.shape)
+                if gres.data_ptr() % 16 == 0 and dgrad_tile_ok(shp, w1, 1, 1, 1, tuple(y1.shape[1:3])):
+                    dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]), aux=gres, ldaux=gres.shape[3],
+                                         mode=1)
+                else:
+                    dxs[i] = _conv_dgrad(shp, w1, dy1, C, C, 1, 1, 1, tuple(y1.shape[1:3]))
+                    late_add.append((i, gres))
+        for i, gres in late_add:
+            dxs[i] = _add_bf16(dxs[i], gres)
         # ---- weight gradients (queued)
         for k, i in enumerate(act):
             x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
             dy2 = r2[k][0]
             C2, C1 = y2.shape[3], y1.shape[3]
-            if fold_fwd:       # bn1's output was never written: the weight-gradient kernel recomputes it from y1
-                dw2 = _wgrad(y1, C1, tuple(y1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
-                             w2.shape[0], w2.shape[1], weight=w2, xf_mode=1, xf=c1)
-            else:
-                dw2 = _wgrad(a1, a1.shape[3], tuple(a1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
-                             w2.shape[0], w2.shape[1], weight=w2)
-            if fold:
-                dw1 = _wgrad(x, ldxs[i], tuple(x.shape), da1[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
-                             w1.shape[0], w1.shape[1], weight=w1, xf_mode=2, xf=xf5[i], x2=y1, ldx2=C1)
-            else:
-                dw1 = _wgrad(x, ldxs[i], tuple(x.shape), dy1s[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
-                             w1.shape[0], w1.shape[1], weight=w1)
+            dw2 = _wgrad(a1, a1.shape[3], tuple(a1.shape), dy2, C2, C2, tuple(y2.shape[1:3]), (3, 3), 1, 1, 1,
+                         w2.shape[0], w2.shape[1], weight=w2)
+            dw1 = _wgrad(x, ldxs[i], tuple(x.shape), dy1s[i], C1, C1, tuple(y1.shape[1:3]), (3, 3), 1, 1, 1,
+                         w1.shape[0], w1.shape[1], weight=w1)
             base = 1 + 7 * i
             grads[base] = dxs.get(i)
             grads[base + 1] = dw1

@@ -153,7 +153,7 @@ def _oracle_block(blk, x, p):
 
 @pytest.mark.parametrize("level", [[(48, 32, 24), (96, 16, 12), (192, 16, 12), (384, 8, 6)],
                                    [(48, 128, 160), (96, 37, 41), (192, 33, 30), (384, 16, 16)],
-                                   # every problem (both passes) wide enough for the persistent kernel: the FOLDED block
+                                   # every problem (both passes) wide enough for the persistent kernel
                                    [(48, 12, 72), (96, 9, 40), (192, 8, 34), (384, 6, 32)]])
 def test_basic_block_group_against_oracle(level):
     """BasicBlockGroupFn: forward, data gradient, and the published gradients of all six parameters per
@@ -223,59 +223,6 @@ def test_basic_block_group_equals_the_unfused_composition():
     check_close_robust("dx fused vs unfused", dx0.float(), dx1.float(), 1e-2, 1e-3)
     for a, b in zip(g0, g1):
         check_close("param grad fused vs unfused", a, b, 2e-3, 5e-4)
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_folded_block_equals_the_unfolded_block(mode):
-    """(mode 2 = forward fold only: the data gradients are then the unfolded path's, bit for bit.)
-    BasicBlockGroupFn with bn1 folded into conv2's operand staging, conv1's data gradient and both weight
-    gradients (csrc/conv_tile_p.hip, conv_wgrad_tile.hip XF variants) against the same node with the BatchNorm
-    passes materialised (SSA_BLOCK_FOLD=0 path): same kernels otherwise, same inputs.  The forward is bit-identical
-    (the staging transform is bn_apply's arithmetic); the backward differs by the regrouping
-    A*(m*dz) + B0 + C0*x of gamma*invstd*(m*dz - c1 - xhat*c2) before its bf16 rounding."""
-    from semseg_amd import ops
-    hb = _hb()
-    be = ops.HipBackend()
-    level = [(48, 12, 72), (96, 9, 40), (192, 8, 34), (384, 6, 32)]
-    res = []
-    for fold in (mode, "0"):
-        saved = hb._BLOCK_FOLD
-        hb._BLOCK_FOLD = fold
-        try:
-            blocks = [_block(C, 700 + i).to(DEV).train() for i, (C, H, W) in enumerate(level)]
-            jobs = [(i, 1) for i in range(len(level))] + [(i, 2) for i in range(len(level))]
-            xs = []
-            for k, (i, p) in enumerate(jobs):
-                C, H, W = level[i]
-                h, w_ = (H, W) if p == 1 else (max(H // 2, 2), max(W // 2, 2))
-                xs.append(_dev(_rand(1, C, h, w_, seed=800 + k)).requires_grad_(True))
-            hb.begin_step(torch.device(DEV))
-            hb.lib().ssa_launch_count(1)
-            outs = be.basic_block([blocks[i] for i, p in jobs], xs)
-            be.end_forward()
-            fwd_launches = hb.lib().ssa_launch_count(1)
-            torch.autograd.backward(outs, [_dev(_rand(o.shape[0], o.shape[3], o.shape[1], o.shape[2], seed=900 + k))
-                                           for k, o in enumerate(outs)])
-            torch.cuda.synchronize()
-            assert not hb._WGRAD_Q and not hb._GRADS.slots
-            res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
-                        [[p.grad.clone() for p in b.parameters()] for b in blocks],
-                        [(b.bn1.running_mean.clone(), b.bn1.running_var.clone()) for b in blocks], fwd_launches))
-        finally:
-            hb._BLOCK_FOLD = saved
-    (o0, dx0, g0, rs0, l0), (o1, dx1, g1, rs1, l1) = res
-    assert l0 <= l1, (l0, l1)
-    for a, b in zip(o0, o1):
-        assert torch.equal(a, b)
-    for (m0, v0), (m1, v1) in zip(rs0, rs1):
-        assert torch.equal(m0, m1) and torch.equal(v0, v1)
-    for k, (a, b) in enumerate(zip(dx0, dx1)):
-        if mode == "2":
-            assert torch.equal(a, b)
-        check_close_robust("dx folded vs unfolded %d" % k, a.float(), b.float(), 1e-2, 2e-3)
-    for i, (ga, gb) in enumerate(zip(g0, g1)):
-        for a, b in zip(ga, gb):
-            check_close_robust("block %d param grad folded vs unfolded" % i, a, b, 5e-3, 1e-3, 1e-3)
 
 
 def test_bn_group_against_oracle():

@@ -40,8 +40,8 @@ class DryLib:
                 except (ctypes.ArgumentError, TypeError) as e:
                     raise AssertionError("%s: argument %d (%r) does not convert to %s: %s" % (name, i, a, t, e))
             self.calls[name] += 1
-            if name == "ssa_conv2d_tile_p":          # the persistent trunk conv: what was staged / folded into it
-                self.calls["ssa_conv2d_tile_p:xf%d:aux%d" % (args[5], args[13])] += 1
+            if name == "ssa_conv2d_tile_p":          # the persistent trunk conv: which epilogue it carried
+                self.calls["ssa_conv2d_tile_p:aux%d" % args[9]] += 1
             return 0
         return launch
 
@@ -209,26 +209,6 @@ def test_lockstep_grouping_and_gradient_arena_glue(dry):
         out = net({"images": inputs["images"]})
     assert tuple(out["pred"].shape) == (2, 19, 128, 128)
     assert not hip_backend._WGRAD_Q
-
-
-def test_folded_basic_block_glue(dry, monkeypatch):
-    """Large enough an input that whole trunk levels qualify for the folded residual block (every problem of the
-    level at least 16 pixels wide): bn1 then runs as a coefficient launch + conv2's staging transform (xf 1) in the
-    forward pass, as a coefficient launch + conv1's data-gradient staging transform (xf 2, with the identity
-    gradient in its epilogue) in the backward pass, and both weight gradients take a folded operand."""
-    from semseg_amd import hip_backend
-    monkeypatch.setattr(hip_backend, "_BLOCK_FOLD", True)
-    assert hip_backend._TILE_P
-    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
-    net(_batch(1, 256, 512)).backward()
-    c = dry.calls
-    folded_fwd = c["ssa_conv2d_tile_p:xf1:aux0"]
-    assert folded_fwd > 0 and c["ssa_bn_coef_train"] == folded_fwd, dict(c)
-    assert c["ssa_conv2d_tile_p:xf2:aux1"] == folded_fwd and c["ssa_bn_bwd_coef"] == folded_fwd, dict(c)
-    assert c["ssa_conv2d_wgrad_tile_xf"] == 2 * folded_fwd, dict(c)
-    assert not hip_backend._WGRAD_Q and not hip_backend._GRADS.slots and not hip_backend._GRADS.armed
-    for n, p in net.named_parameters():
-        assert p.grad is not None and p.grad.shape == p.shape, n
 
 
 def _dist_worker(rank, world, port, q):
