@@ -86,11 +86,10 @@ def test_teacher_forced_ops_at_1024():
         for f in ("ConvHaloGemm3", "ConvHaloGemm1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile", "ConvIgemm",
                   "ConvWgradTr"):
             assert f in fams, "dispatch class %s is not on the traced path" % f
-        # the trunk levels' 3x3 convs: the 48-channel and the 96-channel-chunk instantiation behind one kernel,
-        # forward (plain) and data gradient (fused epilogues)
-        # (conv_tile_p.hip: plain forward <0, 0>, data gradient with the BatchNorm-backward sums <0, 2> / the residual
-        # gradient <0, 1> in the epilogue)
-        for inst in ("ConvTilePAny<0, 0>", "ConvTilePAny<0, 1>", "ConvTilePAny<0, 2>"):
+        # the trunk levels' 3x3 convs: the resident (48 channels) and the streamed instantiation behind one kernel,
+        # conv_tile_p.hip: plain forward <0>, data gradient with the residual gradient <1> / the BatchNorm-backward
+        # sums <2> in the epilogue
+        for inst in ("ConvTilePAny<0>", "ConvTilePAny<1>", "ConvTilePAny<2>"):
             assert inst in names, "%s is not on the path" % inst
         assert any(n.startswith("ConvWgradTile<96,") for n in names)
     assert not tb.rec.failures(), tb.rec.summary(30)

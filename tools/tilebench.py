@@ -40,10 +40,9 @@ class Prob:
     def old(self):
         hb.check(L.ssa_conv2d_tile(ctypes.byref(self.d), P(self.x), P(self.wp), None, P(self.y), P(self.stats), hb._s()), "tile")
 
-    def new(self, xf=0, aux=0):
+    def new(self, aux=0):
         st = None if aux == 1 else self.stats
-        hb.check(L.ssa_conv2d_tile_p(ctypes.byref(self.d), P(self.x), P(self.x2) if xf == 2 else None, self.C,
-                                     P(self.xf) if xf else None, xf, P(self.wp), None, P(self.y), P(st),
+        hb.check(L.ssa_conv2d_tile_p(ctypes.byref(self.d), P(self.x), P(self.wp), None, P(self.y), P(st),
                                      P(self.aux) if aux else None, self.C, P(self.coef) if aux == 2 else None, aux, hb._s()),
                  "tile_p")
 
@@ -91,22 +90,24 @@ def main():
             for p in probs:
                 p.old()
 
-    def level_new(xf=0, aux=0):
+    def level_new(aux=0):
         with hb.group():
             for p in probs:
-                p.new(xf, aux)
+                p.new(aux)
     fl = sum(p.flops for p in probs)
     by = sum(p.bytes for p in probs)
     t = timeit(level_old, reps)
     print("level (8 problems, %.1f GFLOP, %.1f MB): old grouped %.1f us = %.0f TF/s, %.0f GB/s" % (fl / 1e9, by / 1e6, t, fl / t / 1e6, by / t / 1e3))
-    for u in (1, 2, 3, 4, 5, 6, 8):
+    best = (1e9, 4)
+    for u in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
         L.ssa_conv_tile_strip(u)
         t = timeit(level_new, reps)
+        best = min(best, (t, u))
         print("   persistent, strip units %d: %.1f us = %.0f TF/s, %.0f GB/s" % (u, t, fl / t / 1e6, by / t / 1e3))
-    L.ssa_conv_tile_strip(4)
-    for xf, aux in ((1, 0), (0, 2), (2, 1), (0, 1)):
-        t = timeit(lambda: level_new(xf, aux), reps)
-        print("   persistent units 4, xf %d aux %d: %.1f us" % (xf, aux, t))
+    L.ssa_conv_tile_strip(best[1])
+    for aux in (2, 1):
+        t = timeit(lambda: level_new(aux), reps)
+        print("   persistent units %d, aux %d: %.1f us" % (best[1], aux, t))
     L.ssa_conv_tile_strip(0)
     # two-branch level (stage 2)
     probs2 = probs[:4]
@@ -138,7 +139,7 @@ def timing():
         dbg = torch.zeros(24 * 8, dtype=torch.int64, device=DEV)
         L.ssa_conv_tile_strip(units)
         for _ in range(3):
-            hb.check(L.ssa_conv2d_tile_p(ctypes.byref(p.d), P(p.x), None, C, None, 0, P(p.wp), None, P(p.y), P(p.stats), None, C,
+            hb.check(L.ssa_conv2d_tile_p(ctypes.byref(p.d), P(p.x), P(p.wp), None, P(p.y), P(p.stats), None, C,
                                          P(dbg), 0, hb._s()), "tile_p")
         torch.cuda.synchronize()
         t = dbg.cpu().view(24, 8)
