@@ -44,7 +44,7 @@ struct TilePArgs {
   const bf16_t* aux; const float* coef;                    // epilogue tile; [4][Cout] table of aux_mode 2
   int ldx, Cin, ldy, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux;
   int total_tiles, tiles_per_wg, ngroups, nwg;
-  int variant;
+  int variant, nb_first;
 };
 
 // Bijective XCD-aware order (block b runs on XCD b % 8): XCD x gets one contiguous range of work items.
@@ -153,7 +153,7 @@ struct ConvTileP {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w_ = xcd_order(bx, a.nwg);
     const int strip = w_ / a.ngroups, grp = w_ - strip * a.ngroups;
-    const int nb0 = grp * NB;
+    const int nb0 = a.nb_first + grp * NB;
     const int t_begin = strip * a.tiles_per_wg;
     const int t_end = min(a.total_tiles, t_begin + a.tiles_per_wg);
     const int nchunk = Cin / CK;
@@ -456,14 +456,20 @@ struct ConvTileP {
   }
 };
 
-// The two instantiations a trunk level uses behind ONE kernel: 48 input channels (resident filter) and the streamed
-// one (96 / 192 / 384 input channels in chunks of 48), both two n-blocks (64 output channels) per workgroup.
+// The three instantiations a trunk level uses behind ONE kernel:
+//   V0  48 input channels: resident filter, two n-blocks (64 output channels) per workgroup;
+//   V1  96 input channels: streamed filter, two n-blocks per workgroup (the third n-block of a 96-channel layer: V2);
+//   V2  192 / 384 input channels: streamed filter, ONE n-block per workgroup -- a tile of these layers is a serial chain
+//       of 4 / 8 channel chunks, and what bounds a level is its longest chain (profiles/r04_notes.md, call A: 384 @ 32x32
+//       alone 20.4 us with two n-blocks per workgroup = 60 workgroups x 8 units of 54 MFMAs), so the deep layers get
+//       twice the workgroups with half the work each.
 template <int AUXM>
 struct ConvTilePAny {
   typedef TilePArgs Args;
   static constexpr int NT = 256;
   typedef ConvTileP<2, 9, AUXM> V0;
   typedef ConvTileP<2, 3, AUXM> V1;
+  typedef ConvTileP<1, 3, AUXM> V2;
 #ifdef SSA_TILE_TIMING
   static constexpr size_t LDS = (V0::LDS > V1::LDS ? V0::LDS : V1::LDS) + 1536;
 #else
@@ -471,36 +477,51 @@ struct ConvTilePAny {
 #endif
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) {
     if (a.variant == 0) V0::run(a, bx, by, gx);
-    else V1::run(a, bx, by, gx);
+    else if (a.variant == 1) V1::run(a, bx, by, gx);
+    else V2::run(a, bx, by, gx);
   }
 };
 
 static thread_local int g_strip_units = 0;     // work units (54 MFMAs per wave) per workgroup, 0 = per problem
 
+// one job = the n-blocks [nb_first, nb_first + nblocks) of the problem on instantiation `variant` (NB n-blocks per group)
 template <int AUXM>
-int launch_p(const ssa_conv_desc& d, const TilePArgs& a0, hipStream_t s) {
-  TilePArgs a = a0;
+int submit_p(const ssa_conv_desc& d, TilePArgs a, int variant, int NB, int nb_first, int nblocks, hipStream_t s) {
   const int nchunk = d.Cin / 48;
-  constexpr int NB = 2;
-  a.variant = d.Cin == 48 ? 0 : 1;
+  a.variant = variant;
+  a.nb_first = nb_first;
   a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + 31) / 32;
   a.tiles_y = (d.H + 3) / 4;
   a.total_tiles = d.B * a.tiles_x * a.tiles_y;
-  a.ngroups = (a.nb_total + NB - 1) / NB;
+  a.ngroups = (nblocks + NB - 1) / NB;
   int units = g_strip_units;
   if (units <= 0) {
     // a launch of its own: ~2 workgroups per CU from this problem alone
     const long total = (long)a.total_tiles * a.ngroups * nchunk;
-    units = (int)((total + 511) / 512);
+    units = (int)((total * NB / 2 + 511) / 512);
   }
   if (units > 32) units = 32;
-  int tpw = units / nchunk;
+  int tpw = units * 2 / (NB * nchunk);        // a unit of the one-n-block instantiation is half a unit of work
   if (tpw < 1) tpw = 1;
   const int nstrips = (a.total_tiles + tpw - 1) / tpw;
   a.tiles_per_wg = (a.total_tiles + nstrips - 1) / nstrips;
   a.nwg = ((a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg) * a.ngroups;
   return ssa::submit<ConvTilePAny<AUXM>>(a, a.nwg, 1, ConvTilePAny<AUXM>::LDS, s);
+}
+
+template <int AUXM>
+int launch_p(const ssa_conv_desc& d, const TilePArgs& a, hipStream_t s) {
+  const int nb_total = (d.Cout + 31) / 32;
+  if (d.Cin == 48) return submit_p<AUXM>(d, a, 0, 2, 0, nb_total, s);
+  if (d.Cin == 96) {
+    const int pairs = nb_total / 2;
+    if (pairs > 0)
+      if (int rc = submit_p<AUXM>(d, a, 1, 2, 0, 2 * pairs, s)) return rc;
+    if (nb_total & 1) return submit_p<AUXM>(d, a, 2, 1, 2 * pairs, 1, s);
+    return 0;
+  }
+  return submit_p<AUXM>(d, a, 2, 1, 0, nb_total, s);
 }
 
 }  // namespace
@@ -535,7 +556,7 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* w_frag
   a.y = (bf16_t*)y; a.stats = stats; a.aux = (const bf16_t*)aux; a.coef = coef;
   a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
   a.ldaux = ldaux;
-  a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = a.variant = 0;
+  a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = a.variant = a.nb_first = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (aux_mode) {
     case 0: return launch_p<0>(d, a, s);

@@ -18,7 +18,15 @@ reference's loop holds so that the UNMODIFIED loop runs the captured step:
 Everything the step needs is capture safe by construction (no host synchronisation, torch's caching allocator,
 kernels on the current stream; at N > 1 the SyncBN and gradient exchanges are direct RCCL nodes).  Evaluation
 (`net.eval()` / `torch.no_grad()`) goes straight to the module.
+
+Guards: at most `max_graphs` input signatures are captured (a run with ragged shapes would otherwise multiply the
+activation pools); further signatures, and every step after a capture that raised (logged once), run the SAME
+sequence eagerly.  With N > 1 every rank must see the same shapes in the same iteration (the warm-up steps of a
+capture issue collectives).  Reloading the optimizer's state (`optim.load_state_dict`) drops the captured graphs:
+they hold the addresses of the old momentum buffers.
 """
+import sys
+
 import torch
 from torch import nn
 
@@ -26,9 +34,15 @@ from torch import nn
 class GraphedTrainStep:
     """Captured `zero_grad -> net(inputs) -> backward -> optim.step` for dict inputs of device tensors."""
 
-    def __init__(self, net, optim, warmup=2):
-        self.net, self.optim, self.warmup = net, optim, warmup
+    def __init__(self, net, optim, warmup=2, max_graphs=4):
+        self.net, self.optim, self.warmup, self.max_graphs = net, optim, warmup, max_graphs
         self._graphs = {}          # input signature -> (graph, static inputs, static loss)
+        self.eager_only = False    # set after a capture that raised
+        self.replays = 0
+
+    def invalidate(self):
+        """Forget the captured graphs (the optimizer's state tensors were replaced)."""
+        self._graphs = {}
 
     def _signature(self, inputs):
         return tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(inputs.items()) if torch.is_tensor(v))
@@ -53,29 +67,41 @@ class GraphedTrainStep:
                   for p in params]
         bufs = list(self.net.buffers())
         snap_b = [b.detach().clone() for b in bufs]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(self.warmup):        # allocator, momentum buffers, packed-filter cache
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):        # allocator, momentum buffers, packed-filter cache
+                    self._eager(static, loss_out)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            self.optim.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
                 self._eager(static, loss_out)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        self.optim.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            self._eager(static, loss_out)
-        with torch.no_grad():
-            for p, s0, m0 in zip(params, snap_p, snap_m):
-                p.copy_(s0)                     # (bumps the version counter: the captured step re-packs the filters)
-                buf = self.optim.state.get(p, {}).get("momentum_buffer")
-                if buf is not None:
-                    if m0 is not None:
-                        buf.copy_(m0)
-                    else:
-                        buf.zero_()             # a zero buffer is the optimizer's first-step state
-            for b, s0 in zip(bufs, snap_b):
-                b.copy_(s0)
+        finally:
+            # also when the capture raised: the warm-up steps must not have trained the network
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for p, s0, m0 in zip(params, snap_p, snap_m):
+                    p.copy_(s0)                     # (bumps the version counter: the captured step re-packs the filters)
+                    buf = self.optim.state.get(p, {}).get("momentum_buffer")
+                    if buf is not None:
+                        if m0 is not None:
+                            buf.copy_(m0)
+                        else:
+                            buf.zero_()             # a zero buffer is the optimizer's first-step state
+                for b, s0 in zip(bufs, snap_b):
+                    b.copy_(s0)
         return graph, static, loss_out
+
+    def _run_eager(self, inputs):
+        dev = next(v.device for v in inputs.values() if torch.is_tensor(v))
+        loss_out = torch.zeros((), device=dev)
+        if hasattr(self.optim, "sync_lr"):
+            self.optim.sync_lr()
+        self._eager(inputs, loss_out)
+        return loss_out
 
     def __call__(self, inputs):
         """One training step on `inputs`; returns the step's (mean) loss as a detached 0-dim tensor."""
@@ -83,7 +109,16 @@ class GraphedTrainStep:
         ent = self._graphs.get(sig)
         fresh = ent is None
         if fresh:
-            ent = self._graphs[sig] = self._capture(inputs)
+            if self.eager_only or len(self._graphs) >= self.max_graphs:
+                return self._run_eager(inputs)
+            try:
+                ent = self._capture(inputs)
+            except Exception as e:          # noqa: BLE001 -- whatever refused the capture: run the same step eagerly
+                self.eager_only = True
+                print("semseg_amd.graphed: hipGraph capture of the training step failed (%s: %s); the loop goes on with "
+                      "eager launches of the same step" % (type(e).__name__, str(e)[:300]), file=sys.stderr, flush=True)
+                return self._run_eager(inputs)
+            self._graphs[sig] = ent
         graph, static, loss_out = ent
         if hasattr(self.optim, "sync_lr"):
             self.optim.sync_lr()                # the scheduler's current learning rate -> the device scalar
@@ -92,57 +127,69 @@ class GraphedTrainStep:
                 if torch.is_tensor(v):
                     static[k].copy_(v, non_blocking=True)
         graph.replay()
+        self.replays += 1
         return loss_out.clone()
 
 
 class _GraphedNet(nn.Module):
-    """What the reference's loop calls as `net(inputs)`: in training mode the whole captured step."""
+    """What the reference's loop calls as `net(inputs)`: in training mode the whole captured step.
+
+    Transparent to the module tree: the proxy SHARES the wrapped net's `_modules` / `_parameters` / `_buffers`
+    dictionaries instead of registering the net as a child, so `state_dict()` / `load_state_dict()` / `parameters()` /
+    `.cuda()` / `.train()` see exactly the wrapped net's names -- also through an outer wrapper
+    (`DistributedDataParallel(_GraphedNet(net)).state_dict()` has `module.X` keys and loads them back, which is what
+    the reference's `restore_net` -> `forgiving_state_restore`, train.py:396, does with --snapshot / --resume)."""
 
     def __init__(self, net, stepper):
         super().__init__()
-        self.wrapped = net
-        self._stepper = [stepper]              # not a submodule
+        object.__setattr__(self, "_net", net)          # not a registered submodule
+        object.__setattr__(self, "_stepper", stepper)
+        self._modules = net._modules
+        self._parameters = net._parameters
+        self._buffers = net._buffers
+        self.training = net.training
+
+    @property
+    def wrapped(self):
+        return self._net
 
     def forward(self, inputs):
-        if self.wrapped.training and torch.is_grad_enabled():
-            loss = self._stepper[0](inputs)
+        if self._net.training and torch.is_grad_enabled():
+            loss = self._stepper(inputs)
             return loss.requires_grad_(True)   # a leaf: the loop's own .backward() has nothing to do
-        return self.wrapped(inputs)
+        return self._net(inputs)
 
     def train(self, mode=True):
-        self.wrapped.train(mode)
-        return super().train(mode)
-
-    def state_dict(self, *a, **k):
-        return self.wrapped.state_dict(*a, **k)
-
-    def load_state_dict(self, *a, **k):
-        return self.wrapped.load_state_dict(*a, **k)
-
-    def parameters(self, recurse=True):
-        return self.wrapped.parameters(recurse)
-
-    def named_parameters(self, *a, **k):
-        return self.wrapped.named_parameters(*a, **k)
+        self._net.train(mode)
+        self.training = mode
+        return self
 
     def __getattr__(self, name):
         try:
             return super().__getattr__(name)
         except AttributeError:
-            return getattr(super().__getattr__("wrapped"), name)     # .module of the data-parallel wrapper etc.
+            return getattr(object.__getattribute__(self, "_net"), name)     # .module of the data-parallel wrapper etc.
 
 
 class _GraphedOptim:
     """The optimizer as the loop sees it: zero_grad / step are inside the captured step."""
 
-    def __init__(self, optim):
+    def __init__(self, optim, stepper=None):
         self.__dict__["_optim"] = optim
+        self.__dict__["_stepper"] = stepper
 
     def zero_grad(self, *a, **k):
         pass
 
     def step(self, *a, **k):
         pass
+
+    def load_state_dict(self, *a, **k):
+        r = self.__dict__["_optim"].load_state_dict(*a, **k)
+        st = self.__dict__.get("_stepper")
+        if st is not None:
+            st.invalidate()                 # the graphs point at the momentum buffers that were just replaced
+        return r
 
     def __getattr__(self, name):
         return getattr(self.__dict__["_optim"], name)
@@ -151,8 +198,8 @@ class _GraphedOptim:
         setattr(self.__dict__["_optim"], name, value)
 
 
-def graph_training(net, optim, warmup=2):
+def graph_training(net, optim, warmup=2, max_graphs=4):
     """(net, optim) -> proxies under which the reference's unmodified train() loop runs one hipGraph replay per
     iteration (see the module docstring)."""
-    stepper = GraphedTrainStep(net, optim, warmup)
-    return _GraphedNet(net, stepper), _GraphedOptim(optim)
+    stepper = GraphedTrainStep(net, optim, warmup, max_graphs)
+    return _GraphedNet(net, stepper), _GraphedOptim(optim, stepper)

@@ -551,14 +551,24 @@ def tile_p_supported(d):
 
 def _tile_p_wgs(d, units):
     """Workgroups ssa_conv2d_tile_p launches for this problem at `units` (one 128-pixel tile x one 48-channel chunk
-    of the input x two n-blocks: 54 MFMAs per wave) per workgroup (mirror of launch_p, csrc/conv_tile_p.hip)."""
+    of the input x two n-blocks: 54 MFMAs per wave) per workgroup -- mirror of launch_p / submit_p in
+    csrc/conv_tile_p.hip: 48 and 96 input channels run two n-blocks per workgroup (a 96-channel layer's third n-block
+    on the one-n-block instantiation), 192 / 384 one n-block per workgroup."""
     tiles = d.B * ((d.W + 31) // 32) * ((d.H + 3) // 4)
     nb = (d.Cout + 31) // 32
-    groups, nchunk = (nb + 1) // 2, d.Cin // 48
-    tpw = max(1, units // nchunk)
-    nstrips = -(-tiles // tpw)
-    tpw = -(-tiles // nstrips)
-    return -(-tiles // tpw) * groups
+    nchunk = d.Cin // 48
+
+    def job(NB, nblocks):
+        groups = -(-nblocks // NB)
+        tpw = max(1, units * 2 // (NB * nchunk))
+        nstrips = -(-tiles // tpw)
+        tpw = -(-tiles // nstrips)
+        return -(-tiles // tpw) * groups
+    if d.Cin == 48:
+        return job(2, nb)
+    if d.Cin == 96:
+        return (job(2, 2 * (nb // 2)) if nb // 2 else 0) + (job(1, 1) if nb & 1 else 0)
+    return job(1, nb)
 
 
 @contextlib.contextmanager

@@ -3,12 +3,24 @@
 `DistributedDataParallel` stands in for apex.parallel.DistributedDataParallel
 (network/__init__.py:37-39 of the reference): gradients are averaged over ranks.
 On the HIP path the parameter gradients of a step live in the backend's gradient arena
-(hip_backend._GradArena: a few contiguous fp32 chunks in backward order), so the exchange
-is ONE in-place all-reduce (mean) per chunk, enqueued with direct RCCL calls on the compute
-stream at the end of backward -- no flattening copy, no per-parameter hooks, and the same
-captured hipGraph as the single-GPU step.  Gradients that reach a parameter through autograd
-(conv biases; every parameter under the CPU test backend) are collected by hooks and exchanged
-as one flat bucket in an end-of-backward callback.
+(hip_backend._GradArena: a few contiguous fp32 chunks that fill in backward order).  The exchange is
+OVERLAPPED with backward: every SSA_DDP_FLUSH_AT (256) queued layers the weight gradients are flushed and the arena
+range that is now final is all-reduced (mean) in place, by a direct RCCL call, on a communication stream of its own
+(second communicator), ordered behind the weight-gradient stream by an event -- about three exchanges per step
+(~110, ~110, ~65 MB at 1024x1024), the last of which has no later compute to hide behind.  No flattening copy, no
+per-parameter hooks; the exchanges are nodes (a parallel branch) of the same captured hipGraph as the single-GPU step.
+`SSA_DDP_OVERLAP=0`: the same ranges on the compute stream, one communicator.
+
+Order of collectives across ranks (what keeps two communicators from dead-locking): every rank runs the same
+program on the same shapes, so communicator 0's calls (SyncBN sums, level by level; the autograd-bucket all-reduce)
+are issued in the same order on its compute stream everywhere, and communicator 1's (arena ranges) in the same order
+on its communication stream; no kernel of either stream waits for anything but (a) earlier work of its own stream and
+(b) the fork/join events, which point from the compute stream to the communication stream before an exchange and
+back only at the end of backward.  All other kernels of the step are finite, so a collective of either communicator
+that has been launched on every rank always becomes resident on every rank.
+
+Gradients that reach a parameter through autograd (conv biases; every parameter under the CPU test backend) are
+collected by hooks and exchanged as one flat bucket in an end-of-backward callback.
 SyncBN lives in semseg_amd.nn.SyncBatchNorm; its exchange is `allreduce_bn_sums`.
 `backend='nccl'` is RCCL on ROCm.
 """
