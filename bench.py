@@ -48,7 +48,7 @@ def source_sha():
 def family(kernel):
     f = kernel.split("<")[0]
     # the trunk's 3x3 kernels: conv_tile.hip (ConvTile, ConvTileAny) and its persistent form conv_tile_p.hip
-    if f in ("ConvTileAny", "ConvTilePAny", "ConvTileP"):
+    if f in ("ConvTileAny", "ConvTilePAny", "ConvTilePK", "ConvTileP"):
         return "ConvTile"
     # the head convs: conv_halo_gemm.hip (3x3: ConvHaloGemm3, 1x1: ConvHaloGemm1), conv_wgrad_head.hip (3x3: ...Head3)
     return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead"}.get(f, f)

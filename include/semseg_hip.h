@@ -128,14 +128,14 @@ int ssa_conv2d_tile_aux(const ssa_conv_desc* d, const void* x, const void* w_fra
                         const float* coef, int aux_mode, void* stream);
 
 /* Persistent, software-pipelined form of ssa_conv2d_tile / ssa_conv2d_tile_aux for the trunk's 48/96/192/384-channel
- * 3x3 convs (csrc/conv_tile_p.hip): a workgroup walks a strip of tiles of one (problem, pair of n-blocks), the input
- * in chunks of 48 channels, with the filter resident (48 channels) or streamed as one continuous LDS-DMA pipeline
- * through a ring of three buffers, the next halo in flight during the MFMAs, a register-only epilogue (swapped MFMA
- * operands + v_permlane32_swap) and the BatchNorm statistics in registers over the strip.
+ * 3x3 convs (csrc/conv_tile_p.hip): a workgroup walks a strip of tiles of one (problem, 32-channel n-block), the input
+ * in chunks of 48 channels, the filter streamed as one continuous LDS-DMA pipeline through a ring of three buffers,
+ * the next halo in flight during the MFMAs, a register-only epilogue (swapped MFMA operands + v_permlane32_swap) and
+ * the BatchNorm statistics in registers over the strip; three workgroups per CU.  No bias (SSA_EUNSUPPORTED).
  * stats / aux / aux_mode / coef as ssa_conv2d_tile_aux (aux_mode 0: none).
- * ssa_conv_tile_strip(units): work (in units of one 128-pixel tile x one 48-channel chunk = 54 MFMAs per wave) a
- * workgroup of the calling thread's NEXT launches should carry -- the caller of a grouped level knows the level's
- * total; 0 = derive from each problem alone.                                                                    */
+ * ssa_conv_tile_strip(units): work (in units of one 128-pixel tile x one 48-channel chunk x one n-block = 27 MFMAs
+ * per wave) a workgroup of the calling thread's NEXT launches should carry -- the caller of a grouped level knows the
+ * level's total; 0 = derive from each problem alone.                                                              */
 int ssa_conv2d_tile_p_supported(const ssa_conv_desc* d);
 int ssa_conv_tile_strip(int units);
 int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,

@@ -75,7 +75,6 @@ struct TileArgs {
   const bf16_t* x; const uint4* wfrag; const float* bias; bf16_t* y; double* stats;
   const bf16_t* aux; const float* coef;
   int ldx, Cin, ldy, B, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux, aux_mode;
-  int variant;              // ConvTileAny: which instantiation runs this problem
 };
 
 template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
@@ -313,30 +312,12 @@ struct ConvTile {
   }
 };
 
-// The two instantiations every grouped trunk level uses -- 48 channels (both n-blocks per workgroup) and
-// the 96-channel chunked one (96/192/384 channels) -- behind ONE kernel: a depth level's 3x3 convs
-// leave as a single launch (~1,500 workgroups of either kind, ~78 KB of LDS each, two per CU), so
-// the tail of one kind overlaps the body of the other.
-template <bool AUX>
-struct ConvTileAny {
-  typedef TileArgs Args;
-  static constexpr int NT = 256;
-  typedef ConvTile<48, 3, 2, 1, 32, 9, AUX> V0;
-  typedef ConvTile<96, 3, 1, 1, 32, 3, AUX> V1;
-  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) {
-    if (a.variant == 0) V0::run(a, bx, by, gx);
-    else V1::run(a, bx, by, gx);
-  }
-};
-
 struct AuxArgs {
   const void* aux;
   int ld;
   const float* coef;
   int mode;               // 0: none, 1: add, 2: BatchNorm backward sums
 };
-
-static thread_local bool g_any_kernel = false;   // set by tile_impl: grouped launch through ConvTileAny
 
 template <int CK, int KS, int NB, int MI, int TW, int TPC, bool AUX>
 int launch_tile_v(const ssa_conv_desc& d, const void* x, const void* wfrag, const float* bias, void* y,
@@ -356,21 +337,6 @@ int launch_tile_v(const ssa_conv_desc& d, const void* x, const void* wfrag, cons
   a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + TW - 1) / TW; a.tiles_y = (d.H + TH - 1) / TH;
   a.ldaux = ax.ld; a.aux_mode = ax.mode;
-  a.variant = -1;
-  if constexpr (KS == 3 && MI == 1 && TW == 32 && ((CK == 48 && NB == 2 && TPC == 9) || (CK == 96 && NB == 1 && TPC == 3))) {
-    if (g_any_kernel) {
-      a.variant = CK == 48 ? 0 : 1;
-      constexpr size_t halo_b = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (96 * 2 + 16) + 1023) / 1024 * 1024;
-      constexpr size_t lds_b = halo_b + (size_t)2 * 1 * 3 * (96 / 16) * 1024;
-      constexpr size_t halo_a = ((size_t)(TH + 2 * R) * (TW + 2 * R) * (48 * 2 + 16) + 1023) / 1024 * 1024;
-      constexpr size_t lds_a = halo_a + (size_t)1 * 2 * 9 * (48 / 16) * 1024;
-      constexpr size_t stage_a = (size_t)(AUX ? 2 : 1) * BM * (2 * 32 + 8) * 2 + 4 * 2 * 2 * 32 * sizeof(float);
-      size_t lds_any = lds_a > lds_b ? lds_a : lds_b;
-      if (stage_a > lds_any) lds_any = stage_a;
-      if (lds > lds_any) lds_any = lds;
-      return ssa::submit<ConvTileAny<AUX>>(a, a.tiles_x * a.tiles_y * d.B, (a.nb_total + NB - 1) / NB, lds_any, s);
-    }
-  }
   return ssa::submit<ConvTile<CK, KS, NB, MI, TW, TPC, AUX>>(a, a.tiles_x * a.tiles_y * d.B,
                                                              (a.nb_total + NB - 1) / NB, lds, s);
 }
@@ -382,28 +348,20 @@ int launch_tile(const ssa_conv_desc& d, const void* x, const void* wfrag, const 
   return launch_tile_v<CK, KS, NB, MI, TW, TPC, false>(d, x, wfrag, bias, y, stats, s, ax);
 }
 
-// tile shape by image width: TW = 32 where the image is at least 32 wide.
-// big: two MFMA row blocks per wave (256 pixels per workgroup) where LDS allows.
-// grouped launches: 32-pixel-wide tiles down to 16-pixel-wide images (half the lanes of such a tile idle,
-// but the 0.5x pass of the 192/384-channel branches then shares the launch of the 1.0x pass)
-static thread_local bool g_wide_tiles = false;
-
-template <int CK, int KS, int NB, int TPC, bool BIG_OK, bool NARROW_OK = true>
+// tile shape by image width: 32-, 16- or 8-pixel-wide tiles of 128 pixels
+template <int CK, int KS, int NB, int TPC>
 int dispatch_geom(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
-                  double* stats, hipStream_t s, bool want_big, const AuxArgs& ax) {
-  if (d.W >= 32 || !NARROW_OK || (g_wide_tiles && d.W >= 16)) {
-    if constexpr (BIG_OK) {
-      if (want_big) return launch_tile<CK, KS, NB, 2, 32, TPC>(d, x, w, bias, y, stats, s, ax);
-    }
-    return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s, ax);
-  }
-  if constexpr (NARROW_OK) {
-    if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s, ax);
-    return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s, ax);
-  }
-  return SSA_EUNSUPPORTED;
+                  double* stats, hipStream_t s, const AuxArgs& ax) {
+  if (d.W >= 32) return launch_tile<CK, KS, NB, 1, 32, TPC>(d, x, w, bias, y, stats, s, ax);
+  if (d.W >= 16) return launch_tile<CK, KS, NB, 1, 16, TPC>(d, x, w, bias, y, stats, s, ax);
+  return launch_tile<CK, KS, NB, 1, 8, TPC>(d, x, w, bias, y, stats, s, ax);
 }
 
+// What is left for this kernel since the persistent one (conv_tile_p.hip) took the trunk's 48/96/192/384-channel
+// layers: the 64-channel stem / layer1 convs, images narrower than 16 pixels, convs with a bias.  One instantiation
+// per channel count -- 128-pixel tiles, one n-block per workgroup (measured best for these latency-bound layers,
+// profiles/r01_convbench.txt); round 2's variants (two / three n-blocks, 256-pixel tiles, the 96-channel-chunk
+// instantiation and the ConvTileAny kernel of the grouped levels) went with their callers in round 4.
 int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias, void* y,
               double* stats, const AuxArgs& ax, void* stream) {
   if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
@@ -412,50 +370,12 @@ int tile_impl(const ssa_conv_desc* dp, const void* x, const void* w_frag, const 
     return SSA_EINVAL;
   const ssa_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
-  const int nbt = (d.Cout + 31) / 32;
-  // Measured on MI355X (tools/convbench, profiles/r01_convbench.txt): these layers are
-  // latency bound, more and smaller workgroups win everywhere -- 128-pixel tiles and one
-  // n-block per workgroup (2-3 workgroups per CU) -- except the 48-channel layers at
-  // >= 512 tiles, where both n-blocks in one workgroup save the second halo read.
-  // cfg >= 0 (benchmark knob): bit 0 = 128-pixel tile, bit 1 = one n-block per workgroup.
-  const long tiles128 = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
-  // Inside a group bracket (group.h) the problems of a depth level share launches only if they share
-  // the kernel instantiation, and the launch gets its parallelism from all of them: the variant is
-  // then chosen by the channel count alone (48 channels: both n-blocks per workgroup whatever the tile
-  // count), so that the 1.0x and the 0.5x pass of a layer -- and the 192- and 384-channel branches --
-  // leave as ONE launch.  SSA_GROUP_UNIFY=0 keeps the per-problem choice.
-  static const bool unify = !(getenv("SSA_GROUP_UNIFY") && atoi(getenv("SSA_GROUP_UNIFY")) == 0);
-  const bool grouped = unify && ssa::group_state().depth > 0 && d.cfg < 0;
-  static const bool chunk96 = !(getenv("SSA_TILE_CHUNK96") && atoi(getenv("SSA_TILE_CHUNK96")) == 0);
-  const int cfg = d.cfg < 0 ? (1 | ((d.Cin == 48 && (tiles128 >= 512 || grouped)) ? 0 : 2)) : d.cfg;
-  const bool big = !(cfg & 1) && (long)d.H * d.W >= 128L * 128;
-  const bool split_n = (cfg & 2) != 0;
-  g_wide_tiles = grouped;
-  static const bool any_on = !(getenv("SSA_TILE_ANY") && atoi(getenv("SSA_TILE_ANY")) == 0);
-  g_any_kernel = grouped && chunk96 && any_on;
   switch (d.Cin) {
-    case 48:
-      if (nbt == 1 || split_n) return dispatch_geom<48, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
-      if (nbt == 2 || nbt == 4) return dispatch_geom<48, 3, 2, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
-      return dispatch_geom<48, 3, 3, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-    case 64:
-      if (nbt == 1 || split_n) return dispatch_geom<64, 3, 1, 9, true>(d, x, w_frag, bias, y, stats, s, big, ax);
-      return dispatch_geom<64, 3, 2, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-    case 96:
-      // grouped: 96-channel chunks, three taps per (double-buffered) filter stage -- 78 KB of LDS, two
-      // workgroups per CU, and the instantiation the 192- and 384-channel branches share (below)
-      if (grouped && chunk96) return dispatch_geom<96, 3, 1, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-      if (nbt == 1 || split_n) return dispatch_geom<96, 3, 1, 9, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-      if (nbt == 2 || nbt == 4) return dispatch_geom<96, 3, 2, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-      return dispatch_geom<96, 3, 3, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    case 48: return dispatch_geom<48, 3, 1, 9>(d, x, w_frag, bias, y, stats, s, ax);
+    case 64: return dispatch_geom<64, 3, 1, 9>(d, x, w_frag, bias, y, stats, s, ax);
+    case 96: return dispatch_geom<96, 3, 1, 9>(d, x, w_frag, bias, y, stats, s, ax);
     case 192:
-    case 384:
-      // grouped: Cin/96 passes of the 96-channel instantiation -- the 96/192/384-channel problems of a depth
-      // level leave as ONE launch (1,480 workgroups at two per CU instead of three launches of 360-640)
-      if (grouped && chunk96) return dispatch_geom<96, 3, 1, 3, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-      // Cin/192 passes over a 192-channel halo image, one tap per filter stage
-      if (split_n) return dispatch_geom<192, 3, 1, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
-      return dispatch_geom<192, 3, 2, 1, false>(d, x, w_frag, bias, y, stats, s, big, ax);
+    case 384: return dispatch_geom<192, 3, 1, 1>(d, x, w_frag, bias, y, stats, s, ax);   // Cin/192 passes, one tap per filter stage
     default: return SSA_EUNSUPPORTED;
   }
 }

@@ -2,14 +2,13 @@
 // (network/hrnetv2.py:31-66), forward and data gradient (gfx950 / MI355X).
 //
 // A workgroup (4 waves) is PERSISTENT over a strip of consecutive 128-pixel tiles (4 rows x 32) of one (problem,
-// pair of 32-channel n-blocks); the input is processed in chunks of 48 channels: a "unit" = one (tile, chunk) =
-// the 6x34-pixel halo image of 48 channels staged in LDS once + 54 MFMAs (32x32x16) per wave.
-//   * the 48-channel instantiation keeps its whole filter slice (54 KB) RESIDENT in LDS for the strip;
-//     the streamed instantiation (96 / 192 / 384 channels) runs the filter as ONE continuous LDS-DMA pipeline over
-//     stages of 3 taps (18 KB) through a ring of THREE buffers: stage s issues the DMAs of stage s + 2 and ends in
-//     `s_waitcnt vmcnt(K) ; s_barrier` with K counted, so two stages of filter are in flight while one is multiplied
-//     (round 3 had two buffers behind __syncthreads(), whose vmcnt(0) made every 18-MFMA stage wait one L2 round
-//     trip for its successor AND for the next halo's loads: 8,600 clocks per unit against 2,200 of MFMA);
+// 32-channel n-block); the input is processed in chunks of 48 channels: a "unit" = one (tile, chunk) = the 6x34-pixel
+// halo image of 48 channels staged in LDS once + 27 MFMAs (32x32x16) per wave.
+//   * the filter runs as ONE continuous LDS-DMA pipeline over stages of 3 taps (9 KB) through a ring of THREE
+//     buffers: stage s issues the DMAs of stage s + 2 and ends in `s_waitcnt vmcnt(K) ; s_barrier` with K counted, so
+//     two stages of filter are in flight while one is multiplied (round 3 had two buffers behind __syncthreads(),
+//     whose vmcnt(0) made every stage wait one L2 round trip for its successor AND for the next halo's loads:
+//     8,600 clocks per 54-MFMA unit against 2,200 of MFMA);
 //   * the next unit's halo is fetched into registers behind the current unit's DMAs, and no barrier of the loop
 //     waits for it (the barriers wait on LDS traffic only: `s_waitcnt lgkmcnt(0) ; s_barrier`);
 //   * the MFMA operands are SWAPPED (filter fragment as A, pixel fragment as B): the accumulator of a lane then
@@ -17,11 +16,19 @@
 //     registers, completes 16-byte pieces with v_permlane32_swap and stores straight to HBM -- no LDS staging, no
 //     barrier between the MFMAs and the stores (round 3: 64 ds_write_b16 + re-read per lane and tile, 1,300-2,000
 //     clocks per unit);
-//   * BatchNorm statistics of the bf16-rounded outputs stay in registers over the strip (a lane owns 16 channels
-//     per n-block), are reduced over the 32 pixel lanes with DPP adds once per strip and leave as one fp64 atomic
-//     per channel and workgroup;
-//   * XCD-aware order: consecutive strips (which share halo rows) and the n-block groups of a strip (which share
-//     the whole halo) go to the same XCD's L2.
+//   * BatchNorm statistics of the bf16-rounded outputs stay in registers over the strip (a lane owns 16 channels),
+//     are reduced over the 32 pixel lanes with DPP adds once per strip and leave as one fp64 atomic per channel and
+//     workgroup;
+//   * 50 KB of LDS and <= 168 registers: THREE workgroups per CU (12 waves), which is what a level of <= 750 short
+//     workgroups wants -- measured against the round's other geometry (two n-blocks per workgroup, the 48-channel
+//     filter resident: 77 KB, two workgroups per CU), profiles/r04_notes.md calls B-E: that one wins the 8-problem level
+//     in isolation (27.0 against 29.1 us) and loses the 4-problem levels (22.0 / 19.1) and the step (22.99 / 22.51 ms);
+//   * XCD-aware order: consecutive strips (which share halo rows) and the n-blocks of a strip (which share the whole
+//     halo) go to the same XCD's L2.
+// What bounds it (phase stamps, -DSSA_TILE_TIMING): with one n-block per wave every MFMA needs 2 KB of LDS reads,
+// i.e. the full 256 B/clk of the CU at the MFMA rate -- the k-loop runs at 62 clocks per MFMA whatever the fragment
+// ring's depth (3 / 4 / 6: no difference) -- and a level is as long as its longest chain: a 384-channel tile is 8
+// units of ~3,800 clocks.
 // Epilogues (as conv_tile.hip): BatchNorm batch statistics; aux_mode 1: + residual gradient; aux_mode 2: bn1's
 // backward sums from (x tile, dz).  (Round 3's BatchNorm-in-the-staging fold was measured slower and is gone.)
 #include "common.h"
@@ -44,7 +51,6 @@ struct TilePArgs {
   const bf16_t* aux; const float* coef;                    // epilogue tile; [4][Cout] table of aux_mode 2
   int ldx, Cin, ldy, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux;
   int total_tiles, tiles_per_wg, ngroups, nwg;
-  int variant, nb_first;
 };
 
 // Bijective XCD-aware order (block b runs on XCD b % 8): XCD x gets one contiguous range of work items.
@@ -113,15 +119,15 @@ struct ConvTileP {
   static constexpr int NFRAG = NB * STAGE_KS;        // 1 KiB filter fragments per stage
   static constexpr int ND = (NFRAG + 3) / 4;         // DMAs per wave and stage (the last ones duplicated: every wave issues ND)
   static constexpr int STAGE_BYTES = NFRAG * 1024;
-  static constexpr bool RESIDENT = NSTAGE == 1;      // the whole filter slice stays in LDS for the strip
-  static constexpr int NBUF = RESIDENT ? 1 : 3;
+  static constexpr int NBUF = 3;
   static constexpr int HALO_RAW = NPIX * PSB;
   static constexpr int HALO_BYTES = (HALO_RAW + 1023) / 1024 * 1024;
   static constexpr int NAUX = NB * 2;                // 16-byte epilogue pieces per lane and tile
   static constexpr size_t LDS = (size_t)HALO_BYTES + (size_t)NBUF * STAGE_BYTES;
   static_assert(NSTAGE * TPC == TAPS, "taps per stage must divide the tap count");
   static_assert(HALO_BYTES - HALO_RAW >= 2 * NB * 32 * 4, "coefficient table of aux_mode 2 does not fit behind the halo image");
-  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(NSTAGE >= 2, "streamed filter");
+  static_assert(LDS <= 53 * 1024, "three workgroups per CU");
   static_assert(4 * 2 * NB * 32 * 4 <= HALO_RAW, "statistics reduction does not fit");
 
   // DMA of one filter stage into dst: ND fragments per wave.  voff[f] = byte offset of this lane's piece of fragment
@@ -153,7 +159,7 @@ struct ConvTileP {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w_ = xcd_order(bx, a.nwg);
     const int strip = w_ / a.ngroups, grp = w_ - strip * a.ngroups;
-    const int nb0 = a.nb_first + grp * NB;
+    const int nb0 = grp * NB;
     const int t_begin = strip * a.tiles_per_wg;
     const int t_end = min(a.total_tiles, t_begin + a.tiles_per_wg);
     const int nchunk = Cin / CK;
@@ -235,7 +241,7 @@ struct ConvTileP {
 
     const int a_off = (wave * HW_ + (lane & 31)) * PSB + (lane >> 5) * 16;   // pixel fragment rows = the wave's tile row
 
-    f32x16_t acc[NB];
+    f32x16_t acc[NB];     // (two accumulators for even / odd k-steps measured the same: the loop is LDS bound, call D)
 
 #ifdef SSA_TILE_TIMING
     long* tdbg = (AUXM == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
@@ -257,20 +263,17 @@ struct ConvTileP {
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(wfrag);
     auto stage_base = [&](int cc_, int tap0) { return wbytes + (long)(tap0 * csteps_total + cc_ * CST) * 1024; };
     stage_filter(stage_base(0, 0), voff, Bs, wave);
-    if constexpr (!RESIDENT) stage_filter(stage_base(0, TPC), voff, Bs + STAGE_BYTES, wave);
+    stage_filter(stage_base(0, TPC), voff, Bs + STAGE_BYTES, wave);
     fetch(0);
     int s = 0;                                         // global filter-stage counter (streamed variant)
     int cc = 0;
     for (int it = 0; it < n_iter; ++it) {
       // everyone is past the barrier that ended the previous unit's MFMAs: the halo image is free
       SSA_STAMP(0);
-      if constexpr (RESIDENT) {
-        if (it > 0) lds_barrier();
-      }
       stage();
       SSA_STAMP(1);
-      if (it == 0) ssa_wait_vm_barrier<RESIDENT ? 0 : ND, 0>();   // + the filter slice / stage 0 landed
-      else lds_barrier();                                         // halo image visible
+      if (it == 0) ssa_wait_vm_barrier<ND, 0>();       // + filter stage 0 landed
+      else lds_barrier();                              // halo image visible
       SSA_STAMP(2);
       const bool last_chunk = cc + 1 == nchunk;
       int ccn = cc + 1;
@@ -288,9 +291,9 @@ struct ConvTileP {
       SSA_STAMP(3);
 #pragma unroll
       for (int st = 0; st < NSTAGE; ++st) {
-        if constexpr (!RESIDENT) {
+        {
           // stage s + 2 of the continuous filter stream (past the end of the strip: a stage nobody reads)
-          const int cc2 = st == 0 ? cc : ccn;
+          const int cc2 = st + 2 < NSTAGE ? cc : ccn;
           const int tap2 = ((st + 2) % NSTAGE) * TPC;
           stage_filter(stage_base(cc2, tap2), voff, Bs + ((s + 2) % 3) * STAGE_BYTES, wave);
         }
@@ -309,9 +312,9 @@ struct ConvTileP {
             }
           }
         }
-        const unsigned char* Bc = Bs + (RESIDENT ? 0 : (s % 3) * STAGE_BYTES) + lane * 16;
+        const unsigned char* Bc = Bs + (s % 3) * STAGE_BYTES + lane * 16;
         // fragments of k-step ksl + RD - 1 are read while the MFMAs of k-step ksl run: a ring of RD register sets
-        constexpr int RD = 4;
+        constexpr int RD = 4;                 // (3 and 6 measured the same, call E)
         bf16x8_t ra[RD], rb[RD][NB];
         auto rd_frag = [&](int ksl) {
           const int tap = st * TPC + ksl / CST, cs = ksl % CST;
@@ -333,17 +336,15 @@ struct ConvTileP {
           __builtin_amdgcn_sched_group_barrier(0x008, NB, 0);
         }
         if (st == 0) SSA_STAMP(4);
-        if constexpr (!RESIDENT) {
-          // stage s + 1 landed (everything issued before this stage's own DMAs / loads); buffer s % 3 and, after the
-          // last stage, the halo image are free
-          if (st == 0) {
-            if (AUX && last_chunk) ssa_wait_vm_barrier<ND + IT + NAUX, 0>();
-            else ssa_wait_vm_barrier<ND + IT, 0>();
-          } else {
-            ssa_wait_vm_barrier<ND, 0>();
-          }
-          ++s;
+        // stage s + 1 landed (everything issued before this stage's own DMAs / loads); buffer s % 3 and, after the
+        // last stage, the halo image are free
+        if (st == 0) {
+          if (AUX && last_chunk) ssa_wait_vm_barrier<ND + IT + NAUX, 0>();
+          else ssa_wait_vm_barrier<ND + IT, 0>();
+        } else {
+          ssa_wait_vm_barrier<ND, 0>();
         }
+        ++s;
         if (st == 0) SSA_STAMP(5);
       }
       SSA_STAMP(6);
@@ -456,72 +457,44 @@ struct ConvTileP {
   }
 };
 
-// The three instantiations a trunk level uses behind ONE kernel:
-//   V0  48 input channels: resident filter, two n-blocks (64 output channels) per workgroup;
-//   V1  96 input channels: streamed filter, two n-blocks per workgroup (the third n-block of a 96-channel layer: V2);
-//   V2  192 / 384 input channels: streamed filter, ONE n-block per workgroup -- a tile of these layers is a serial chain
-//       of 4 / 8 channel chunks, and what bounds a level is its longest chain (profiles/r04_notes.md, call A: 384 @ 32x32
-//       alone 20.4 us with two n-blocks per workgroup = 60 workgroups x 8 units of 54 MFMAs), so the deep layers get
-//       twice the workgroups with half the work each.
 template <int AUXM>
-struct ConvTilePAny {
+struct ConvTilePK {
   typedef TilePArgs Args;
   static constexpr int NT = 256;
-  typedef ConvTileP<2, 9, AUXM> V0;
-  typedef ConvTileP<2, 3, AUXM> V1;
-  typedef ConvTileP<1, 3, AUXM> V2;
+  static constexpr int WPE = 3;                  // three workgroups per CU: <= 168 registers
+  typedef ConvTileP<1, 3, AUXM> V;
 #ifdef SSA_TILE_TIMING
-  static constexpr size_t LDS = (V0::LDS > V1::LDS ? V0::LDS : V1::LDS) + 1536;
+  static constexpr size_t LDS = V::LDS + 1536;
 #else
-  static constexpr size_t LDS = V0::LDS > V1::LDS ? V0::LDS : V1::LDS;
+  static constexpr size_t LDS = V::LDS;
 #endif
-  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) {
-    if (a.variant == 0) V0::run(a, bx, by, gx);
-    else if (a.variant == 1) V1::run(a, bx, by, gx);
-    else V2::run(a, bx, by, gx);
-  }
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int gx) { V::run(a, bx, by, gx); }
 };
 
-static thread_local int g_strip_units = 0;     // work units (54 MFMAs per wave) per workgroup, 0 = per problem
+static thread_local int g_strip_units = 0;     // work units (27 MFMAs per wave) per workgroup, 0 = per problem
 
-// one job = the n-blocks [nb_first, nb_first + nblocks) of the problem on instantiation `variant` (NB n-blocks per group)
 template <int AUXM>
-int submit_p(const ssa_conv_desc& d, TilePArgs a, int variant, int NB, int nb_first, int nblocks, hipStream_t s) {
+int launch_p(const ssa_conv_desc& d, const TilePArgs& a0, hipStream_t s) {
+  TilePArgs a = a0;
   const int nchunk = d.Cin / 48;
-  a.variant = variant;
-  a.nb_first = nb_first;
   a.nb_total = (d.Cout + 31) / 32;
   a.tiles_x = (d.W + 31) / 32;
   a.tiles_y = (d.H + 3) / 4;
   a.total_tiles = d.B * a.tiles_x * a.tiles_y;
-  a.ngroups = (nblocks + NB - 1) / NB;
+  a.ngroups = a.nb_total;
   int units = g_strip_units;
   if (units <= 0) {
-    // a launch of its own: ~2 workgroups per CU from this problem alone
+    // a launch of its own: ~3 workgroups per CU from this problem alone
     const long total = (long)a.total_tiles * a.ngroups * nchunk;
-    units = (int)((total * NB / 2 + 511) / 512);
+    units = (int)((total + 767) / 768);
   }
-  if (units > 32) units = 32;
-  int tpw = units * 2 / (NB * nchunk);        // a unit of the one-n-block instantiation is half a unit of work
+  if (units > 64) units = 64;
+  int tpw = units / nchunk;
   if (tpw < 1) tpw = 1;
   const int nstrips = (a.total_tiles + tpw - 1) / tpw;
   a.tiles_per_wg = (a.total_tiles + nstrips - 1) / nstrips;
   a.nwg = ((a.total_tiles + a.tiles_per_wg - 1) / a.tiles_per_wg) * a.ngroups;
-  return ssa::submit<ConvTilePAny<AUXM>>(a, a.nwg, 1, ConvTilePAny<AUXM>::LDS, s);
-}
-
-template <int AUXM>
-int launch_p(const ssa_conv_desc& d, const TilePArgs& a, hipStream_t s) {
-  const int nb_total = (d.Cout + 31) / 32;
-  if (d.Cin == 48) return submit_p<AUXM>(d, a, 0, 2, 0, nb_total, s);
-  if (d.Cin == 96) {
-    const int pairs = nb_total / 2;
-    if (pairs > 0)
-      if (int rc = submit_p<AUXM>(d, a, 1, 2, 0, 2 * pairs, s)) return rc;
-    if (nb_total & 1) return submit_p<AUXM>(d, a, 2, 1, 2 * pairs, 1, s);
-    return 0;
-  }
-  return submit_p<AUXM>(d, a, 2, 1, 0, nb_total, s);
+  return ssa::submit<ConvTilePK<AUXM>>(a, a.nwg, 1, ConvTilePK<AUXM>::LDS, s);
 }
 
 }  // namespace
@@ -556,7 +529,7 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* w_frag
   a.y = (bf16_t*)y; a.stats = stats; a.aux = (const bf16_t*)aux; a.coef = coef;
   a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
   a.ldaux = ldaux;
-  a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = a.variant = a.nb_first = 0;
+  a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (aux_mode) {
     case 0: return launch_p<0>(d, a, s);

@@ -542,47 +542,37 @@ def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
 
 
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs
-_TILE_P = os.environ.get("SSA_TILE_P", "1") != "0"
-_TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "500"))      # most workgroups a grouped level may launch (< 2 per CU)
+_TILE_P_WGS = int(os.environ.get("SSA_TILE_P_WGS", "750"))      # most workgroups a grouped level may launch (< 3 per CU)
 
 def tile_p_supported(d):
-    return _TILE_P and bool(lib().ssa_conv2d_tile_p_supported(ctypes.byref(d)))
+    return bool(lib().ssa_conv2d_tile_p_supported(ctypes.byref(d)))
 
 
 def _tile_p_wgs(d, units):
     """Workgroups ssa_conv2d_tile_p launches for this problem at `units` (one 128-pixel tile x one 48-channel chunk
-    of the input x two n-blocks: 54 MFMAs per wave) per workgroup -- mirror of launch_p / submit_p in
-    csrc/conv_tile_p.hip: 48 and 96 input channels run two n-blocks per workgroup (a 96-channel layer's third n-block
-    on the one-n-block instantiation), 192 / 384 one n-block per workgroup."""
+    of the input x one 32-channel n-block: 27 MFMAs per wave) per workgroup -- mirror of launch_p in
+    csrc/conv_tile_p.hip."""
     tiles = d.B * ((d.W + 31) // 32) * ((d.H + 3) // 4)
     nb = (d.Cout + 31) // 32
     nchunk = d.Cin // 48
-
-    def job(NB, nblocks):
-        groups = -(-nblocks // NB)
-        tpw = max(1, units * 2 // (NB * nchunk))
-        nstrips = -(-tiles // tpw)
-        tpw = -(-tiles // nstrips)
-        return -(-tiles // tpw) * groups
-    if d.Cin == 48:
-        return job(2, nb)
-    if d.Cin == 96:
-        return (job(2, 2 * (nb // 2)) if nb // 2 else 0) + (job(1, 1) if nb & 1 else 0)
-    return job(1, nb)
+    tpw = max(1, units // nchunk)
+    nstrips = -(-tiles // tpw)
+    tpw = -(-tiles // nstrips)
+    return -(-tiles // tpw) * nb
 
 
 @contextlib.contextmanager
 def tile_strip(descs):
     """Strip length of the persistent conv kernel for a level whose 3x3 problems are `descs` (those the kernel does
-    not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (two per CU) --
-    a grouped launch of 520 workgroups runs as two rounds of 512 + 8 and takes 37 us where 492 take 29
-    (profiles/r03_notes.md, call D).  Handed to the library for the launches issued inside the bracket (same thread)."""
+    not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (three per CU;
+    a level of more workgroups than slots runs as two rounds: profiles/r03_notes.md call D, r04_notes.md call C).
+    Handed to the library for the launches issued inside the bracket (same thread)."""
     ds = [d for d in descs if tile_p_supported(d)]
     if not ds:
         yield
         return
-    units = 32
-    for u in range(1, 33):
+    units = 64
+    for u in range(1, 65):
         if sum(_tile_p_wgs(d, u) for d in ds) <= _TILE_P_WGS:
             units = u
             break

@@ -89,7 +89,7 @@ def test_teacher_forced_ops_at_1024():
         # the trunk levels' 3x3 convs: the resident (48 channels) and the streamed instantiation behind one kernel,
         # conv_tile_p.hip: plain forward <0>, data gradient with the residual gradient <1> / the BatchNorm-backward
         # sums <2> in the epilogue
-        for inst in ("ConvTilePAny<0>", "ConvTilePAny<1>", "ConvTilePAny<2>"):
+        for inst in ("ConvTilePK<0>", "ConvTilePK<1>", "ConvTilePK<2>"):
             assert inst in names, "%s is not on the path" % inst
         assert any(n.startswith("ConvWgradTile<96,") for n in names)
     assert not tb.rec.failures(), tb.rec.summary(30)

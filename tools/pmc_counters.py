@@ -35,7 +35,7 @@ def inst(name):
 
 def family(i):
     f = re.sub(r"<.*", "", i)
-    if f in ("ConvTileAny", "ConvTilePAny", "ConvTileP"):
+    if f in ("ConvTileAny", "ConvTilePAny", "ConvTilePK", "ConvTileP"):
         return "ConvTile"
     return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead"}.get(f, f)
 

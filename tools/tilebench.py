@@ -99,7 +99,7 @@ def main():
     t = timeit(level_old, reps)
     print("level (8 problems, %.1f GFLOP, %.1f MB): old grouped %.1f us = %.0f TF/s, %.0f GB/s" % (fl / 1e9, by / 1e6, t, fl / t / 1e6, by / t / 1e3))
     best = (1e9, 4)
-    for u in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+    for u in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
         L.ssa_conv_tile_strip(u)
         t = timeit(level_new, reps)
         best = min(best, (t, u))
