@@ -33,6 +33,13 @@ extern "C" {
 #define SSA_EUNSUPPORTED (-2)
 
 int ssa_version(void);
+/* Storage format of the 16-bit activations this build was compiled for (csrc/common.h): 0 = bf16
+ * (libsemseg_hip.so), 1 = fp16 (libsemseg_hip_f16.so, -DSSA_ELEM_F16; the reference's --fp16 / apex O1 format,
+ * train.py:381).  Every `bf16` in the names and comments below reads "the build's 16-bit element".            */
+int ssa_elem_type(void);
+/* First 16 hex digits of sha256 over the kernel sources the library was built from (csrc/Makefile): the Python
+ * loader recomputes it over the sources next to the binary and refuses a stale build.                          */
+const char* ssa_source_sha(void);
 
 /* ------------------------------------------------------- grouped launches --
  * The 2-4 resolution branches of a HighResolutionModule (network/hrnetv2.py:181-254)

@@ -1,12 +1,23 @@
 // Shared device helpers for the gfx950 (CDNA4) segmentation kernels.
-// Activations are NHWC, bf16 stored as raw 16-bit words; all arithmetic is
+// Activations are NHWC, 16-bit elements stored as raw words; all arithmetic is
 // fp32 (fp64 for the BN / RMI statistics).
+//
+// The 16-bit STORAGE FORMAT is an instantiation parameter of the whole library: every conversion and the MFMA
+// go through the handful of helpers below, and the build compiles the same sources twice --
+//   libsemseg_hip.so       bf16 storage (default; v_mfma_f32_32x32x16_bf16)
+//   libsemseg_hip_f16.so   fp16 storage (-DSSA_ELEM_F16; v_mfma_f32_32x32x16_f16, same rate) -- the reference's own
+//                          reduced precision (apex O1 / --fp16, train.py:381), 8x finer than bf16
+// (the names bf16_t / bf2f / f2bf keep their round-1 spelling: "the 16-bit activation element").
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;                                   // raw bf16 bits
+typedef unsigned short bf16_t;                                   // raw bits of a 16-bit activation element
+#ifdef SSA_ELEM_F16
+typedef _Float16 bf16x8_t __attribute__((ext_vector_type(8)));   // MFMA A/B fragment
+#else
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));     // MFMA A/B fragment
+#endif
 typedef float f32x16_t __attribute__((ext_vector_type(16)));     // 32x32 MFMA C/D
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -17,7 +28,11 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 // never defines SSA_EMU.
 #ifdef SSA_EMU
 #define SSA_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::dyn_lds())
+#ifdef SSA_ELEM_F16
+__device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return emu::mfma_32x32x16_f16(a, b, c); }
+#else
 __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return emu::mfma_32x32x16_bf16(a, b, c); }
+#endif
 __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return emu::ds_read_tr16_b64(lds_ptr); }
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
 __device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
@@ -30,7 +45,11 @@ __device__ __forceinline__ void ssa_glds16_untracked_sv(const void* sbase, unsig
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
 __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+#ifdef SSA_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 // ds_read_b64_tr_b16: 4x4 transposing LDS read (lane map: tests/test_kernels_gpu.py::test_probe_tr16)
 __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) {
@@ -94,12 +113,32 @@ namespace ssa { void count_launches(int n); }   // group.hip: library-wide launc
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifdef SSA_ELEM_F16
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even (v_cvt_f16_f32 / v_cvt_pk_f16_f32 under the default rounding mode); values beyond 65504
+// become inf -- the activations this library stores are BatchNorm outputs and conv outputs of normalised inputs
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t f2bf_pair(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w[i]);
+    f[2 * i] = (float)h[0];
+    f[2 * i + 1] = (float)h[1];
+  }
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t v) {
   return __uint_as_float(((uint32_t)v) << 16);
 }
 // round-to-nearest-even, NaN kept quiet: v_cvt_pk_bf16_f32 on gfx950 (one instruction; the shift-and-add
 // sequence it replaces was five VALU operations per element in every epilogue and staging transform)
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, (__bf16)f);
@@ -114,6 +153,7 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
+#endif
 __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 v;
   v.x = f2bf_pair(f[0], f[1]);

@@ -71,6 +71,23 @@ static SideStreams* side_streams() {
 
 extern "C" {
 
+// 0: bf16 storage (libsemseg_hip.so), 1: fp16 storage (libsemseg_hip_f16.so, -DSSA_ELEM_F16) -- the loader checks it
+int ssa_elem_type(void) {
+#ifdef SSA_ELEM_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// first 16 hex digits of sha256 over the kernel sources this library was built from (csrc/Makefile); the loader
+// recomputes it over the sources next to the binary and refuses a stale build
+#ifndef SSA_SOURCE_SHA
+#define SSA_SOURCE_SHA "unknown"
+#endif
+const char* ssa_source_sha(void) { return SSA_SOURCE_SHA; }
+
+
 int ssa_group_begin(void) {
   ssa::GroupState& g = ssa::group_state();
   if (g.depth == 0) {

@@ -10,9 +10,34 @@ import os
 from ctypes import c_int, c_long, c_float, c_double, c_void_p, c_size_t, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsemseg_hip.so"))
+# Storage format of the 16-bit activations = which build of the library the process runs on (csrc/common.h):
+#   SSA_ACT_DTYPE=bf16 (default)  lib/libsemseg_hip.so
+#   SSA_ACT_DTYPE=fp16            lib/libsemseg_hip_f16.so -- the reference's own reduced precision (--fp16 / apex O1)
+ACT = os.environ.get("SSA_ACT_DTYPE", "bf16").lower()
+if ACT in ("f16", "float16", "half"):
+    ACT = "fp16"
+if ACT not in ("bf16", "fp16"):
+    raise RuntimeError("SSA_ACT_DTYPE must be bf16 or fp16, not %r" % ACT)
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsemseg_hip.so" if ACT == "bf16" else "libsemseg_hip_f16.so"))
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 
 _LIB = None
+
+
+def source_sha():
+    """First 16 hex digits of sha256 over the kernel sources next to the library -- what csrc/Makefile embeds in the
+    binary (ssa_source_sha).  None if the sources are not there (a binary-only installation)."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "group.h"),
+                                                              os.path.normpath(os.path.join(_HERE, "..", "..", "include", "semseg_hip.h"))]
+    if not files or not all(os.path.exists(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 class PackJob(ctypes.Structure):
@@ -44,6 +69,8 @@ class ConvDesc(ctypes.Structure):
 _P = c_void_p
 _SIGS = {
     "ssa_version": ([], c_int),
+    "ssa_elem_type": ([], c_int),
+    "ssa_source_sha": ([], ctypes.c_char_p),
     "ssa_group_begin": ([], c_int),
     "ssa_group_end": ([_P], c_int),
     "ssa_group_abort": ([], c_int),
@@ -165,9 +192,20 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         if missing:
-            raise RuntimeError("libsemseg_hip.so is stale, missing symbols: %s" % ", ".join(missing))
+            raise RuntimeError("%s is stale, missing symbols: %s" % (os.path.basename(LIB_PATH), ", ".join(missing)))
+        if handle.ssa_elem_type() != (1 if ACT == "fp16" else 0):
+            raise RuntimeError("%s was built for the other storage format (SSA_ACT_DTYPE=%s)" % (LIB_PATH, ACT))
+        # the binary is git-ignored and travels as a file: tie it to the sources it claims to be built from
+        built, here = handle.ssa_source_sha().decode(), source_sha()
+        if here is not None and built != here and os.environ.get("SSA_ALLOW_STALE_LIB", "0") != "1":
+            raise RuntimeError("%s was built from other sources (embedded %s, csrc/ now %s): rebuild with "
+                               "`make -C semantic-segmentation_amd/csrc`" % (os.path.basename(LIB_PATH), built, here))
         _LIB = handle
     return _LIB
+
+
+def built_sha():
+    return lib().ssa_source_sha().decode()
 
 
 def check(rc, what):

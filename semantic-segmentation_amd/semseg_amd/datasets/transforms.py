@@ -73,7 +73,8 @@ def crop_flip_normalize(img_u8, labels_u8, window, flip, mean_std=MEAN_STD):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     mean = (ctypes.c_float * 3)(*mean_std[0])
     std = (ctypes.c_float * 3)(*mean_std[1])
-    out = torch.empty((1, ch, cw, 16), dtype=torch.bfloat16, device=img_u8.device)
+    from ..hip_backend import ACT_DTYPE
+    out = torch.empty((1, ch, cw, 16), dtype=ACT_DTYPE, device=img_u8.device)
     check(lib().ssa_image_u8_crop_flip_normalize(ctypes.c_void_p(img_u8.data_ptr()), H, W, x0, y0, cw, ch, int(bool(flip)),
                                                  mean, std, ctypes.c_void_p(out.data_ptr()), 16, stream),
           "ssa_image_u8_crop_flip_normalize")

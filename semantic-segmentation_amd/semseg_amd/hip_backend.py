@@ -31,7 +31,16 @@ import torch
 
 from ._lib import lib, check, ConvDesc, PackJob, BnUpdateJob, ProfileRec
 
-ACT_DTYPE = torch.bfloat16
+from ._lib import ACT as _ACT_NAME     # storage format of the activations = the library build (SSA_ACT_DTYPE)
+ACT_DTYPE = torch.float16 if _ACT_NAME == "fp16" else torch.bfloat16
+
+
+def _no_fp16_training():
+    """fp16 storage is the EVALUATION path this round: a 1024x1024 step's per-pixel loss gradients (~1e-6) underflow
+    fp16 without the loss scaling apex O1 applies (amp.scale_loss, train.py:504), which the captured step does not
+    carry yet.  Raise rather than train on flushed gradients."""
+    if _ACT_NAME == "fp16":
+        raise NotImplementedError("SSA_ACT_DTYPE=fp16 is the evaluation path; train with bf16 storage (the default)")
 
 
 def _s():
@@ -1884,6 +1893,7 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
+        _no_fp16_training()
         dl, acc = ctx.saved_tensors
         up = up.float().contiguous()
         g = dl.clone()
@@ -1931,6 +1941,7 @@ class BceRmiFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
+        _no_fp16_training()
         L = lib()
         up = up.float().contiguous()
         if not ctx.do_rmi:

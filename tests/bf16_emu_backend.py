@@ -20,7 +20,8 @@ import contextlib
 # storage type the emulation rounds to: bf16 = the product's; fp16 = what the reference's apex-O1 path stores
 # (`storage(torch.float16)`: the noise floor the REFERENCE'S OWN mixed-precision run has against its fp32 run,
 # tests/test_storage_floor_cpu.py)
-_STORAGE = [torch.bfloat16]
+from util import ACT_DTYPE as _ACT
+_STORAGE = [_ACT]     # the product's storage format in this process (SSA_ACT_DTYPE)
 
 
 @contextlib.contextmanager

@@ -14,13 +14,15 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU_LIB = os.path.join(ROOT, "tools", "emu", "build", "libsemseg_emu.so")
+_F16 = os.environ.get("SSA_ACT_DTYPE", "bf16").lower() in ("fp16", "f16", "float16", "half")
+EMU_LIB = os.path.join(ROOT, "tools", "emu", "build_f16" if _F16 else "build", "libsemseg_emu.so")
 
 _HANDLE = None
 
 
 def build_emu():
-    subprocess.check_call(["sh", os.path.join(ROOT, "tools", "emu", "build.sh")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["sh", os.path.join(ROOT, "tools", "emu", "build.sh")] + (["f16"] if _F16 else []),
+                          stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 

@@ -15,6 +15,8 @@ import threading
 
 import torch
 
+from util import ACT_DTYPE
+
 from bf16_emu_backend import Bf16EmuBackend
 from semseg_amd.ops import BackendBase, _is_list, _lst
 
@@ -40,8 +42,11 @@ class Record:
         self.n_ops = 0
 
     def add(self, idx, op, what, got, ref, tol):
-        got = got.detach().float().cpu()
-        ref = ref.detach().float().cpu()
+        # compared where the larger side already is (a device-side teacher's tensors stay on the device: a
+        # 2048 x 4096 activation is 400 MB, its round trip over PCIe would dominate the test)
+        dev = got.device if got.is_cuda else ref.device
+        got = got.detach().to(dev).float()
+        ref = ref.detach().to(dev).float()
         assert got.shape == ref.shape, (op, what, got.shape, ref.shape)
         finite = bool(torch.isfinite(got).all())
         err = (got - ref).abs()
@@ -90,7 +95,7 @@ def _hip_dtype(t):
     d = getattr(t, "_hip_dtype", None)
     if d is not None:
         return d
-    return torch.float32 if (t.dim() == 4 and t.shape[-1] in F32_CHANNELS) or t.dim() == 0 else torch.bfloat16
+    return torch.float32 if (t.dim() == 4 and t.shape[-1] in F32_CHANNELS) or t.dim() == 0 else ACT_DTYPE
 
 
 def _isolated(fn):
@@ -186,9 +191,13 @@ class TeacherBackend(BackendBase):
     name = "teacher-forced"
     act_dtype = torch.float32
 
-    def __init__(self, cpu_net, hip_net, device="cuda"):
+    def __init__(self, cpu_net, hip_net, device="cuda", teacher_device="cpu"):
         """device='cpu': self-test of this harness -- the 'HIP' side is a second emulation backend on
-        CPU mirrors (tests/test_teacher_cpu.py), every comparison must then come out exact."""
+        CPU mirrors (tests/test_teacher_cpu.py), every comparison must then come out exact.
+        teacher_device='cuda': the teacher (`cpu_net`, moved there by the caller) runs the SAME oracle operators --
+        plain torch fp32 -- on the device (SURVEY.md section 8c's "second oracle": the reference's arithmetic on ROCm
+        PyTorch), which is what makes the full-size evaluation shapes (2048 x 4096 passes, Mapillary-sized images)
+        affordable inside the GPU suite; tests/test_parity_eval_gpu.py pins it to the CPU oracle at a small shape."""
         from semseg_amd import ops
         self.emu = Bf16EmuBackend()
         self.device = device
@@ -196,7 +205,7 @@ class TeacherBackend(BackendBase):
         self.hip = ops.HipBackend() if device != "cpu" else Bf16EmuBackend()
         self.rec = Record()
         self.debug = None            # optional callable, see tools/debug_teacher.py
-        self._anchor = torch.zeros((), requires_grad=True)
+        self._anchor = torch.zeros((), requires_grad=True, device=teacher_device)
         self.mod = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_modules(), hip_net.named_modules())}
         self.par = {id(a): b for (_, a), (_, b) in zip(cpu_net.named_parameters(), hip_net.named_parameters())}
 
@@ -235,7 +244,7 @@ class TeacherBackend(BackendBase):
         got = self.hip.image_to_nhwc(images.to(self.device), out_hw)
         self.rec.add(self.rec.n_ops, "image_to_nhwc", "out0", got, ref, BF16_TOL)
         self.rec.n_ops += 1
-        ref._hip_dtype = torch.bfloat16
+        ref._hip_dtype = ACT_DTYPE
         return ref
 
     # -- list-aware public surface
@@ -342,7 +351,7 @@ class TeacherBackend(BackendBase):
 
     def to_act(self, x):
         y = self.emu.to_act(x)
-        y._hip_dtype = torch.bfloat16
+        y._hip_dtype = ACT_DTYPE
         return y
 
     def ocr_gather(self, feats, logits):
@@ -355,7 +364,7 @@ class TeacherBackend(BackendBase):
     def ocr_attention(self, q, k, v, scale):
         for t in (k, v):
             if not hasattr(t, "_hip_dtype"):
-                t._hip_dtype = torch.bfloat16
+                t._hip_dtype = ACT_DTYPE
         return self._one("ocr_attention", "ocr_attention", [q, k, v], ((2e-2, 8e-3), (3e-2, 1.5e-2)), (scale,))
 
     def sigmoid(self, x):

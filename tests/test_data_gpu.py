@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import ACT_DTYPE
+
 from test_data_cpu import golden_masks, checksums
 
 pytestmark = pytest.mark.gpu
@@ -85,7 +87,7 @@ def test_pipeline_tail_on_device_is_bit_exact():
         out, gts = crop_flip_normalize(torch.from_numpy(img).cuda(), torch.from_numpy(lab).cuda(), window, flip,
                                        (g["mean"], g["std"]))
         want_im, want_lab = oracle(img, lab, window, flip, g["mean"], g["std"])
-        want = torch.from_numpy(want_im).permute(1, 2, 0).to(torch.bfloat16)
+        want = torch.from_numpy(want_im).permute(1, 2, 0).to(ACT_DTYPE)
         got = out[0].cpu()
         assert torch.equal(got[..., :3].view(torch.int16), want.contiguous().view(torch.int16)), window
         assert int(got[..., 3:].abs().max()) == 0

@@ -141,6 +141,12 @@ def test_eval_op_by_op(setup):
         print("eval %-9s rel err hip %.4f emu %.4f" % (k, eh, ee))
         assert torch.isfinite(hip[k]).all()
         assert eh <= 1.5 * ee + 5e-3, k
+    from util import ACT_DTYPE
+    if ACT_DTYPE == torch.float16:
+        # the reference's own storage format: an order of magnitude closer to the fp32 oracle than bf16 (~0.17)
+        eh = _rel(hip["pred"], ref["pred"])
+        print("fp16 storage: eval pred rel err %.4f (emulation %.4f)" % (eh, _rel(emu["pred"], ref["pred"])))
+        assert eh <= 0.03, eh
     ah = (hip["pred"].argmax(1) == ref["pred"].argmax(1)).float().mean().item()
     ae = (emu["pred"].argmax(1) == ref["pred"].argmax(1)).float().mean().item()
     print("argmax agreement with the oracle: hip %.4f emu %.4f" % (ah, ae))

@@ -1,0 +1,61 @@
+"""The fp16-storage instantiation of the library (lib/libsemseg_hip_f16.so, -DSSA_ELEM_F16; SSA_ACT_DTYPE=fp16) -- the
+reference's own reduced precision (--fp16 / apex O1: train.py:381, scripts/eval_mapillary.yml:10,14; BASELINE.json
+configs[4]).
+
+The storage format is a property of the process (one library build per process), so the SAME test files run again in a
+child process with SSA_ACT_DTYPE=fp16: tests/util.py rounds inputs / references to the product's format, the
+storage-emulation backend (tests/bf16_emu_backend.py) follows it, and the end-to-end evaluation test additionally
+asserts the fp16 bound (eval `pred` relative error <= 0.03: 1.5 x the ~0.013-0.02 floor fp16 storage itself gives on
+this network, against ~0.17 for bf16).  Training in fp16 needs the reference's loss scaling and is refused by the
+product (hip_backend._no_fp16_training)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, log, timeout):
+    env = dict(os.environ, SSA_ACT_DTYPE="fp16")
+    env.pop("PYTEST_CURRENT_TEST", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-s"] + args,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", log), "w") as f:
+        f.write(r.stdout[-200000:])
+        f.write(r.stderr[-20000:])
+    tail = "\n".join(r.stdout.splitlines()[-25:])
+    assert r.returncode == 0, "%s under SSA_ACT_DTYPE=fp16:\n%s\n%s" % (args, tail, r.stderr[-2000:])
+    assert " passed" in tail and " failed" not in tail, tail
+    return r.stdout
+
+
+@pytest.mark.gpu
+def test_kernels_on_the_fp16_build():
+    """Every op-level kernel test (forward, data and weight gradients, BatchNorm, resampling, OCR, losses) against the
+    oracle with fp16-rounded inputs, and the grouped / fused-backward tests."""
+    _run(["tests/test_kernels_gpu.py", "tests/test_group_gpu.py", "tests/test_fuse_bwd_gpu.py"], "fp16_kernels.log", 900)
+
+
+@pytest.mark.gpu
+def test_eval_end_to_end_on_the_fp16_build():
+    """HRNet-OCR-MScale evaluation (two-scale and hierarchical {0.5, 1, 2}) end to end against the fp32 oracle: within
+    1.5 x the fp16-storage emulation at every tensor the operator surface returns, and `pred` within 0.03 relative."""
+    out = _run(["tests/test_e2e_gpu.py", "-k", "eval_op_by_op or eval_nscale"], "fp16_e2e_eval.log", 900)
+    assert "fp16 storage: eval pred rel err" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_training_is_refused_on_the_fp16_build():
+    code = ("import os, sys; sys.path[:0] = [%r, %r]\n"
+            "import torch\n"
+            "from semseg_amd.loss import CrossEntropyLoss2d\n"
+            "x = torch.randn(1, 19, 8, 8, device='cuda', requires_grad=True)\n"
+            "l = CrossEntropyLoss2d(ignore_index=255).cuda()(x, torch.zeros(1, 8, 8, dtype=torch.long, device='cuda'))\n"
+            "try:\n    l.backward()\nexcept (NotImplementedError, RuntimeError) as e:\n    print('REFUSED', type(e).__name__)\n"
+            % (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SSA_ACT_DTYPE="fp16"),
+                       capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout, r.stdout + r.stderr[-2000:]

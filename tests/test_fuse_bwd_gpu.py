@@ -7,6 +7,8 @@ import os
 import pytest
 import torch
 
+from util import ACT_DTYPE
+
 pytestmark = pytest.mark.gpu
 
 
@@ -18,9 +20,9 @@ def _setup(B, H, W, C, seed):
     from semseg_amd import hip_backend as hb
     from semseg_amd._lib import ConvDesc
     g = torch.Generator().manual_seed(seed)
-    dy = (torch.randn(B, H, W, C, generator=g)).to(torch.bfloat16).cuda()
+    dy = (torch.randn(B, H, W, C, generator=g)).to(ACT_DTYPE).cuda()
     w = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
-    aux = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).cuda()
+    aux = torch.randn(B, H, W, C, generator=g).to(ACT_DTYPE).cuda()
     hb.clear_pack_cache()
     wpt, _ = hb._packed_filter(w, 3, 0, C)
     d = hb._tile_desc(B, H, W, C, C, C, (3, 3), 1, 1, 1, H, W, False)
@@ -34,7 +36,7 @@ def test_aux_add_is_the_unfused_add(B, H, W, C):
     ref = hb._tile_conv(d, dy, wpt, None, None)
     out = hb._tile_conv_aux(d, dy, wpt, None, aux, C, None, 1)
     torch.cuda.synchronize()
-    want = (ref.float() + aux.float()).to(torch.bfloat16)       # what autograd's bf16 add produces
+    want = (ref.float() + aux.float()).to(ACT_DTYPE)       # what autograd's bf16 add produces
     assert torch.equal(out, want)
 
 

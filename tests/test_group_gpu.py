@@ -15,7 +15,7 @@ import math
 import pytest
 import torch
 
-from util import bf16_round, check_close, check_close_robust, nhwc, nchw
+from util import bf16_round, check_close, check_close_robust, nhwc, nchw, ACT_DTYPE
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -32,7 +32,7 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 def _dev(x):
-    return nhwc(x).to(DEV).to(torch.bfloat16).contiguous()
+    return nhwc(x).to(DEV).to(ACT_DTYPE).contiguous()
 
 
 def _hb():

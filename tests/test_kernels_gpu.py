@@ -13,7 +13,7 @@ import os
 import pytest
 import torch
 
-from util import bf16_round, check_close, report, nhwc, nchw
+from util import bf16_round, check_close, report, nhwc, nchw, ACT_DTYPE
 
 pytestmark = pytest.mark.gpu
 
@@ -36,8 +36,8 @@ def test_probe_mfma32(out_dir):
     import ctypes
     a = _rand(32, 16, seed=1)
     b = _rand(16, 32, seed=2)       # asymmetric on purpose
-    a_d = a.to(DEV).to(torch.bfloat16).contiguous()
-    bt_d = b.t().contiguous().to(DEV).to(torch.bfloat16)
+    a_d = a.to(DEV).to(ACT_DTYPE).contiguous()
+    bt_d = b.t().contiguous().to(DEV).to(ACT_DTYPE)
     c_d = torch.zeros(32, 32, device=DEV)
     check(lib().ssa_probe_mfma32(ctypes.c_void_p(a_d.data_ptr()), ctypes.c_void_p(bt_d.data_ptr()),
                                  ctypes.c_void_p(c_d.data_ptr()), None), "probe")
@@ -117,7 +117,7 @@ def _to_dev_nhwc(x, cpad=None):
     t = nhwc(x)
     if cpad is not None and cpad > t.shape[3]:
         t = torch.nn.functional.pad(t, (0, cpad - t.shape[3]))
-    return t.to(DEV).to(torch.bfloat16).contiguous()
+    return t.to(DEV).to(ACT_DTYPE).contiguous()
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -144,7 +144,7 @@ def test_conv_fwd_bwd(case):
     check_close("conv_fwd %s" % (case,), nchw(yd.float()), yr, *tol)
     gyd = nhwc(gy).to(DEV)
     if not out_f32:
-        gyd = gyd.to(torch.bfloat16)
+        gyd = gyd.to(ACT_DTYPE)
     yd.backward(gyd)
     torch.cuda.synchronize()
     if cin_pad == Cin:
@@ -164,7 +164,7 @@ def test_stride2_dgrad_by_parity_matches_zero_inserted():
         hb.clear_pack_cache()
         w = _rand(Cout, Cin, 3, 3, seed=11, scale=0.05).to(DEV)
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        dy = nhwc(_rand(B, Cout, Ho, Wo, seed=12)).to(DEV).to(torch.bfloat16).contiguous()
+        dy = nhwc(_rand(B, Cout, Ho, Wo, seed=12)).to(DEV).to(ACT_DTYPE).contiguous()
         assert hb._DGRAD_S2
         got = hb._conv_dgrad((B, H, W, Cin), w, dy, Cout, Cout, 2, 1, 1, (Ho, Wo))
         hb._DGRAD_S2 = False
@@ -249,7 +249,7 @@ def test_wgrad_tile_kernel(C, B, H, W):
     w = torch.zeros(C, C, 3, 3, requires_grad=True)
     O.conv2d(x, w, None, 1, 1, 1).backward(gy)
     xd = _to_dev_nhwc(x)
-    gd = nhwc(gy).to(DEV).to(torch.bfloat16).contiguous()
+    gd = nhwc(gy).to(DEV).to(ACT_DTYPE).contiguous()
     d = ConvDesc(B, H, W, C, C, H, W, C, C, 3, 3, 1, 1, 1, 0, 0, 0, -1)
     ns, ws = ctypes.c_int(0), ctypes.c_size_t(0)
     L = lib()
@@ -378,7 +378,7 @@ def test_bn_train(C, relu, res, post):
     pmd = pm.to(DEV) if post else None
     nbt = torch.zeros((), dtype=torch.long, device=DEV)
     z = hb.BatchNormActFn.apply(xd, gd, bd, rd, pmd, rmd, rvd, nbt, 0.1, 1e-5, True, relu, False, None)
-    z.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    z.backward(nhwc(gy).to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
     check_close("bn_fwd", nchw(z.float()), y)
     check_close("bn_running_mean", rmd, rm, 1e-4, 1e-4)
@@ -448,7 +448,7 @@ def test_maxpool3x3s2(B, C, H, W):
     yr.backward(gy)
     xd = _to_dev_nhwc(x).requires_grad_(True)
     yd = hb.MaxPool3x3s2Fn.apply(xd)
-    yd.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    yd.backward(nhwc(gy).to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
     assert torch.equal(nchw(yd.float()).cpu(), yr.detach())
     check_close("maxpool dx", nchw(xd.grad.float()), xr.grad, 1e-2, 4e-3)
@@ -464,7 +464,7 @@ def test_global_avg_pool():
     yr.backward(gy)
     xd = _to_dev_nhwc(x).requires_grad_(True)
     yd = hb.GlobalAvgPoolFn.apply(xd)
-    yd.backward(nhwc(gy).to(DEV).to(torch.bfloat16))
+    yd.backward(nhwc(gy).to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
     check_close("gap fwd", nchw(yd.float()), yr)
     check_close("gap dx", nchw(xd.grad.float()), xr.grad)
@@ -487,7 +487,7 @@ def test_bilinear(C, hi, wi, ho, wo, f32):
     xd = nhwc(x).to(DEV)
     gyd = nhwc(gy).to(DEV)
     if not f32:
-        xd, gyd = xd.to(torch.bfloat16), gyd.to(torch.bfloat16)
+        xd, gyd = xd.to(ACT_DTYPE), gyd.to(ACT_DTYPE)
     xd.requires_grad_(True)
     yd = hb.BilinearFn.apply(xd, ho, wo, f32)
     yd.backward(gyd)
@@ -517,9 +517,9 @@ def test_sum_act():
     y = torch.relu(tr[0] + tr[1] + tr[2])
     gy = _rand(2, 12, 10, 48, seed=9)
     y.backward(gy)
-    td = [t.to(DEV).to(torch.bfloat16).requires_grad_(True) for t in ts]
+    td = [t.to(DEV).to(ACT_DTYPE).requires_grad_(True) for t in ts]
     z = hb.SumActFn.apply(True, *td)
-    z.backward(gy.to(DEV).to(torch.bfloat16))
+    z.backward(gy.to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
     check_close("sum_act", z.float(), y)
     for i in range(3):
@@ -559,11 +559,11 @@ def test_ocr_attention():
     out = O.object_attention(qr, kr.permute(0, 2, 1), vr, D)
     g = _rand(B, H * W, D, seed=4)
     out.backward(g)
-    qd = q.view(B, H, W, D).to(DEV).to(torch.bfloat16).requires_grad_(True)
-    kd = k.to(DEV).to(torch.bfloat16).requires_grad_(True)
-    vd = v.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    qd = q.view(B, H, W, D).to(DEV).to(ACT_DTYPE).requires_grad_(True)
+    kd = k.to(DEV).to(ACT_DTYPE).requires_grad_(True)
+    vd = v.to(DEV).to(ACT_DTYPE).requires_grad_(True)
     od = hb.OcrAttnFn.apply(qd, kd, vd, D ** -0.5)
-    od.backward(g.view(B, H, W, D).to(DEV).to(torch.bfloat16))
+    od.backward(g.view(B, H, W, D).to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
     check_close("attn_fwd", od.float().view(B, H * W, D), out, 2e-2, 8e-3)
     check_close("attn_dq", qd.grad.float().view(B, H * W, D), qr.grad, 3e-2, 1.5e-2)

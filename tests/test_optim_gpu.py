@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import ACT_DTYPE
+
 pytestmark = pytest.mark.gpu
 
 # Run on an MI355X in round 1: the first parametrisation (profiles/r01_optim_gpu_test.log: parameters
@@ -68,7 +70,7 @@ def test_fused_sgd_step_refreshes_packed_filters():
     from semseg_amd.nn import Conv2d
     torch.manual_seed(0)
     conv = Conv2d(16, 16, kernel_size=3, padding=1, bias=False).cuda()
-    x = torch.randn(1, 8, 8, 16, device="cuda").to(torch.bfloat16)
+    x = torch.randn(1, 8, 8, 16, device="cuda").to(ACT_DTYPE)
     B = ops.HipBackend()
     B.begin_step(x.device)
     y0 = B.conv2d(x, conv.weight, None, 1, 1, 1).float()

@@ -4,8 +4,16 @@ import os
 import torch
 
 
+import os
+
+# storage format of the product's 16-bit activations in THIS process (semseg_amd/_lib.py: SSA_ACT_DTYPE): the tests
+# round their inputs / references to it, so the same test files run against the bf16 and the fp16 build
+ACT_DTYPE = torch.float16 if os.environ.get("SSA_ACT_DTYPE", "bf16").lower() in ("fp16", "f16", "float16", "half") else torch.bfloat16
+
+
 def bf16_round(t):
-    return t.to(torch.bfloat16).to(torch.float32)
+    """t rounded to the product's 16-bit storage format (bf16 by default; the name is round 1's)."""
+    return t.to(ACT_DTYPE).to(torch.float32)
 
 
 def report(name, got, ref):

@@ -5,9 +5,10 @@ set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 ROOT=$(cd "$HERE/../.." && pwd)
 SRC="$ROOT/semantic-segmentation_amd/csrc"
-OUT="$HERE/build"
+# sh tools/emu/build.sh f16 : the fp16-storage build (-DSSA_ELEM_F16) -> build_f16/libsemseg_emu.so
+if [ "$1" = "f16" ]; then OUT="$HERE/build_f16"; EXTRA="-DSSA_ELEM_F16"; else OUT="$HERE/build"; EXTRA=""; fi
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
-FLAGS="-x c++ -std=c++17 -O2 -g0 -fPIC -DSSA_EMU -I$HERE/include -Wno-unused-function -Wno-unused-value -Wno-unknown-pragmas -Wno-pass-failed"
+FLAGS="-x c++ -std=c++17 -O2 -g0 -fPIC -DSSA_EMU $EXTRA -I$HERE/include -Wno-unused-function -Wno-unused-value -Wno-unknown-pragmas -Wno-pass-failed"
 mkdir -p "$OUT"
 pids=""
 objs=""

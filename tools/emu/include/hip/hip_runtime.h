@@ -198,6 +198,29 @@ static inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return c;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+static inline f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+  const int lane = cur->lane;
+  unsigned char* mine = wave_buf(lane);
+  memcpy(mine, &a, 16);
+  memcpy(mine + 16, &b, 16);
+  sync_wave();
+  const int col = lane & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; ++k) {
+      _Float16 ha, hb;
+      memcpy(&ha, wave_buf(row + 32 * (k >> 3)) + 2 * (k & 7), 2);
+      memcpy(&hb, wave_buf(col + 32 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+      acc += (float)ha * (float)hb;
+    }
+    c[r] = acc;
+  }
+  sync_wave();
+  return c;
+}
+
 static inline s16x4 ds_read_tr16_b64(const void* p) {
   const int lane = cur->lane;
   memcpy(wave_buf(lane), p, 8);
