@@ -30,6 +30,13 @@ import torch.distributed as dist  # noqa: E402
 FLOP_FWD_BWD_PER_IMAGE = 5.7274e12
 PEAK_BF16_MFMA = 2.5e15          # dense, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12                # bytes/s, MI355X_MICROARCH.md
+def _lib_sha():
+    """Hash of the kernel sources the loaded library was built from (embedded by csrc/Makefile, checked against the
+    sources on disk by semseg_amd._lib.lib())."""
+    from semseg_amd import _lib
+    return _lib.built_sha()
+
+
 CONV_FAMILIES = ("ConvTile", "ConvHaloGemm", "ConvIgemm", "ConvWgradTile", "ConvWgradHead", "ConvWgradTr")
 
 
@@ -412,6 +419,7 @@ def main():
                        "eager_ms_per_step": eager_ms,
                        "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)",
                        "library_launches_per_step": launches_per_step,
+                       "lib_sha": _lib_sha(),
                        # deferred weight gradients: flushed every N layers onto a side stream (a parallel branch of
                        # the captured step); None = on the compute stream at the end of backward
                        "wgrad_side_stream_flush_at": hb._WGRAD_FLUSH_AT if hb._WGRAD_SIDE else None,

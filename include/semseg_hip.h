@@ -368,6 +368,14 @@ int ssa_bilinear_fwd(const void* x, int in_dtype, int B, int Hi, int Wi, int C,
 int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
                      int lddy, void* dx, int dx_dtype, int Hi, int Wi, int lddx,
                      void* stream);
+/* The same backward for an UPSAMPLING resize (Ho >= 2 Hi), separable (bilinear weights factor): pass X sums over the
+ * output columns into tmp ([B, Ho, Wi, C] fp32, dense, 16-byte aligned), pass Y over the output rows -- window_x +
+ * window_y taps per element instead of their product, dy read once.  Two dependent launches: never both in one
+ * ssa_group bracket.  network/mynn.py:42-114 (Upsample / scale_as), network/hrnetv2.py:246-249,440-445.          */
+int ssa_bilinear_bwd_x(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C, int lddy, float* tmp, int Wi,
+                       void* stream);
+int ssa_bilinear_bwd_y(const float* tmp, int B, int Ho, int Wi, int C, void* dx, int dx_dtype, int Hi, int lddx,
+                       void* stream);
 
 /* ----------------------------------------------------------------- pooling ----
  * DeepLabV3+/ResNet-50 (BASELINE configs[0]): nn.MaxPool2d(3, 2, 1) of the ResNet

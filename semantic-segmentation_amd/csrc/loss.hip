@@ -593,7 +593,15 @@ int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
   hipError_t e = hipMemsetAsync(gram, 0, sizeof(double) * NG * BC, s);
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)2 * (GROWS + 2) * gram_stride(Wp) * sizeof(double);
-  if (lds > 60000) return SSA_EUNSUPPORTED;
+  // wide crops (pooled width beyond ~620: crops wider than ~2,480 pixels at pool stride 4) need more than the default
+  // 64 KB of dynamic LDS for the fp64 tiles: raise the kernel's limit, up to the CU's 160 KB (pooled width ~1,700)
+  static size_t lds_set = 0;
+  if (lds > 160 * 1024) return SSA_EUNSUPPORTED;
+  if (lds > 60000 && lds > lds_set) {
+    e = hipFuncSetAttribute((const void*)rmi_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
   hipLaunchKernelGGL(rmi_gram_kernel, dim3((Hp - 2 + GROWS - 1) / GROWS, BC), dim3(NT), lds, s,
                      pooled_pr, pooled_la, Hp, Wp, gram);
   SSA_LAUNCH_CHECK();

@@ -186,6 +186,90 @@ __device__ __forceinline__ void bilinear_bwd_s_body(const InT* __restrict__ dy, 
   }
 }
 
+// ---- backward of an UPSAMPLING resize, separable: the gather above reads (window_y x window_x) output pixels per input
+// element -- 8 x 8 at scale 4, 16 x 16 at scale 8, every gradient element ~4 times over and poorly coalesced (0.85-0.9
+// TB/s measured on the 19-channel fp32 logits and on the trunk's 8x branch, profiles/r04_notes.md).  Bilinear weights
+// factor, w(oy, ox -> iy, ix) = wy(oy -> iy) * wx(ox -> ix), so
+//   pass X:  tmp[b, oy, ix, c] = sum_ox wx * dy[b, oy, ox, c]      (fp32, [B, Ho, Wi, C]; dy read ONCE, coalesced)
+//   pass Y:  dx[b, iy, ix, c]  = sum_oy wy * tmp[b, oy, ix, c]     (unit-stride reads along (ix, c))
+// -- window_x + window_y taps instead of their product.  Two dependent launches: the host issues the X passes of a
+// level in one bracket and the Y passes in the next.
+template <typename InT, int V>
+__device__ __forceinline__ void bilinear_bwd_x_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
+                                                    float* __restrict__ tmp, int Wi, float sw, const int bx, const int gx) {
+  const int VC = C / V;
+  const long n = (long)B * Ho * Wi * VC;
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
+    const int cg = (int)(i % VC);
+    long t = i / VC;
+    const int ix = (int)(t % Wi); t /= Wi;           // t = b * Ho + oy
+    int xlo, xhi;
+    cand_range(ix, sw, Wo, &xlo, &xhi);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const InT* row = dy + t * (long)Wo * lddy + cg * V;
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      const float wx = weight_for(ox, sw, Wi, ix);
+      if (wx == 0.f) continue;
+      if constexpr (V == 8) {
+        float g[8];
+        unpack8(*reinterpret_cast<const uint4*>(row + (long)ox * lddy), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wx * g[j];
+      } else {
+        acc[0] += wx * ld_as_f32(row + (long)ox * lddy);
+      }
+    }
+    float* o = tmp + (t * Wi + ix) * (long)C + cg * V;
+    if constexpr (V == 8) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      o[0] = acc[0];
+    }
+  }
+}
+
+template <typename OutT, int V>
+__device__ __forceinline__ void bilinear_bwd_y_body(const float* __restrict__ tmp, int B, int Ho, int Wi, int C,
+                                                    OutT* __restrict__ dx, int Hi, int lddx, float sh, const int bx,
+                                                    const int gx) {
+  const int VC = C / V;
+  const long n = (long)B * Hi * Wi * VC;
+  for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
+    const int cg = (int)(i % VC);
+    long t = i / VC;
+    const int ix = (int)(t % Wi); t /= Wi;
+    const int iy = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    int ylo, yhi;
+    cand_range(iy, sh, Ho, &ylo, &yhi);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    const float* col = tmp + ((long)b * Ho * Wi + ix) * C + cg * V;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = weight_for(oy, sh, Hi, iy);
+      if (wy == 0.f) continue;
+      const float* src = col + (long)oy * Wi * C;
+      if constexpr (V == 8) {
+        const float4 a = *reinterpret_cast<const float4*>(src), c4 = *reinterpret_cast<const float4*>(src + 4);
+        acc[0] += wy * a.x; acc[1] += wy * a.y; acc[2] += wy * a.z; acc[3] += wy * a.w;
+        acc[4] += wy * c4.x; acc[5] += wy * c4.y; acc[6] += wy * c4.z; acc[7] += wy * c4.w;
+      } else {
+        acc[0] += wy * src[0];
+      }
+    }
+    OutT* o = dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + cg * V;
+    if constexpr (V == 8) {
+      *reinterpret_cast<uint4*>(o) = pack8(acc);
+    } else {
+      st_from_f32(o, acc[0]);
+    }
+  }
+}
+
 // NCHW fp32 image -> (optionally resized) NHWC bf16, channels zero padded.
 // ResizeX(x, s) of network/mynn.py:101-114 fused with the layout change.
 __global__ void image_resize_kernel(const float* __restrict__ x, int B, int C, int Hi, int Wi,
@@ -264,6 +348,23 @@ int launch_bilinear(const void* src, int B, int Hs, int Ws, int C, int lds, void
   typename K::Args a{(const InT*)src, (OutT*)dst, B, Hs, Ws, C, lds, Hd, Wd, ldd, sh, sw};
   return ssa::submit<K>(a, grid_for(nthreads), 1, 0, s);
 }
+
+template <typename InT, int V>
+struct BilinearBwdXK {
+  struct Args { const InT* dy; float* tmp; int B, Ho, Wo, C, lddy, Wi; float sw; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    bilinear_bwd_x_body<InT, V>(a.dy, a.B, a.Ho, a.Wo, a.C, a.lddy, a.tmp, a.Wi, a.sw, bx, gx);
+  }
+};
+template <typename OutT, int V>
+struct BilinearBwdYK {
+  struct Args { const float* tmp; OutT* dx; int B, Ho, Wi, C, Hi, lddx; float sh; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    bilinear_bwd_y_body<OutT, V>(a.tmp, a.B, a.Ho, a.Wi, a.C, a.dx, a.Hi, a.lddx, a.sh, bx, gx);
+  }
+};
 
 // ---- few-channel tensors (class logits [.., 19], attention maps [.., 1]; fp32 on this path): one
 // thread per PIXEL.  The source indices / weights are computed once per pixel instead of once per
@@ -372,6 +473,55 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
     return launch_bilinear<float, bf16_t, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
   if (dy_dtype == 0 && dx_dtype == 0)
     return launch_bilinear<bf16_t, bf16_t, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
+  return SSA_EINVAL;
+}
+
+int ssa_bilinear_bwd_x(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C, int lddy, float* tmp, int Wi,
+                       void* stream) {
+  if (!dy || !tmp || B <= 0 || Ho <= 0 || Wo <= 0 || Wi <= 0 || C <= 0) return SSA_EINVAL;
+  if (reinterpret_cast<uintptr_t>(tmp) & 15u) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float sw = (float)Wi / (float)Wo;
+  const long n = (long)B * Ho * Wi * C;
+  if (dy_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15u) == 0) {
+    typedef BilinearBwdXK<bf16_t, 8> K;
+    K::Args a{(const bf16_t*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
+    return ssa::submit<K>(a, grid_for(n / 8), 1, 0, s);
+  }
+  if (dy_dtype == 0) {
+    typedef BilinearBwdXK<bf16_t, 1> K;
+    K::Args a{(const bf16_t*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
+    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+  }
+  if (dy_dtype == 1) {
+    typedef BilinearBwdXK<float, 1> K;
+    K::Args a{(const float*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
+    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+  }
+  return SSA_EINVAL;
+}
+
+int ssa_bilinear_bwd_y(const float* tmp, int B, int Ho, int Wi, int C, void* dx, int dx_dtype, int Hi, int lddx,
+                       void* stream) {
+  if (!tmp || !dx || B <= 0 || Ho <= 0 || Hi <= 0 || Wi <= 0 || C <= 0) return SSA_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float sh = (float)Hi / (float)Ho;
+  const long n = (long)B * Hi * Wi * C;
+  if (dx_dtype == 0 && C % 8 == 0 && lddx % 8 == 0 && ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0) {
+    typedef BilinearBwdYK<bf16_t, 8> K;
+    K::Args a{tmp, (bf16_t*)dx, B, Ho, Wi, C, Hi, lddx, sh};
+    return ssa::submit<K>(a, grid_for(n / 8), 1, 0, s);
+  }
+  if (dx_dtype == 0) {
+    typedef BilinearBwdYK<bf16_t, 1> K;
+    K::Args a{tmp, (bf16_t*)dx, B, Ho, Wi, C, Hi, lddx, sh};
+    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+  }
+  if (dx_dtype == 1) {
+    typedef BilinearBwdYK<float, 1> K;
+    K::Args a{tmp, (float*)dx, B, Ho, Wi, C, Hi, lddx, sh};
+    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+  }
   return SSA_EINVAL;
 }
 

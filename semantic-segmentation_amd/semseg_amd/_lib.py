@@ -125,6 +125,8 @@ _SIGS = {
                           c_int, _P], c_int),
     "ssa_bilinear_bwd": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int,
                           c_int, _P], c_int),
+    "ssa_bilinear_bwd_x": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P], c_int),
+    "ssa_bilinear_bwd_y": ([_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P], c_int),
     "ssa_maxpool3x3s2_fwd": ([_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P], c_int),
     "ssa_maxpool3x3s2_bwd": ([_P, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P], c_int),
     "ssa_global_avg_pool_fwd": ([_P, c_int, c_int, c_long, c_int, _P, _P], c_int),

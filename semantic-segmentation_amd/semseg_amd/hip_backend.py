@@ -38,7 +38,8 @@ ACT_DTYPE = torch.float16 if _ACT_NAME == "fp16" else torch.bfloat16
 def _no_fp16_training():
     """fp16 storage is the EVALUATION path this round: a 1024x1024 step's per-pixel loss gradients (~1e-6) underflow
     fp16 without the loss scaling apex O1 applies (amp.scale_loss, train.py:504), which the captured step does not
-    carry yet.  Raise rather than train on flushed gradients."""
+    carry yet.  The criteria of the operator surface (ops.HipBackend.cross_entropy / bce_rmi) raise rather than
+    train on flushed gradients; the kernels themselves are format-agnostic and tested in both formats."""
     if _ACT_NAME == "fp16":
         raise NotImplementedError("SSA_ACT_DTYPE=fp16 is the evaluation path; train with bf16 storage (the default)")
 
@@ -1478,6 +1479,27 @@ def _dt(t):
     raise TypeError(t.dtype)
 
 
+def _bilinear_bwd_group(jobs):
+    """Backward of N bilinear resizes.  job = (dy_ptr, dy_dtype_code, lddy, B, Hi, Wi, C, Ho, Wo, dx).  Upsampling
+    resizes (Ho >= 2 Hi and Wo >= 2 Wi) run the separable form -- all X passes of the level in one bracket, all Y
+    passes in the next (ssa_bilinear_bwd_x / _y) --, the others the one-pass gather."""
+    L = lib()
+    sep = [j for j in jobs if j[7] >= 2 * j[4] and j[8] >= 2 * j[5]]
+    rest = [j for j in jobs if not (j[7] >= 2 * j[4] and j[8] >= 2 * j[5])]
+    tmps = []
+    with group():
+        for dyp, dt, lddy, B, Hi, Wi, C, Ho, Wo, dx in sep:
+            tmp = torch.empty((B, Ho, Wi, C), dtype=torch.float32, device=dx.device)
+            tmps.append(tmp)
+            check(L.ssa_bilinear_bwd_x(dyp, dt, B, Ho, Wo, C, lddy, _p(tmp), Wi, _s()), "ssa_bilinear_bwd_x")
+        for dyp, dt, lddy, B, Hi, Wi, C, Ho, Wo, dx in rest:
+            check(L.ssa_bilinear_bwd(dyp, dt, B, Ho, Wo, C, lddy, _p(dx), _dt(dx), Hi, Wi, C, _s()), "ssa_bilinear_bwd")
+    if sep:
+        with group():
+            for (dyp, dt, lddy, B, Hi, Wi, C, Ho, Wo, dx), tmp in zip(sep, tmps):
+                check(L.ssa_bilinear_bwd_y(_p(tmp), B, Ho, Wi, C, _p(dx), _dt(dx), Hi, C, _s()), "ssa_bilinear_bwd_y")
+
+
 class BilinearGroupFn(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=False) of N tensors; spec[i] = (Ho, Wo, out_f32)."""
 
@@ -1508,16 +1530,16 @@ class BilinearGroupFn(torch.autograd.Function):
                 dy, lddy = dy.contiguous(), C
             prep.append((dy, lddy))
         dxs = [None]
-        with group():
-            for pr, (B, Hi, Wi, C, Ho, Wo, in_dtype) in zip(prep, ctx.meta):
-                if pr is None:
-                    dxs.append(None)
-                    continue
-                dy, lddy = pr
-                dx = torch.empty((B, Hi, Wi, C), dtype=in_dtype, device=dy.device)
-                check(lib().ssa_bilinear_bwd(_p(dy), _dt(dy), B, Ho, Wo, C, lddy, _p(dx), _dt(dx), Hi, Wi, C, _s()),
-                      "ssa_bilinear_bwd")
-                dxs.append(dx)
+        jobs = []
+        for pr, (B, Hi, Wi, C, Ho, Wo, in_dtype) in zip(prep, ctx.meta):
+            if pr is None:
+                dxs.append(None)
+                continue
+            dy, lddy = pr
+            dx = torch.empty((B, Hi, Wi, C), dtype=in_dtype, device=dy.device)
+            jobs.append((_p(dy), _dt(dy), lddy, B, Hi, Wi, C, Ho, Wo, dx))
+            dxs.append(dx)
+        _bilinear_bwd_group(jobs)
         return tuple(dxs)
 
 
@@ -1565,22 +1587,22 @@ class UpsampleCatGroupFn(torch.autograd.Function):
             if lddy % 8 or dy.data_ptr() % 16:
                 dy, lddy = dy.contiguous(), dy.shape[3]
             prep.append((dy, lddy))
-        with group():
-            for gi, n in enumerate(ctx.counts):
-                for j in range(n):
-                    B, Hi, Wi, C, Ho, Wo, off, Ct = ctx.meta[k + j]
-                    if prep[gi] is None:
-                        dxs.append(None)
-                        continue
-                    dy, lddy = prep[gi]
-                    if j == 0 and (Hi, Wi) == (Ho, Wo):
-                        dxs.append(dy[..., off:off + C])      # identity resize: the gradient is the slice itself
-                        continue
-                    dx = torch.empty((B, Hi, Wi, C), dtype=ACT_DTYPE, device=dy.device)
-                    check(lib().ssa_bilinear_bwd(ctypes.c_void_p(dy.data_ptr() + 2 * off), _dt(dy), B, Ho, Wo, C, lddy,
-                                                 _p(dx), _dt(dx), Hi, Wi, C, _s()), "ssa_bilinear_bwd")
-                    dxs.append(dx)
-                k += n
+        jobs = []
+        for gi, n in enumerate(ctx.counts):
+            for j in range(n):
+                B, Hi, Wi, C, Ho, Wo, off, Ct = ctx.meta[k + j]
+                if prep[gi] is None:
+                    dxs.append(None)
+                    continue
+                dy, lddy = prep[gi]
+                if j == 0 and (Hi, Wi) == (Ho, Wo):
+                    dxs.append(dy[..., off:off + C])      # identity resize: the gradient is the slice itself
+                    continue
+                dx = torch.empty((B, Hi, Wi, C), dtype=ACT_DTYPE, device=dy.device)
+                jobs.append((ctypes.c_void_p(dy.data_ptr() + 2 * off), _dt(dy), lddy, B, Hi, Wi, C, Ho, Wo, dx))
+                dxs.append(dx)
+            k += n
+        _bilinear_bwd_group(jobs)
         return tuple(dxs)
 
 
@@ -1893,7 +1915,6 @@ class CrossEntropyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
-        _no_fp16_training()
         dl, acc = ctx.saved_tensors
         up = up.float().contiguous()
         g = dl.clone()
@@ -1941,7 +1962,6 @@ class BceRmiFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, up):
-        _no_fp16_training()
         L = lib()
         up = up.float().contiguous()
         if not ctx.do_rmi:

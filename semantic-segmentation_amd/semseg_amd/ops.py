@@ -268,9 +268,13 @@ class HipBackend(BackendBase):
         return self.sum_act([x], relu=True)
 
     def cross_entropy(self, logits, labels, ignore_index):
+        if logits.requires_grad and torch.is_grad_enabled():
+            self.hb._no_fp16_training()
         return self.hb.CrossEntropyFn.apply(logits, labels, ignore_index)
 
     def bce_rmi(self, logits, labels, do_rmi, weight_lambda=0.5):
+        if logits.requires_grad and torch.is_grad_enabled():
+            self.hb._no_fp16_training()
         return self.hb.BceRmiFn.apply(logits, labels, bool(do_rmi), weight_lambda)
 
 

@@ -34,6 +34,12 @@ def storage(dtype):
         _STORAGE[0] = prev
 
 
+# channel counts of the tensors the HIP path keeps in fp32 (class logits, attention maps): every tensor here has dtype
+# fp32, so the emulation goes by channel count.  A test with another class count adds it (tests/teacher_backend.py
+# shares this set).
+F32_CHANNELS = {1, 19}
+
+
 class _Round(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -69,7 +75,7 @@ class Bf16EmuBackend(OracleBackend):
         y = super()._bilinear(x, size, out_f32)
         # class logits ([..,19]) and attention maps ([..,1]) are fp32 tensors on the
         # HIP path too (everything here has dtype fp32, so go by channel count)
-        return y if (out_f32 or x.shape[3] in (1, 19)) else R(y)
+        return y if (out_f32 or x.shape[3] in F32_CHANNELS) else R(y)
 
     def max_pool3x3s2(self, x):
         return R(super().max_pool3x3s2(x))

@@ -17,7 +17,7 @@ import torch
 
 from util import ACT_DTYPE
 
-from bf16_emu_backend import Bf16EmuBackend
+from bf16_emu_backend import Bf16EmuBackend, F32_CHANNELS       # (one set: the emulation rounds by it too)
 from semseg_amd.ops import BackendBase, _is_list, _lst
 
 BF16_TOL = (1e-2, 4e-3)        # one bf16 rounding of the output (tests/util.py)
@@ -88,7 +88,7 @@ class Record:
         return "\n".join(lines)
 
 
-F32_CHANNELS = {1, 19}          # class logits / attention maps are fp32 on the HIP path (add the class count of the model)
+# F32_CHANNELS: class logits / attention maps are fp32 on the HIP path (add the class count of the model)
 
 
 def _hip_dtype(t):

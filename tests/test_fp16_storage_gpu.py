@@ -53,8 +53,9 @@ def test_training_is_refused_on_the_fp16_build():
             "import torch\n"
             "from semseg_amd.loss import CrossEntropyLoss2d\n"
             "x = torch.randn(1, 19, 8, 8, device='cuda', requires_grad=True)\n"
-            "l = CrossEntropyLoss2d(ignore_index=255).cuda()(x, torch.zeros(1, 8, 8, dtype=torch.long, device='cuda'))\n"
-            "try:\n    l.backward()\nexcept (NotImplementedError, RuntimeError) as e:\n    print('REFUSED', type(e).__name__)\n"
+            "try:\n"
+            "    CrossEntropyLoss2d(ignore_index=255).cuda()(x, torch.zeros(1, 8, 8, dtype=torch.long, device='cuda')).backward()\n"
+            "except NotImplementedError as e:\n    print('REFUSED', type(e).__name__)\n"
             % (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SSA_ACT_DTYPE="fp16"),
                        capture_output=True, text=True, timeout=300)

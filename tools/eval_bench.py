@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""Secondary measurement (not the headline metric): inference throughput of the two eval
-configurations of BASELINE.json on one MI355X, synthetic Cityscapes-sized input, random
-weights, hipGraph replay:
+"""Secondary measurement (not the headline metric): inference throughput of the three eval
+configurations of BASELINE.json on one MI355X, synthetic input, random weights, hipGraph replay:
   configs[1]  HRNet-OCR single scale, 1024x2048                     (ocrnet.HRNet)
   configs[2]  HRNet-OCR-MScale hierarchical attention {0.5,1.0,2.0}  (ocrnet.HRNet_Mscale, N_SCALES)
-usage: python tools/eval_bench.py [iters]"""
+  configs[4]  Mapillary: 65 classes, {0.5,1.0,2.0} on a 1536x2048 image (the 2.0x pass is 3072x4096), one GPU --
+              BASELINE.json asks for fp16: run with SSA_ACT_DTYPE=fp16 (the row says which storage format ran)
+usage: python tools/eval_bench.py [iters] [mapillary H W]"""
 import json
 import os
 import sys
@@ -61,7 +62,9 @@ def run(name, arch, n_scales, H, W, iters, classes=19, use_graph=True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     pred = out_buf["pred"]
-    res = {"config": name, "arch": arch, "scales": n_scales or [1.0], "input": [H, W], "ms_per_image": dt * 1e3,
+    from semseg_amd import _lib
+    res = {"config": name, "arch": arch, "storage": _lib.ACT, "scales": n_scales or [1.0], "input": [H, W], "classes": classes,
+           "ms_per_image": dt * 1e3,
            "images_per_s": 1.0 / dt, "hipgraph": graph is not None, "pred_shape": list(pred.shape),
            "finite": bool(torch.isfinite(pred).all()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(res))
@@ -76,7 +79,9 @@ if __name__ == "__main__":
         # on ONE GPU (the reference needs amp O3 to fit); H W from argv
         H, W = int(sys.argv[3]), int(sys.argv[4])
         run("configs[4] Mapillary-sized {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], H, W, iters,
-            classes=65, use_graph=False)
+            classes=65)
         sys.exit(0)
     run("configs[1] HRNet-OCR single-scale eval", "ocrnet.HRNet", None, 1024, 2048, iters)
     run("configs[2] HRNet-OCR-MScale {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1024, 2048, iters)
+    run("configs[4] Mapillary 65 classes {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1536, 2048, iters,
+        classes=65)
