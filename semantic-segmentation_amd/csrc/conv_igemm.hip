@@ -517,10 +517,9 @@ struct WgradReduceK {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
       }
-      for (; sp < nsplit; ++sp) {
+      for (; sp < nsplit; ++sp) {      // (a run-time index into acc[] would put the array in scratch memory: call H)
         const float4 v = *reinterpret_cast<const float4*>(src + (long)sp * split_stride);
-        const int u = sp & 7;
-        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
       }
       float r[4];
       r[0] = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));

@@ -194,39 +194,69 @@ __device__ __forceinline__ void bilinear_bwd_s_body(const InT* __restrict__ dy, 
 //   pass Y:  dx[b, iy, ix, c]  = sum_oy wy * tmp[b, oy, ix, c]     (unit-stride reads along (ix, c))
 // -- window_x + window_y taps instead of their product.  Two dependent launches: the host issues the X passes of a
 // level in one bracket and the Y passes in the next.
+constexpr int kXRows = 8;         // output rows per thread of pass X: the column weights are computed once for all of them
+
 template <typename InT, int V>
 __device__ __forceinline__ void bilinear_bwd_x_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
                                                     float* __restrict__ tmp, int Wi, float sw, const int bx, const int gx) {
   const int VC = C / V;
-  const long n = (long)B * Ho * Wi * VC;
+  const long rows = (long)B * Ho;                       // (b, oy) flattened: dy rows are Wo * lddy apart
+  const long rblocks = (rows + kXRows - 1) / kXRows;
+  const long n = rblocks * Wi * VC;
   for (long i = bx * (long)blockDim.x + threadIdx.x; i < n; i += (long)gx * blockDim.x) {
     const int cg = (int)(i % VC);
     long t = i / VC;
-    const int ix = (int)(t % Wi); t /= Wi;           // t = b * Ho + oy
+    const int ix = (int)(t % Wi);
+    const long r0 = (t / Wi) * kXRows;
     int xlo, xhi;
     cand_range(ix, sw, Wo, &xlo, &xhi);
-    float acc[V];
+    // the candidates' weights once per thread (up to kMaxCand stay in registers; wider windows recompute per row)
+    float wxs[kMaxCand];
+    const int nx = xhi - xlo + 1;
+    const bool hoisted = nx <= kMaxCand;
 #pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    const InT* row = dy + t * (long)Wo * lddy + cg * V;
-    for (int ox = xlo; ox <= xhi; ++ox) {
-      const float wx = weight_for(ox, sw, Wi, ix);
-      if (wx == 0.f) continue;
-      if constexpr (V == 8) {
-        float g[8];
-        unpack8(*reinterpret_cast<const uint4*>(row + (long)ox * lddy), g);
+    for (int k = 0; k < kMaxCand; ++k) wxs[k] = (hoisted && k < nx) ? weight_for(xlo + k, sw, Wi, ix) : 0.f;
+    for (int rr = 0; rr < kXRows; ++rr) {
+      const long r = r0 + rr;
+      if (r >= rows) break;
+      float acc[V];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += wx * g[j];
+      for (int j = 0; j < V; ++j) acc[j] = 0.f;
+      const InT* row = dy + r * (long)Wo * lddy + cg * V;
+      if (hoisted) {
+#pragma unroll
+        for (int k = 0; k < kMaxCand; ++k) {
+          if (wxs[k] == 0.f) continue;
+          if constexpr (V == 8) {
+            float g[8];
+            unpack8(*reinterpret_cast<const uint4*>(row + (long)(xlo + k) * lddy), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wxs[k] * g[j];
+          } else {
+            acc[0] += wxs[k] * ld_as_f32(row + (long)(xlo + k) * lddy);
+          }
+        }
       } else {
-        acc[0] += wx * ld_as_f32(row + (long)ox * lddy);
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = weight_for(ox, sw, Wi, ix);
+          if (wx == 0.f) continue;
+          if constexpr (V == 8) {
+            float g[8];
+            unpack8(*reinterpret_cast<const uint4*>(row + (long)ox * lddy), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wx * g[j];
+          } else {
+            acc[0] += wx * ld_as_f32(row + (long)ox * lddy);
+          }
+        }
       }
-    }
-    float* o = tmp + (t * Wi + ix) * (long)C + cg * V;
-    if constexpr (V == 8) {
-      *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    } else {
-      o[0] = acc[0];
+      float* o = tmp + (r * Wi + ix) * (long)C + cg * V;
+      if constexpr (V == 8) {
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      } else {
+        o[0] = acc[0];
+      }
     }
   }
 }
@@ -486,17 +516,17 @@ int ssa_bilinear_bwd_x(const void* dy, int dy_dtype, int B, int Ho, int Wo, int 
   if (dy_dtype == 0 && C % 8 == 0 && lddy % 8 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15u) == 0) {
     typedef BilinearBwdXK<bf16_t, 8> K;
     K::Args a{(const bf16_t*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
-    return ssa::submit<K>(a, grid_for(n / 8), 1, 0, s);
+    return ssa::submit<K>(a, grid_for(n / 8 / kXRows + 1), 1, 0, s);
   }
   if (dy_dtype == 0) {
     typedef BilinearBwdXK<bf16_t, 1> K;
     K::Args a{(const bf16_t*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
-    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+    return ssa::submit<K>(a, grid_for(n / kXRows + 1), 1, 0, s);
   }
   if (dy_dtype == 1) {
     typedef BilinearBwdXK<float, 1> K;
     K::Args a{(const float*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
-    return ssa::submit<K>(a, grid_for(n), 1, 0, s);
+    return ssa::submit<K>(a, grid_for(n / kXRows + 1), 1, 0, s);
   }
   return SSA_EINVAL;
 }

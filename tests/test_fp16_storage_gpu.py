@@ -48,6 +48,13 @@ def test_eval_end_to_end_on_the_fp16_build():
 
 
 @pytest.mark.gpu
+def test_eval_teacher_forced_on_the_fp16_build():
+    """Teacher-forced evaluation, op by op at one-rounding tolerance, on the fp16 build: the hierarchical {0.5, 1, 2}
+    evaluation at 128 x 192 and BASELINE configs[1] (HRNet-OCR single scale, 1024 x 2048)."""
+    _run(["tests/test_parity_eval_gpu.py", "-k", "three_scales_small or single_scale_1024x2048"], "fp16_eval_parity.log", 900)
+
+
+@pytest.mark.gpu
 def test_training_is_refused_on_the_fp16_build():
     code = ("import os, sys; sys.path[:0] = [%r, %r]\n"
             "import torch\n"

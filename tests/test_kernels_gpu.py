@@ -102,6 +102,11 @@ CONV_CASES = [
     (1, 128, 128, 64, 64, 3, 2, 1, 1, False, False),
     (1, 2, 3, 48, 24, 3, 2, 1, 1, False, False),
     (1, 1, 9, 48, 48, 3, 2, 1, 1, False, False),
+    # the scale-attention head's last conv (network/utils.py:360: 256 -> 1, fp32 out) at the three pass sizes of a
+    # 128 x 192 {0.5, 1, 2} evaluation -- round 4's fp16 end-to-end test pointed at the smallest one
+    (1, 16, 24, 256, 1, 1, 1, 0, 1, False, True),
+    (1, 32, 48, 256, 1, 1, 1, 0, 1, False, True),
+    (1, 64, 96, 256, 1, 1, 1, 0, 1, False, True),
 ]
 
 

@@ -111,6 +111,12 @@ def test_device_oracle_equals_cpu_oracle():
     assert err <= 1e-4, err
 
 
+def test_eval_mscale_three_scales_small():
+    """The hierarchical evaluation at the end-to-end test's size (128 x 192: passes of 64 x 96, 128 x 192, 256 x 384 --
+    the trunk's smallest branch is 2 x 3 pixels): the narrow-image dispatch classes, teacher-forced."""
+    _teacher_eval("HRNet_Mscale", 19, [0.5, 1.0, 2.0], 128, 192)
+
+
 def test_eval_hrnet_ocr_single_scale_1024x2048():
     """BASELINE configs[1]."""
     _teacher_eval("HRNet", 19, None, 1024, 2048)
