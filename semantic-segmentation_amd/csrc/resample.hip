@@ -194,7 +194,8 @@ __device__ __forceinline__ void bilinear_bwd_s_body(const InT* __restrict__ dy, 
 //   pass Y:  dx[b, iy, ix, c]  = sum_oy wy * tmp[b, oy, ix, c]     (unit-stride reads along (ix, c))
 // -- window_x + window_y taps instead of their product.  Two dependent launches: the host issues the X passes of a
 // level in one bracket and the Y passes in the next.
-constexpr int kXRows = 8;         // output rows per thread of pass X: the column weights are computed once for all of them
+constexpr int kXRows = 1;         // output rows per thread of pass X (8, with the column weights computed once for all of them,
+                                  // measured slower: 34 -> 46 us per launch, too few threads in flight; profiles/r04_notes.md call I)
 
 template <typename InT, int V>
 __device__ __forceinline__ void bilinear_bwd_x_body(const InT* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,

@@ -1481,11 +1481,16 @@ def _dt(t):
 
 def _bilinear_bwd_group(jobs):
     """Backward of N bilinear resizes.  job = (dy_ptr, dy_dtype_code, lddy, B, Hi, Wi, C, Ho, Wo, dx).  Upsampling
-    resizes (Ho >= 2 Hi and Wo >= 2 Wi) run the separable form -- all X passes of the level in one bracket, all Y
-    passes in the next (ssa_bilinear_bwd_x / _y) --, the others the one-pass gather."""
+    resizes (Ho >= 2 Hi and Wo >= 2 Wi) of 16-bit tensors with C % 8 == 0 -- the trunk's branch upsamples, 2x / 4x /
+    8x -- run the separable form: all X passes of the level in one bracket, all Y passes in the next
+    (ssa_bilinear_bwd_x / _y; 607 -> 275 us per step).  The others take the one-pass gather: for the 19-channel fp32
+    logits the separable form measured SLOWER (scalar loads: 542 against 470 us per step, profiles/r04_notes.md)."""
     L = lib()
-    sep = [j for j in jobs if j[7] >= 2 * j[4] and j[8] >= 2 * j[5]]
-    rest = [j for j in jobs if not (j[7] >= 2 * j[4] and j[8] >= 2 * j[5])]
+
+    def separable(j):
+        return j[1] == 0 and j[6] % 8 == 0 and j[2] % 8 == 0 and j[7] >= 2 * j[4] and j[8] >= 2 * j[5]
+    sep = [j for j in jobs if separable(j)]
+    rest = [j for j in jobs if not separable(j)]
     tmps = []
     with group():
         for dyp, dt, lddy, B, Hi, Wi, C, Ho, Wo, dx in sep:
