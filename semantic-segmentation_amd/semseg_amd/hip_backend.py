@@ -737,6 +737,40 @@ def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, di
     return j
 
 
+_WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
+
+
+def _fit_tile_strips(jobs, strip):
+    """Strip length (128-pixel tiles per workgroup) of the halo-staged weight-gradient launches, per launch: a grouped
+    launch carries up to 16 layers of one instantiation (csrc/group.h) and its workgroups are persistent, so a launch
+    of 552 or 640 workgroups runs as a full round on the chip's 512 slots (two 64 KB workgroups per CU) plus a tail
+    round of the same length -- 96-105 us where 480 workgroups take 76 (profiles/r04_notes.md).  For every launch
+    pick the strip length in [strip, 2*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
+    out = {}
+    if not _WGRAD_FIT or strip <= 0:
+        return out
+    groups = {}
+    for j in jobs:
+        B, H, W, Cin = j.geom_in
+        if j.k != (3, 3) or j.stride != 1 or j.dil != 1 or j.pad != 1 or Cin != j.cout_pad or Cin not in (48, 64, 96, 192, 384):
+            continue
+        parts = {48: 1, 64: 1, 96: 3, 192: 12, 384: 48}[Cin]
+        tiles = B * ((W + 31) // 32) * ((H + 3) // 4)
+        groups.setdefault(min(Cin, 96), []).append((j, tiles, parts))
+    for lst in groups.values():
+        for i in range(0, len(lst), 16):
+            chunk = lst[i:i + 16]
+            best = None
+            for s_ in range(strip, 2 * strip + 1):
+                wgs = sum(-(-t // s_) * p for _, t, p in chunk)
+                cost = -(-wgs // 512) * (s_ + 2.0)
+                if best is None or cost < best[0] - 1e-9:
+                    best = (cost, s_)
+            for j, _, _ in chunk:
+                out[id(j)] = best[1]
+    return out
+
+
 def _run_wgrad_jobs(jobs, strip):
     """Plan every job, launch all weight-gradient kernels in one bracket, all reduces in a second."""
     if not jobs:
@@ -744,6 +778,10 @@ def _run_wgrad_jobs(jobs, strip):
     L = lib()
     dev = jobs[0].x.device
     by_target = {}
+    seq = {}
+    for j in jobs:                          # the order the kernels are submitted in below: by parameter, passes together
+        seq.setdefault(j.target.data_ptr(), []).append(j)
+    fitted = _fit_tile_strips([j for js in seq.values() for j in js], strip)
     for j in jobs:
         B, H, W, Cin = j.geom_in
         Ho, Wo = j.geom_out
@@ -754,7 +792,7 @@ def _run_wgrad_jobs(jobs, strip):
         if al and L.ssa_conv2d_wgrad_head_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
             j.kind = "head"
         else:
-            d.cfg = strip
+            d.cfg = fitted.get(id(j), strip)
             if _WGRAD_TILE and al and j.lddy % 8 == 0 and \
                     L.ssa_conv2d_wgrad_tile_plan(ctypes.byref(d), j.cout_pad, ctypes.byref(nsplit), ctypes.byref(ws)) == 0:
                 j.kind = "tile"

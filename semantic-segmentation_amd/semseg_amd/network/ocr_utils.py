@@ -91,14 +91,17 @@ class SpatialOCR_Module(nn.Module):
         keep = 1.0 - drop.p
         return (torch.rand(n, c, device=x.device) < keep).to(torch.float32) / keep
 
-    def forward(self, feats, proxy_feats):
-        """feats / proxy_feats: tensors, or lists of tensors (the scale passes)."""
+    def forward(self, feats, proxy_feats, feats_cat=None):
+        """feats / proxy_feats: tensors, or lists of tensors (the scale passes).  feats_cat: a second handle of
+        `feats` for the concatenation (ops.fan_out, see OCR_block.forward); default: feats itself."""
         B = ops.backend()
         context = self.object_context_block(feats, proxy_feats)
+        if feats_cat is None:
+            feats_cat = feats
         if isinstance(feats, (list, tuple)):
-            x = [B.cat([c, f]) for c, f in zip(context, feats)]
+            x = [B.cat([c, f]) for c, f in zip(context, feats_cat)]
             post = [self._mask(xi) for xi in x]
         else:
-            x = B.cat([context, feats])
+            x = B.cat([context, feats_cat])
             post = self._mask(x)
         return conv_bn(self.conv_bn_dropout[0], self.conv_bn_dropout[1][0], x, relu=True, post=post)
