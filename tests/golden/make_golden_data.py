@@ -5,6 +5,9 @@ maps).  Run in the build container: python tests/golden/make_golden_data.py"""
 import importlib.util
 import json
 import os
+import sys
+
+sys.dont_write_bytecode = True       # /root/reference is read-only input: leave no __pycache__ behind in it
 
 import numpy as np
 from PIL import Image
