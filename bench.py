@@ -355,21 +355,24 @@ def main():
         # collected offline (rocprofv3 cannot run inside this process) by tools/pmc_traffic.py; refused
         # unless it was measured on these very kernel sources
         traffic, traffic_src, mfma_busy, pmc_fam = None, None, None, {}
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc.json")
-        if os.path.exists(pmc):
+        # newest profiles/rNN_pmc.json first
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")), reverse=True):
+            rel = os.path.relpath(pmc, ROOT)
             with open(pmc) as f:
                 pj = json.load(f)
-            if pj.get("source_sha") == source_sha():
-                ent = pj["kernels"].get(name)
-                if ent:
-                    traffic, traffic_src = ent.get("hbm_bytes_per_launch"), "profiles/r03_pmc.json"
-                    mfma_busy = ent.get("mfma_busy_frac")
-                # MFMA-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles), fabric bytes, LDS conflicts per family
-                pmc_fam = {k: {"mfma_busy_frac": v.get("mfma_busy_frac"), "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
-                               "lds_conflict_frac": v.get("lds_conflict_frac"), "waves_per_simd": v.get("waves_per_simd")}
-                           for k, v in pj["kernels"].items() if k in CONV_FAMILIES}
-            else:
-                traffic_src = "profiles/r03_pmc.json refused: measured on other kernel sources"
+            if pj.get("source_sha") != source_sha():
+                traffic_src = traffic_src or "%s refused: measured on other kernel sources" % rel
+                continue
+            ent = pj["kernels"].get(name)
+            if ent:
+                traffic, traffic_src = ent.get("hbm_bytes_per_launch"), rel
+                mfma_busy = ent.get("mfma_busy_frac")
+            # MFMA-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles), fabric bytes, LDS conflicts per family
+            pmc_fam = {k: {"mfma_busy_frac": v.get("mfma_busy_frac"), "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
+                           "lds_conflict_frac": v.get("lds_conflict_frac"), "waves_per_simd": v.get("waves_per_simd")}
+                       for k, v in pj["kernels"].items() if k in CONV_FAMILIES}
+            break
         sec = d["us"] * 1e-6
         mfma_bound = d["flops"] / max(d["bytes"], 1.0) > PEAK_BF16_MFMA / PEAK_HBM
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name,
