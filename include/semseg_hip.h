@@ -148,6 +148,22 @@ int ssa_conv_tile_strip(int units);
 int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
                       double* stats, const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
 
+/* The 48-channel-block geometry of the same convs (csrc/conv_tile_q.hip; opt-in: the host glue uses it under
+ * SSA_TILE_Q=1): a wave computes (pb x 16 pixels) x 48 output channels with v_mfma_f32_16x16x32 (pb = 4 / 2 / 1 chosen
+ * per problem from the channel count, one kernel for all), K flattened over (tap, channel) of 48-channel chunks, the
+ * filter in two 21 KB stages per chunk through a ring of two LDS buffers, epilogue pieces completed with
+ * v_permlane16_swap; two workgroups per CU.  Cin in {48, 96, 192, 384}, Cout % 48 == 0, no bias.  w_frag:
+ * ssa_pack_filter mode 2 + 8 (forward) / 3 + 8 (data gradient): [Cout / 48][Cin / 48][14][3][64 lanes][8], see
+ * frag_offset in csrc/conv_igemm.hip.  stats / aux / aux_mode / coef as ssa_conv2d_tile_aux.
+ * ssa_conv_tile_q_strip(budget): MFMAs per wave (in units of 42) a workgroup of the calling thread's NEXT launches
+ * should carry, 0 = derive from each problem alone; ssa_conv_tile_q_wgs: the workgroups a problem launches at a budget
+ * (for the caller that sizes a grouped level).                                                                      */
+int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d);
+int ssa_conv_tile_q_strip(int budget);
+int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget);
+int ssa_conv2d_tile_q(const ssa_conv_desc* d, const void* x, const void* w_frag, void* y, double* stats,
+                      const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
+
 /* Halo-chunk implicit GEMM for the large-channel 3x3 / 1x1 stride-1 "same" convs
  * of the OCR and attention heads (Cin >= 192, Cin % 48 == 0 or % 64 == 0):
  * 256-pixel x 128-channel workgroup tiles, the input halo tile of each 48/64
@@ -218,7 +234,9 @@ typedef struct ssa_pack_job {
   const float* w_oihw;
   void* w_packed;
   long elem_begin;   /* unused by the kernel (reserved)                        */
-  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, pad_;
+  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows;
+  int layout;        /* mode 2 / 3: 0 = fragments of conv_tile(_p).hip / conv_halo_gemm.hip, 1 = of conv_tile_q.hip
+                        (ssa_pack_filter: mode + 8)                                 */
 } ssa_pack_job;
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job,
                              void* stream);
@@ -561,6 +579,10 @@ int ssa_axpy_f32(const float* x, float alpha, float* y, long n, int accumulate,
  * ds_read_b64_tr_b16 lane maps are verified on the device, not assumed).      */
 int ssa_probe_mfma32(const void* a, const void* b, float* c, void* stream);
 int ssa_probe_tr16(unsigned short* out, int mode, void* stream);
+/* c[16][16] = a[16][32] * b[32][16] (b given transposed: [16 n][32 k]) through v_mfma_f32_16x16x32; out[64][2] =
+ * (a, b) of every lane after v_permlane16_swap of a = lane, b = lane + 100.                                  */
+int ssa_probe_mfma16(const void* a, const void* bt, float* c, void* stream);
+int ssa_probe_swap16(unsigned* out, void* stream);
 
 #ifdef __cplusplus
 }

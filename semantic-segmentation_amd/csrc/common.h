@@ -33,6 +33,11 @@ __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t 
 #else
 __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) { return emu::mfma_32x32x16_bf16(a, b, c); }
 #endif
+#ifdef SSA_ELEM_F16
+__device__ __forceinline__ f32x4_t ssa_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return emu::mfma_16x16x32_f16(a, b, c); }
+#else
+__device__ __forceinline__ f32x4_t ssa_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return emu::mfma_16x16x32_bf16(a, b, c); }
+#endif
 __device__ __forceinline__ s16x4_t ssa_tr16_b64(const void* lds_ptr) { return emu::ds_read_tr16_b64(lds_ptr); }
 __device__ __forceinline__ void ssa_glds16(const void* gsrc, void* lds_dst) { emu::global_load_lds16(gsrc, lds_dst); }
 __device__ __forceinline__ void ssa_wave_sync() { emu::sync_wave(); }
@@ -49,6 +54,15 @@ __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t 
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 #else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// D = A(16x32) * B(32x16) + C on one wave; lane l holds row/column l & 15, k-group l >> 4 (8 consecutive k); D: column
+// l & 15, rows 4 * (l >> 4) + j  (conv_tile_q.hip; lane map pinned by ssa_probe_mfma16)
+__device__ __forceinline__ f32x4_t ssa_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+#ifdef SSA_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
 // ds_read_b64_tr_b16: 4x4 transposing LDS read (lane map: tests/test_kernels_gpu.py::test_probe_tr16)

@@ -1,0 +1,548 @@
+// 48-channel-block geometry of the persistent halo-tile convolution for the 3x3 stride-1 convs of the HRNetV2-W48
+// trunk (network/hrnetv2.py:31-66), forward and data gradient (gfx950 / MI355X).  OPT-IN this round
+// (SSA_TILE_Q=1): checked on the CPU emulation and by the op-level tests, not yet the default -- conv_tile_p.hip is.
+//
+// Why another geometry (profiles/r04_notes.md, "what bounds the trunk conv now"): conv_tile_p.hip computes a
+// 32-pixel x 32-channel block per wave with v_mfma_f32_32x32x16 -- 2 KB of LDS reads per MFMA, the CU's whole LDS
+// bandwidth at the MFMA rate, 32-channel n-blocks that waste a quarter of the work on 48 channels, and a chain of 8
+// dependent units for a 384-channel tile.  Every width of the W48 trunk (48 / 96 / 192 / 384) is a multiple of 48, so:
+//   * a wave computes (PB x 16 pixels) x 48 output channels with v_mfma_f32_16x16x32: PB pixel fragments + 3 filter
+//     fragments feed 3*PB MFMAs per k-step of 32 -- 0.58 KB of LDS reads per MFMA at PB = 4 (3.4x fewer bytes per
+//     FLOP), no n-block waste;
+//   * K runs flattened over (tap, channel) of a 48-channel chunk: 432 = 13.5 k-steps, padded to 14 with zero filter
+//     rows (the pixel operand of the padding re-reads the lane's previous k-group: finite data, times zero);
+//   * a workgroup = 4 waves = 16 x (4*PB) pixels x 48 channels; the four waves share the filter stage in LDS; a
+//     "unit" = one (tile, 48-channel chunk) = 14 k-steps = 42*PB MFMAs per wave, two filter stages of 21 KB through
+//     a ring of two LDS buffers behind counted barriers (three barriers per unit; conv_tile_p: four per 27 MFMAs);
+//     the 48-channel layers' whole filter slice (42 KB) IS the ring: loaded once per workgroup;
+//   * PB is chosen per PROBLEM at run time (one kernel, so a level's problems still share one grouped launch):
+//     4 for 48 / 96 channels, 2 for 192, 1 for 384 -- the chain of dependent units per tile stays at 2 x 168,
+//     4 x 84, 8 x 42 MFMAs instead of growing with the channel count;
+//   * the accumulator of a lane holds 4 consecutive channels of one pixel (filter as the A operand); the epilogue
+//     completes 16-byte pieces with v_permlane16_swap (channel blocks 0 / 1 against each other, block 2 of two pixel
+//     rows against each other) and stores from registers;
+//   * 78 KB of LDS, <= 256 registers: two workgroups per CU.
+// Epilogues as conv_tile_p.hip: BatchNorm batch statistics; aux_mode 1: + residual gradient; aux_mode 2: bn1's
+// backward sums from (x tile, dz).  Filter layout: ssa_pack_filter mode 2 / 3 with the flag 8 ("Q fragments").
+#include "common.h"
+#include "group.h"
+#include <stdlib.h>
+#include "../../include/semseg_hip.h"
+
+namespace {
+
+constexpr int kStatReplicas = 8;   // as conv_tile.hip (ssa_bn_stat_replicas)
+
+struct TileQArgs {
+  const bf16_t* x; const uint4* wfrag; bf16_t* y; double* stats;
+  const bf16_t* aux; const float* coef;                    // epilogue tile; [4][Cout] table of aux_mode 2
+  int ldx, Cin, ldy, H, W, Cout, nt_total, tiles_x, tiles_y, ldaux;
+  int total_tiles, tiles_per_wg, nwg, pb;
+};
+
+// Bijective XCD-aware order (block b runs on XCD b % 8): XCD x gets one contiguous range of work items.
+__device__ __forceinline__ int xcd_order_q(int v, int n) {
+  const int q = n >> 3, r = n & 7, x = v & 7, k = v >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ void lds_barrier_q() {
+#ifdef SSA_EMU
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// 16-lane rows r = lane >> 4: rows 2i and 2i + 1 exchange: afterwards (a, b) of an even row = (own a, partner's a), of
+// an odd row = (partner's b, own b)   [v_permlane16_swap: odd rows of the first operand <-> even rows of the second;
+// pinned on the device by ssa_probe_swap16]
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+#ifdef SSA_EMU
+  const unsigned pa = __shfl_xor(a, 16, 64), pb = __shfl_xor(b, 16, 64);
+  if (((threadIdx.x >> 4) & 1) == 0) b = pa; else a = pb;
+#else
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+#endif
+}
+
+// sum over the 16 lanes of this lane's row; valid in every lane afterwards
+__device__ __forceinline__ float row_sum16(float v) {
+#ifdef SSA_EMU
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#else
+#define SSA_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  SSA_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+  SSA_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+  SSA_DPP_ADD(0x141);     // row_half_mirror
+  SSA_DPP_ADD(0x140);     // row_mirror
+#undef SSA_DPP_ADD
+  return v;
+#endif
+}
+
+template <int PB, int AUXM>
+struct ConvTileQBody {
+  static constexpr bool AUX = AUXM != 0;
+  static constexpr int NT = 256;
+  static constexpr int CK = 48;                      // input channels per unit = output channels per workgroup
+  static constexpr int TW = 16, TH = 4 * PB;         // wave w computes rows w*PB .. w*PB + PB - 1 of the tile
+  static constexpr int HW_ = TW + 2, HH_ = TH + 2, NPIX = HH_ * HW_;
+  static constexpr int PSB = CK * 2 + 16;            // halo pixel stride (bytes): 7 slots of 16 bytes, conflict-free fragment reads
+  static constexpr int CP = CK / 8;                  // 16-byte pieces per halo pixel
+  static constexpr int NA = (NT / CP) * CP;          // staging threads: thread t always moves channel group t % CP
+  static constexpr int RP = NA / CP;                 // halo pixels per staging pass
+  static constexpr int IT = (NPIX + RP - 1) / RP;    // halo loads per thread and unit
+  static constexpr int KS = 14;                      // k-steps of 32 per unit: 9 taps x 48 channels = 432, padded to 448
+  static constexpr int KREAL = 9 * CK;
+  static constexpr int SKS = 7;                      // k-steps per filter stage
+  static constexpr int NFRAG = SKS * 3;              // 1 KiB filter fragments per stage (3 channel blocks of 16 per k-step)
+  static constexpr int ND = (NFRAG + 3) / 4;         // DMAs per wave and stage (the last ones duplicated: every wave issues ND)
+  static constexpr int STAGE_BYTES = NFRAG * 1024;
+  static constexpr int UNIT_BYTES = 2 * STAGE_BYTES; // filter bytes per (48-channel n-tile, chunk)
+  static constexpr int HALO_RAW = NPIX * PSB;
+  static constexpr int HALO_BYTES = (HALO_RAW + 2 * CK * 4 + 1023) / 1024 * 1024;   // + the coefficient table of aux_mode 2
+  static constexpr int NPA = PB;                     // 16-byte epilogue pieces per lane from channel blocks 0 / 1
+  static constexpr int NPB = PB >= 2 ? PB / 2 : 1;   // ... from channel block 2
+  static constexpr int NPC = NPA + NPB;
+  static constexpr size_t LDS = (size_t)HALO_BYTES + 2 * (size_t)STAGE_BYTES;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(4 * 2 * CK * 4 <= HALO_RAW, "statistics reduction does not fit");
+  static_assert(IT <= 8, "halo pieces per thread");
+
+  static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND],
+                                                      unsigned char* dst, int wave) {
+#pragma unroll
+    for (int f = 0; f < ND; ++f) {
+      const int fi = min(f * 4 + wave, NFRAG - 1);      // wave-uniform; the last fragments are issued twice
+      ssa_glds16_untracked_sv(sbase, voff[f], dst + (size_t)fi * 1024);
+    }
+  }
+
+  static __device__ __forceinline__ void run(const TileQArgs& a, const int bx) {
+    const bf16_t* __restrict__ x = a.x;
+    bf16_t* __restrict__ y = a.y;
+    double* __restrict__ stats = a.stats;
+    const bf16_t* __restrict__ aux = a.aux;
+    const float* __restrict__ coef = a.coef;
+    const int ldx = a.ldx, Cin = a.Cin, ldy = a.ldy, H = a.H, W = a.W, Cout = a.Cout;
+    const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, ldaux = a.ldaux;
+    SSA_DYN_LDS(unsigned char, smem);
+    unsigned char* Bs = smem + HALO_BYTES;
+    float* ctab = reinterpret_cast<float*>(smem + HALO_RAW);      // aux_mode 2: [2][48] mask scale / shift
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_ = xcd_order_q(bx, a.nwg);
+    const int strip = w_ / a.nt_total, nt = w_ - strip * a.nt_total;
+    const int cbase = nt * CK;                                     // first output channel of this workgroup
+    const int t_begin = strip * a.tiles_per_wg;
+    const int t_end = min(a.total_tiles, t_begin + a.tiles_per_wg);
+    const int nchunk = Cin / CK;
+    const int n_iter = (t_end - t_begin) * nchunk;
+    if (n_iter <= 0) return;
+    const bool resident = nchunk == 1;                             // the ring holds the whole filter slice
+
+    // ---- staging role of this thread: channel group cg of halo pixels prow, prow + RP, ...
+    const bool stg = tid < NA;
+    const int cg = tid % CP, prow = tid / CP;
+    uint4 v[IT];
+    unsigned okmask = 0;                       // bit i: piece i lies inside the image
+    int hyx[IT], rel[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int pix = prow + i * RP;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      const bool have = stg && pix < NPIX;
+      hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
+      rel[i] = (hy * W + hx) * ldx;
+    }
+    const int rel_c = (W + 1) * ldx;                               // halo pixel (1, 1) = output pixel (0, 0) of the tile
+    int f_b, f_ty, f_tx;
+    {
+      f_tx = t_begin % tiles_x;
+      const int r = t_begin / tiles_x;
+      f_ty = r % tiles_y;
+      f_b = r / tiles_y;
+    }
+    int c_b = f_b, c_ty = f_ty, c_tx = f_tx;
+    auto fetch = [&](int cc) {
+      const int x0 = f_tx * TW, y0 = f_ty * TH;
+      const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + cc * CK + cg * 8;
+      okmask = 0;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
+        const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
+        okmask |= (ok ? 1u : 0u) << i;
+      }
+    };
+    auto advance = [&](int* b, int* ty, int* tx) {
+      if (++*tx == tiles_x) {
+        *tx = 0;
+        if (++*ty == tiles_y) { *ty = 0; ++*b; }
+      }
+    };
+    auto stage = [&]() {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int pix = prow + i * RP;
+        const uint4 o = ((okmask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
+        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = o;
+      }
+    };
+
+    // ---- MFMA / epilogue role of this lane: pixel column px of the tile, k-group / channel group g
+    const int px = lane & 15, g = lane >> 4;
+    const int chA = (g & 1) * 16 + (g >> 1) * 8;      // channels (within the 48) of this lane's pieces of blocks 0 / 1
+    const int chB = 32 + (g >> 1) * 8;                //                                          ... of block 2
+    const bool b_lane = PB >= 2 || (g & 1) == 0;      // PB = 1: the odd rows hold copies of the even rows' block-2 pieces
+    float SA[AUXM == 1 ? 1 : 8], QA[AUXM == 1 ? 1 : 8], SB[AUXM == 1 ? 1 : 8], QB[AUXM == 1 ? 1 : 8];
+#pragma unroll
+    for (int j = 0; j < (AUXM == 1 ? 1 : 8); ++j) { SA[j] = QA[j] = SB[j] = QB[j] = 0.f; }
+    if constexpr (AUXM == 2) {
+      for (int i = tid; i < 2 * CK; i += NT) {
+        const int k = i / CK, c = i - k * CK;
+        ctab[i] = coef[k * Cout + cbase + c];
+      }
+    }
+    uint4 auxv[AUX ? NPC : 1];
+
+    // pixel fragment of k-step ks: 8 channels of (tap, channel) = flattened k-group ks*32 + 8*g of the halo pixel
+    // (row + kh, px + kw); the padding groups (k >= 432) re-read the lane's k-group 16 below (their filter rows are zero)
+    int offk[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      int kk = ks * 32 + g * 8;
+      if (kk >= KREAL) kk -= 16;
+      const int tap = kk / CK, c = kk - tap * CK;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      offk[ks] = (kh * HW_ + kw) * PSB + c * 2;
+    }
+    const int b_off = (wave * PB * HW_ + px) * PSB;
+
+    f32x4_t acc[3][PB];
+
+    unsigned voff[ND];
+#pragma unroll
+    for (int f = 0; f < ND; ++f) voff[f] = (unsigned)((min(f * 4 + wave, NFRAG - 1) * 64 + lane) * 16);
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(a.wfrag) + (long)nt * nchunk * UNIT_BYTES;
+    auto stage_base = [&](int cc_, int st_) { return wbytes + (long)(cc_ * 2 + st_) * STAGE_BYTES; };
+
+    // ---- prologue: filter stage 0 on its way into LDS, first halo into registers
+    stage_filter(stage_base(0, 0), voff, Bs, wave);
+    fetch(0);
+    int s = 0;                                         // global filter-stage counter: stage s lives in buffer s & 1
+    int cc = 0;
+    for (int it = 0; it < n_iter; ++it) {
+      // everyone is past the barrier that ended the previous unit's MFMAs: the halo image is free
+      stage();
+      if (it == 0) ssa_wait_vm_barrier<0, 0>();        // halo image visible + filter stage 0 landed
+      else lds_barrier_q();                            // halo image visible
+      const bool last_chunk = cc + 1 == nchunk;
+      int ccn = cc + 1;
+      if (last_chunk) { ccn = 0; if (it + 1 < n_iter) advance(&f_b, &f_ty, &f_tx); }
+      const int x0 = c_tx * TW, y0 = c_ty * TH + wave * PB;
+      const int ox = x0 + px;
+      const long img = (long)c_b * H * W;
+      // element offset of this lane's piece p (p < NPA: pixel row p, channels chA; else rows 2j / 2j + 1, channels chB)
+      auto piece_row = [&](int p) { return p < NPA ? y0 + p : y0 + (PB >= 2 ? 2 * (p - NPA) + (g & 1) : 0); };
+      auto piece_ok = [&](int p) { return piece_row(p) < H && ox < W && (p < NPA || b_lane); };
+      auto piece_pix = [&](int p) { return img + (long)min(piece_row(p), H - 1) * W + min(ox, W - 1); };
+      if (cc == 0) {
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][pb][r] = 0.f;
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        // stage s + 1 of the continuous filter stream into the buffer stage s - 1 left (past the end of the strip: a
+        // stage nobody reads); a resident slice is complete after the first two stages
+        if (!resident || s == 0) {
+          const int cc1 = st == 0 ? cc : ccn;
+          stage_filter(stage_base(cc1, st ^ 1), voff, Bs + ((s + 1) & 1) * STAGE_BYTES, wave);
+        }
+        if (st == 0) {
+          // next unit's halo (the last unit re-reads its own: the count of loads in flight stays fixed) and this
+          // tile's epilogue operand: in flight during the MFMAs, behind the DMAs
+          fetch(ccn);
+          if constexpr (AUX) {
+            if (last_chunk) {
+#pragma unroll
+              for (int p = 0; p < NPC; ++p)
+                auxv[p] = *reinterpret_cast<const uint4*>(aux + piece_pix(p) * ldaux + cbase + (p < NPA ? chA : chB));
+            }
+          }
+        }
+        const unsigned char* Ac = Bs + (s & 1) * STAGE_BYTES + lane * 16;
+        const unsigned char* Bc = smem + b_off;
+        bf16x8_t fa[2][3], fb[2][PB];
+        auto rd_frag = [&](int ksl) {
+          const unsigned char* bp = Bc + offk[st * SKS + ksl];
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb)
+            fb[ksl & 1][pb] = *reinterpret_cast<const bf16x8_t*>(bp + pb * HW_ * PSB);
+#pragma unroll
+          for (int mb = 0; mb < 3; ++mb)
+            fa[ksl & 1][mb] = *reinterpret_cast<const bf16x8_t*>(Ac + (ksl * 3 + mb) * 1024);
+        };
+        rd_frag(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 + PB, 0);
+#pragma unroll
+        for (int ksl = 0; ksl < SKS; ++ksl) {
+          if (ksl + 1 < SKS) rd_frag(ksl + 1);
+#pragma unroll
+          for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+              acc[mb][pb] = ssa_mfma16(fa[ksl & 1][mb], fb[ksl & 1][pb], acc[mb][pb]);     // D[channel][pixel]
+          if (ksl + 1 < SKS) {
+            // the next k-step's fragment reads spread between this k-step's MFMAs
+#pragma unroll
+            for (int r = 0; r < 3 + PB; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, (3 * PB) / (3 + PB) > 0 ? (3 * PB) / (3 + PB) : 1, 0);
+            }
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 3 * PB, 0);
+        }
+        // stage s + 1 landed (it was issued before this stage's loads); buffer s & 1 and, after the second stage,
+        // the halo image are free
+        if (st == 0) {
+          if (AUX && last_chunk) ssa_wait_vm_barrier<IT + NPC, 0>();
+          else ssa_wait_vm_barrier<IT, 0>();
+        } else {
+          ssa_wait_vm_barrier<0, 0>();
+        }
+        ++s;
+      }
+      if (last_chunk) {
+        // ---- epilogue in registers: 4 channels per (block, pixel row) -> 16-byte pieces by row exchange -> HBM
+        unsigned w[3][PB][2];
+#pragma unroll
+        for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+            w[mb][pb][0] = f2bf_pair(acc[mb][pb][0], acc[mb][pb][1]);
+            w[mb][pb][1] = f2bf_pair(acc[mb][pb][2], acc[mb][pb][3]);
+          }
+        // one 16-byte piece: fused epilogue, statistics (S / Q = this lane's sums of the piece's 8 channels), store
+        auto finish = [&](uint4 o, const int p, const int ch, float (&S)[AUXM == 1 ? 1 : 8], float (&Q)[AUXM == 1 ? 1 : 8]) {
+          const bool ok = piece_ok(p);
+          if constexpr (AUXM == 1) {
+            float f[8], xv[8];
+            unpack8(o, f);
+            unpack8(auxv[p], xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += xv[j];
+            o = pack8(f);
+          } else if constexpr (AUXM == 2) {
+            float f[8], xv[8];
+            unpack8(o, f);
+            unpack8(auxv[p], xv);
+            const float4 ma0 = *reinterpret_cast<const float4*>(ctab + ch);
+            const float4 ma1 = *reinterpret_cast<const float4*>(ctab + ch + 4);
+            const float4 mb0 = *reinterpret_cast<const float4*>(ctab + CK + ch);
+            const float4 mb1 = *reinterpret_cast<const float4*>(ctab + CK + ch + 4);
+            const float ma[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
+            const float mb[8] = {mb0.x, mb0.y, mb0.z, mb0.w, mb1.x, mb1.y, mb1.z, mb1.w};
+            if (ok) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float gm = (xv[j] * ma[j] + mb[j]) > 0.f ? f[j] : 0.f;
+                S[j] += gm;
+                Q[j] += gm * xv[j];
+              }
+            }
+          } else {
+            if (stats != nullptr && ok) {
+              float f[8];
+              unpack8(o, f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { S[j] += f[j]; Q[j] += f[j] * f[j]; }
+            }
+          }
+          if (ok) *reinterpret_cast<uint4*>(y + piece_pix(p) * ldy + cbase + ch) = o;
+        };
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+          // blocks 0 and 1 of pixel row p: even rows end up with 8 channels of block 0, odd rows of block 1
+          unsigned a0 = w[0][p][0], a1 = w[0][p][1], b0 = w[1][p][0], b1 = w[1][p][1];
+          swap16(a0, b0);
+          swap16(a1, b1);
+          finish(make_uint4(a0, a1, b0, b1), p, chA, SA, QA);
+        }
+#pragma unroll
+        for (int p2 = 0; p2 < NPB; ++p2) {
+          // block 2 of pixel rows 2j (-> even lane rows) and 2j + 1 (-> odd lane rows); PB = 1: the row against itself
+          const int r0 = PB >= 2 ? 2 * p2 : 0, r1 = PB >= 2 ? r0 + 1 : 0;
+          unsigned a0 = w[2][r0][0], a1 = w[2][r0][1], b0 = w[2][r1][0], b1 = w[2][r1][1];
+          swap16(a0, b0);
+          swap16(a1, b1);
+          finish(make_uint4(a0, a1, b0, b1), NPA + p2, chB, SB, QB);
+        }
+        advance(&c_b, &c_ty, &c_tx);
+      }
+      cc = ccn;
+    }
+
+    // ---- statistics of the strip: 16 pixel lanes -> (block 2: the two lane rows of a channel group) -> wave ->
+    // workgroup -> one fp64 atomic per channel
+    if constexpr (AUXM == 1) {
+      return;          // residual add: no statistics (stats is NULL by contract)
+    } else {
+      if (stats == nullptr) return;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        SA[j] = row_sum16(SA[j]);
+        QA[j] = row_sum16(QA[j]);
+        SB[j] = row_sum16(SB[j]);
+        QB[j] = row_sum16(QB[j]);
+        SB[j] += __shfl_xor(SB[j], 16, 64);
+        QB[j] += __shfl_xor(QB[j], 16, 64);
+      }
+      __syncthreads();                                 // every wave is done with the halo image
+      float* red = reinterpret_cast<float*>(smem);     // [4 waves][2][48]
+      if (px == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red[(wave * 2 + 0) * CK + chA + j] = SA[j];
+          red[(wave * 2 + 1) * CK + chA + j] = QA[j];
+          if ((g & 1) == 0) {
+            red[(wave * 2 + 0) * CK + chB + j] = SB[j];
+            red[(wave * 2 + 1) * CK + chB + j] = QB[j];
+          }
+        }
+      }
+      __syncthreads();
+      double* st = stats + (long)(strip % kStatReplicas) * 2 * Cout;
+      if (tid < CK) {
+        const int n = cbase + tid;
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          sv += red[(w2 * 2 + 0) * CK + tid];
+          qv += red[(w2 * 2 + 1) * CK + tid];
+        }
+        double sd = (double)sv, qd = (double)qv;
+        // aux_mode 2 accumulated sum(m*dz*x); the consumer wants sum(m*dz*xhat), xhat = (x - mean) * invstd
+        if constexpr (AUXM == 2) qd = (double)coef[3 * Cout + n] * (qd - (double)coef[2 * Cout + n] * sd);
+        atomicAdd(&st[n], sd);
+        atomicAdd(&st[Cout + n], qd);
+      }
+    }
+  }
+};
+
+// One kernel for the three wave shapes: a level's problems (48 ... 384 channels) share one grouped launch.
+template <int AUXM>
+struct ConvTileQK {
+  typedef TileQArgs Args;
+  static constexpr int NT = 256;
+  static constexpr int WPE = 2;                  // two workgroups per CU: <= 256 registers
+  static constexpr size_t LDS = ConvTileQBody<4, AUXM>::LDS;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
+    if (a.pb == 4) ConvTileQBody<4, AUXM>::run(a, bx);
+    else if (a.pb == 2) ConvTileQBody<2, AUXM>::run(a, bx);
+    else ConvTileQBody<1, AUXM>::run(a, bx);
+  }
+};
+
+static thread_local int g_q_budget = 0;        // MFMA budget (units of 42 per wave) per workgroup, 0 = per problem
+
+int choose_pb(const ssa_conv_desc& d) {
+  static const int forced = getenv("SSA_TILE_Q_PB") ? atoi(getenv("SSA_TILE_Q_PB")) : 0;
+  const int nchunk = d.Cin / 48;
+  int pb = nchunk <= 2 ? 4 : (nchunk == 4 ? 2 : 1);
+  if (forced == 1 || forced == 2 || forced == 4) pb = forced;
+  while (pb > 1 && 2 * pb >= d.H) pb >>= 1;     // half the rows still cover the image
+  return pb;
+}
+
+void plan_q(const ssa_conv_desc& d, int budget, TileQArgs* a) {
+  const int nchunk = d.Cin / 48;
+  a->pb = choose_pb(d);
+  a->nt_total = d.Cout / 48;
+  a->tiles_x = (d.W + 15) / 16;
+  a->tiles_y = (d.H + 4 * a->pb - 1) / (4 * a->pb);
+  a->total_tiles = d.B * a->tiles_x * a->tiles_y;
+  if (budget <= 0) {
+    // a launch of its own: ~2 workgroups per CU from this problem alone
+    const long total = (long)a->total_tiles * a->nt_total * nchunk * a->pb;
+    budget = (int)((total + 511) / 512);
+  }
+  int tpw = budget / (nchunk * a->pb);
+  if (tpw < 1) tpw = 1;
+  if (tpw > 64) tpw = 64;
+  const int nstrips = (a->total_tiles + tpw - 1) / tpw;
+  a->tiles_per_wg = (a->total_tiles + nstrips - 1) / nstrips;
+  a->nwg = ((a->total_tiles + a->tiles_per_wg - 1) / a->tiles_per_wg) * a->nt_total;
+}
+
+template <int AUXM>
+int launch_q(const ssa_conv_desc& d, const TileQArgs& a0, hipStream_t s) {
+  TileQArgs a = a0;
+  plan_q(d, g_q_budget, &a);
+  return ssa::submit<ConvTileQK<AUXM>>(a, a.nwg, 1, ConvTileQK<AUXM>::LDS, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d) {
+  if (!ssa_conv2d_tile_supported(d)) return 0;
+  if (d->W < 16) return 0;                    // 16-pixel-wide tiles; narrower images stay on conv_tile.hip
+  if (d->Cout % 48) return 0;
+  return d->Cin == 48 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
+}
+
+int ssa_conv_tile_q_strip(int budget) {
+  g_q_budget = budget < 0 ? 0 : budget;
+  return SSA_OK;
+}
+
+int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget) {
+  if (!d || !ssa_conv2d_tile_q_supported(d)) return 0;
+  TileQArgs a;
+  plan_q(*d, budget, &a);
+  return a.nwg;
+}
+
+int ssa_conv2d_tile_q(const ssa_conv_desc* dp, const void* x, const void* w_frag, void* y, double* stats,
+                      const void* aux, int ldaux, const float* coef, int aux_mode, void* stream) {
+  if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
+  if (!ssa_conv2d_tile_q_supported(dp)) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
+    return SSA_EINVAL;
+  if (aux_mode < 0 || aux_mode > 2) return SSA_EINVAL;
+  if (aux_mode && (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u))) return SSA_EINVAL;
+  if (aux_mode == 2 && (!coef || !stats)) return SSA_EINVAL;
+  if (aux_mode == 1 && stats) return SSA_EINVAL;
+  if (dp->ldy % 8) return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  TileQArgs a;
+  a.x = (const bf16_t*)x; a.wfrag = (const uint4*)w_frag;
+  a.y = (bf16_t*)y; a.stats = stats; a.aux = (const bf16_t*)aux; a.coef = coef;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
+  a.ldaux = ldaux;
+  a.nt_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.nwg = a.pb = 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (aux_mode) {
+    case 0: return launch_q<0>(d, a, s);
+    case 1: return launch_q<1>(d, a, s);
+    default: return launch_q<2>(d, a, s);
+  }
+}
+
+}  // extern "C"

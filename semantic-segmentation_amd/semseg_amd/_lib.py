@@ -43,7 +43,7 @@ def source_sha():
 class PackJob(ctypes.Structure):
     """Mirror of ssa_pack_job (64 bytes)."""
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("elem_begin", c_long)] + [(n, c_int) for n in (
-        "Cout", "Cin", "KH", "KW", "cin_pad", "cout_pad", "Kpad", "mode", "rows", "pad_")]
+        "Cout", "Cin", "KH", "KW", "cin_pad", "cout_pad", "Kpad", "mode", "rows", "layout")]
 
 
 class BnUpdateJob(ctypes.Structure):
@@ -88,6 +88,10 @@ _SIGS = {
     "ssa_conv2d_tile_p_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv_tile_strip": ([c_int], c_int),
     "ssa_conv2d_tile_p": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
+    "ssa_conv2d_tile_q_supported": ([POINTER(ConvDesc)], c_int),
+    "ssa_conv_tile_q_strip": ([c_int], c_int),
+    "ssa_conv_tile_q_wgs": ([POINTER(ConvDesc), c_int], c_int),
+    "ssa_conv2d_tile_q": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
     "ssa_conv2d_halo_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
@@ -166,6 +170,8 @@ _SIGS = {
     "ssa_ewise_bwd_f32": ([c_int, _P, _P, _P, _P, _P, c_long, _P], c_int),
     "ssa_axpy_f32": ([_P, c_float, _P, c_long, c_int, _P], c_int),
     "ssa_probe_mfma32": ([_P, _P, _P, _P], c_int),
+    "ssa_probe_mfma16": ([_P, _P, _P, _P], c_int),
+    "ssa_probe_swap16": ([_P, _P], c_int),
     "ssa_probe_tr16": ([_P, c_int, _P], c_int),
 }
 

@@ -172,8 +172,8 @@ def invalidate_packed_filters():
         e.version = -1
 
 
-def _make_job(w, out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows):
-    return PackJob(w.data_ptr(), out.data_ptr(), 0, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, 0)
+def _make_job(w, out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout=0):
+    return PackJob(w.data_ptr(), out.data_ptr(), 0, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout)
 
 
 def refresh_packed_filters():
@@ -215,6 +215,10 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
+    layout = 1 if mode in (10, 11) else 0       # fragment order of csrc/conv_tile_q.hip (ssa_pack_filter mode 2 / 3 + 8)
+    api_mode = mode
+    if layout:
+        mode -= 8
     if mode >= 4:               # parity class (py, px) of a stride-2 data gradient: (1+py)*(1+px) taps
         rows, kdim = Cin, (1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) * cout_pad
     elif mode & 1 == 0:
@@ -223,6 +227,10 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
         rows, kdim = Cin, KH * KW * cout_pad
     if mode < 2 or mode >= 4:
         Kpad = _roundup(kdim, 32)
+    elif layout:                # 48-row n-tiles, 14 k-steps of 32 per 48-channel chunk (9 * 48 = 432 real)
+        cpad = cout_pad if mode & 1 else cin_pad
+        assert (KH, KW) == (3, 3) and cpad % 48 == 0, (KH, KW, cpad)
+        rows, Kpad = _roundup(rows, 48), cpad // 48 * 448
     else:                       # MFMA-fragment order (conv_tile.hip): rows padded to 32, K exact
         rows, Kpad = _roundup(rows, 32), kdim
     w = weight.detach()
@@ -235,11 +243,11 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
         e.out = torch.zeros((rows, Kpad), dtype=ACT_DTYPE, device=weight.device)    # the tiled repack keeps the padding
         e.Kpad = Kpad
         e.wref = weakref.ref(weight)
-        e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows)
+        e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout)
         if direct:              # only parameters packed straight from their own storage are batched
             _PACKED[key] = e
             _JOB_TABLE.update(key=None)      # a new destination buffer: the device table is stale
-    check(lib().ssa_pack_filter(_p(w), _p(e.out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, _s()),
+    check(lib().ssa_pack_filter(_p(w), _p(e.out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, api_mode, _s()),
           "ssa_pack_filter")
     e.version = weight._version
     return e.out, e.Kpad
@@ -525,7 +533,7 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     return y
 
 
-def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0):
+def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0, q=False):
     """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs; aux = fused epilogue tile of
     the data gradient, see ssa_conv2d_tile_aux) or conv_halo_gemm.hip (large-channel 3x3 / 1x1)."""
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
@@ -534,7 +542,10 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
     _note(2.0 * P * d.Cout * d.Cin * d.KH * d.KW,
           _conv_bytes(P, d.Cin, P, d.Cout, (d.KH, d.KW), 4 if d.out_f32 else 2) + (2.0 * P * d.Cout if mode else 0.0))
     L = lib()
-    if not halo and bias is None and tile_p_supported(d):
+    if q:
+        check(L.ssa_conv2d_tile_q(ctypes.byref(d), _p(x), _p(wfrag), _p(y), _p(stats), _p(aux), ldaux, _p(coef), mode,
+                                  _s()), "ssa_conv2d_tile_q")
+    elif not halo and bias is None and tile_p_supported(d):
         check(L.ssa_conv2d_tile_p(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats),
                                   _p(aux), ldaux, _p(coef), mode, _s()), "ssa_conv2d_tile_p")
     elif mode:
@@ -549,6 +560,15 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
 
 def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
     return _tile_conv(d, x, wfrag, None, stats, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
+
+
+# ---- 48-channel-block geometry of the trunk conv (csrc/conv_tile_q.hip): opt-in until it has been measured
+_TILE_Q = os.environ.get("SSA_TILE_Q", "0") == "1"
+_TILE_Q_WGS = int(os.environ.get("SSA_TILE_Q_WGS", "512"))      # most workgroups a grouped level may launch (2 per CU)
+
+
+def tile_q_supported(d):
+    return _TILE_Q and bool(lib().ssa_conv2d_tile_q_supported(ctypes.byref(d)))
 
 
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs
@@ -577,6 +597,21 @@ def tile_strip(descs):
     not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (three per CU;
     a level of more workgroups than slots runs as two rounds: profiles/r03_notes.md call D, r04_notes.md call C).
     Handed to the library for the launches issued inside the bracket (same thread)."""
+    dq = [d for d in descs if tile_q_supported(d)]
+    if dq:
+        # the same for the opt-in geometry: the smallest MFMA budget per workgroup whose workgroups fit two per CU
+        L = lib()
+        budget = 256
+        for b in range(4, 260, 4):
+            if sum(L.ssa_conv_tile_q_wgs(ctypes.byref(d), b) for d in dq) <= _TILE_Q_WGS:
+                budget = b
+                break
+        L.ssa_conv_tile_q_strip(budget)
+        try:
+            yield
+        finally:
+            L.ssa_conv_tile_q_strip(0)
+        return
     ds = [d for d in descs if tile_p_supported(d)]
     if not ds:
         yield
@@ -617,7 +652,10 @@ def _conv_fwd(x, ldx, weight, b, stride, pad, dil, out_f32, want_stats):
     stats = None
     if want_stats and not out_f32 and not (_NO_IGEMM_STATS and not (use_tile or use_halo)):
         stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-    if use_tile or use_halo:
+    if use_tile and b is None and tile_q_supported(td):
+        wp, _ = _packed_filter(weight, 10, Cin, 0)
+        y = _tile_conv(td, x, wp, None, stats, q=True)
+    elif use_tile or use_halo:
         wp, _ = _packed_filter(weight, 2, Cin, 0)
         y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
     else:
@@ -650,6 +688,9 @@ def _conv_dgrad(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw, 
     use_halo = (not use_tile) and al and halo_supported(td)
     if mode:
         assert use_tile
+    if use_tile and tile_q_supported(td):
+        wpt, _ = _packed_filter(weight, 11, 0, cout_pad)
+        return _tile_conv(td, dyb, wpt, None, stats, aux=aux, ldaux=ldaux, coef=coef, mode=mode, q=True)
     if use_tile or use_halo:
         wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
         return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode)

@@ -221,6 +221,35 @@ static inline f32x16 mfma_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
   return c;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// MFMA 16x16x32: A lane l holds row l&15, k = 8*(l>>4)+j; B likewise by column; D column l&15, rows 4*(l>>4)+r
+// (pinned on the device by ssa_probe_mfma16)
+template <class LD>
+static inline f32x4 mfma_16x16x32_impl(const void* a, const void* b, f32x4 c, LD ld) {
+  const int lane = cur->lane;
+  unsigned char* mine = wave_buf(lane);
+  memcpy(mine, a, 16);
+  memcpy(mine + 16, b, 16);
+  sync_wave();
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k)
+      acc += ld(wave_buf(row + 16 * (k >> 3)) + 2 * (k & 7)) * ld(wave_buf(col + 16 * (k >> 3)) + 16 + 2 * (k & 7));
+    c[r] = acc;
+  }
+  sync_wave();
+  return c;
+}
+static inline f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return mfma_16x16x32_impl(&a, &b, c, [](const unsigned char* p) {
+    unsigned short u; memcpy(&u, p, 2); const unsigned i = (unsigned)u << 16; float f; memcpy(&f, &i, 4); return f; });
+}
+static inline f32x4 mfma_16x16x32_f16(f16x8 a, f16x8 b, f32x4 c) {
+  return mfma_16x16x32_impl(&a, &b, c, [](const unsigned char* p) { _Float16 h; memcpy(&h, p, 2); return (float)h; });
+}
+
 static inline s16x4 ds_read_tr16_b64(const void* p) {
   const int lane = cur->lane;
   memcpy(wave_buf(lane), p, 8);
