@@ -157,10 +157,10 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag,
  * frag_offset in csrc/conv_igemm.hip.  stats / aux / aux_mode / coef as ssa_conv2d_tile_aux.
  * ssa_conv_tile_q_strip(budget): MFMAs per wave (in units of 42) a workgroup of the calling thread's NEXT launches
  * should carry, 0 = derive from each problem alone; ssa_conv_tile_q_wgs: the workgroups a problem launches at a budget
- * (for the caller that sizes a grouped level).                                                                      */
+ * and aux_mode (aux_mode 2 runs at pb <= 2) -- for the caller that sizes a grouped level.                                                                      */
 int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d);
 int ssa_conv_tile_q_strip(int budget);
-int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget);
+int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget, int aux_mode);
 int ssa_conv2d_tile_q(const ssa_conv_desc* d, const void* x, const void* w_frag, void* y, double* stats,
                       const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
 

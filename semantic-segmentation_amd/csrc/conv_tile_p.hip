@@ -214,13 +214,17 @@ struct ConvTileP {
         if (++*ty == tiles_y) { *ty = 0; ++*b; }
       }
     };
-    // registers -> LDS halo image (pixels outside the image are zero)
+    // registers -> LDS halo image (pixels outside the image are zero).  Branch-free: a thread without an i-th piece
+    // writes into the unused 16-byte pad behind a halo pixel's 96 bytes -- with the stores (and the vmcnt waits in
+    // front of them) under per-piece branches the compiler loses track of which loads have landed and drains the
+    // vector-memory queue (vmcnt(0): the filter DMAs just issued included) before it re-uses one of their registers
+    const int pad_slot = (tid % NPIX) * PSB + CK * 2;
     auto stage = [&]() {
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int pix = prow + i * RP;
         const uint4 o = ((okmask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
-        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = o;
+        *reinterpret_cast<uint4*>(smem + (hyx[i] != 0xffff ? pix * PSB + cg * 16 : pad_slot)) = o;
       }
     };
 
@@ -311,6 +315,9 @@ struct ConvTileP {
               }
             }
           }
+          // the loads are ISSUED here, ahead of the MFMAs (left alone the compiler sinks them below the k-loop to re-use
+          // their registers for fragments)
+          asm volatile("" ::: "memory");
         }
         const unsigned char* Bc = Bs + (s % 3) * STAGE_BYTES + lane * 16;
         // fragments of k-step ksl + RD - 1 are read while the MFMAs of k-step ksl run: a ring of RD register sets

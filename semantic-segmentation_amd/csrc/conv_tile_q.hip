@@ -154,14 +154,13 @@ struct ConvTileQBody {
     const int cg = tid % CP, prow = tid / CP;
     uint4 v[IT];
     unsigned okmask = 0;                       // bit i: piece i lies inside the image
-    int hyx[IT], rel[IT];
+    int hyx[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int pix = prow + i * RP;
       const int hy = pix / HW_, hx = pix - hy * HW_;
       const bool have = stg && pix < NPIX;
       hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
-      rel[i] = (hy * W + hx) * ldx;
     }
     const int rel_c = (W + 1) * ldx;                               // halo pixel (1, 1) = output pixel (0, 0) of the tile
     int f_b, f_ty, f_tx;
@@ -180,7 +179,7 @@ struct ConvTileQBody {
       for (int i = 0; i < IT; ++i) {
         const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
         const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
+        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? ((hyx[i] >> 8) * W + (hyx[i] & 255)) * ldx : rel_c));
         okmask |= (ok ? 1u : 0u) << i;
       }
     };
@@ -190,12 +189,17 @@ struct ConvTileQBody {
         if (++*ty == tiles_y) { *ty = 0; ++*b; }
       }
     };
+    // registers -> LDS halo image (pixels outside the image are zero).  Branch-free: a thread without an i-th piece
+    // writes into the unused 16-byte pad behind a halo pixel's 96 bytes -- with the stores (and the vmcnt waits in
+    // front of them) under per-piece branches the compiler loses track of which loads have landed and drains the
+    // vector-memory queue (vmcnt(0): the filter DMAs just issued included) before it re-uses a register
+    const int pad_slot = (tid % NPIX) * PSB + CK * 2;
     auto stage = [&]() {
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         const int pix = prow + i * RP;
         const uint4 o = ((okmask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
-        if (hyx[i] != 0xffff) *reinterpret_cast<uint4*>(smem + pix * PSB + cg * 16) = o;
+        *reinterpret_cast<uint4*>(smem + (hyx[i] != 0xffff ? pix * PSB + cg * 16 : pad_slot)) = o;
       }
     };
 
@@ -216,16 +220,18 @@ struct ConvTileQBody {
     uint4 auxv[AUX ? NPC : 1];
 
     // pixel fragment of k-step ks: 8 channels of (tap, channel) = flattened k-group ks*32 + 8*g of the halo pixel
-    // (row + kh, px + kw); the padding groups (k >= 432) re-read the lane's k-group 16 below (their filter rows are zero)
-    int offk[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      int kk = ks * 32 + g * 8;
-      if (kk >= KREAL) kk -= 16;
-      const int tap = kk / CK, c = kk - tap * CK;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      offk[ks] = (kh * HW_ + kw) * PSB + c * 2;
-    }
+    // (row + kh, px + kw); the padding groups (k >= 432) re-read the lane's k-group 16 below (their filter rows are
+    // zero).  ks is a compile-time constant at every call: two constants and a select per k-step instead of a
+    // register per k-step
+    const int g8 = g * 8;
+    auto offk = [&](const int ks) {
+      const int kk0 = ks * 32, tap0 = kk0 / CK, c0 = kk0 - tap0 * CK;
+      const int conA = ((tap0 / 3) * HW_ + tap0 % 3) * PSB + c0 * 2;
+      if (kk0 + 24 >= KREAL) return conA + (g8 >= KREAL - kk0 ? g8 - 16 : g8) * 2;      // the padded last k-step
+      const int tap1 = tap0 + 1;
+      const int conB = ((tap1 / 3) * HW_ + tap1 % 3) * PSB + (c0 - CK) * 2;
+      return (g8 >= CK - c0 ? conB : conA) + g8 * 2;
+    };
     const int b_off = (wave * PB * HW_ + px) * PSB;
 
     f32x4_t acc[3][PB];
@@ -283,38 +289,78 @@ struct ConvTileQBody {
                 auxv[p] = *reinterpret_cast<const uint4*>(aux + piece_pix(p) * ldaux + cbase + (p < NPA ? chA : chB));
             }
           }
+          // the loads are ISSUED here, ahead of the MFMAs (left alone the compiler sinks them below the k-loop to re-use
+          // their registers for fragments, and then waits vmcnt(0) -- i.e. for the DMAs just issued -- before the loop)
+          asm volatile("" ::: "memory");
         }
         const unsigned char* Ac = Bs + (s & 1) * STAGE_BYTES + lane * 16;
         const unsigned char* Bc = smem + b_off;
-        bf16x8_t fa[2][3], fb[2][PB];
-        auto rd_frag = [&](int ksl) {
-          const unsigned char* bp = Bc + offk[st * SKS + ksl];
-#pragma unroll
-          for (int pb = 0; pb < PB; ++pb)
-            fb[ksl & 1][pb] = *reinterpret_cast<const bf16x8_t*>(bp + pb * HW_ * PSB);
+        // filter fragments double-buffered over k-steps.  Pixel fragments: PB = 4 re-loads a fragment for the next
+        // k-step right after its last MFMA of this one (9 MFMAs = 144 clocks ahead of its next use; 16 registers
+        // instead of 32 -- the AUX = 2 body would not fit otherwise); PB <= 2 double-buffers them too (3-6 MFMAs
+        // would not cover the LDS latency)
+        constexpr int NFB = PB == 4 ? 1 : 2;
+        bf16x8_t fa[2][3], fb[NFB][PB];
+        auto rd_a = [&](int ksl) {
 #pragma unroll
           for (int mb = 0; mb < 3; ++mb)
             fa[ksl & 1][mb] = *reinterpret_cast<const bf16x8_t*>(Ac + (ksl * 3 + mb) * 1024);
         };
-        rd_frag(0);
+        auto rd_b = [&](int ksl, int pb) {
+          fb[ksl % NFB][pb] = *reinterpret_cast<const bf16x8_t*>(Bc + offk(st * SKS + ksl) + pb * HW_ * PSB);
+        };
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) rd_b(0, pb);
+        rd_a(0);
         __builtin_amdgcn_sched_group_barrier(0x100, 3 + PB, 0);
 #pragma unroll
         for (int ksl = 0; ksl < SKS; ++ksl) {
-          if (ksl + 1 < SKS) rd_frag(ksl + 1);
-#pragma unroll
-          for (int mb = 0; mb < 3; ++mb)
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb)
-              acc[mb][pb] = ssa_mfma16(fa[ksl & 1][mb], fb[ksl & 1][pb], acc[mb][pb]);     // D[channel][pixel]
           if (ksl + 1 < SKS) {
-            // the next k-step's fragment reads spread between this k-step's MFMAs
+            rd_a(ksl + 1);
+            if constexpr (NFB == 2) {
 #pragma unroll
-            for (int r = 0; r < 3 + PB; ++r) {
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, (3 * PB) / (3 + PB) > 0 ? (3 * PB) / (3 + PB) : 1, 0);
+              for (int pb = 0; pb < PB; ++pb) rd_b(ksl + 1, pb);
             }
           }
-          __builtin_amdgcn_sched_group_barrier(0x008, 3 * PB, 0);
+#pragma unroll
+          for (int pb = 0; pb < PB; ++pb) {
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+              acc[mb][pb] = ssa_mfma16(fa[ksl & 1][mb], fb[ksl % NFB][pb], acc[mb][pb]);     // D[channel][pixel]
+            if constexpr (NFB == 1) {
+              if (ksl + 1 < SKS) rd_b(ksl + 1, pb);
+            }
+          }
+          // issue order of the k-step: the next k-step's 3 + PB fragment reads spread between this one's 3*PB MFMAs
+          // (left alone the compiler shortens the fragments' live ranges by reading each one right in front of its
+          // first MFMA, i.e. it exposes the LDS latency every three MFMAs)
+          if (ksl + 1 < SKS) {
+            if constexpr (PB == 4) {
+#pragma unroll
+              for (int r = 0; r < 3; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            } else if constexpr (PB == 2) {
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 3; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * PB, 0);
+          }
         }
         // stage s + 1 landed (it was issued before this stage's loads); buffer s & 1 and, after the second stage,
         // the halo image are free
@@ -452,26 +498,31 @@ struct ConvTileQK {
   static constexpr int WPE = 2;                  // two workgroups per CU: <= 256 registers
   static constexpr size_t LDS = ConvTileQBody<4, AUXM>::LDS;
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
-    if (a.pb == 4) ConvTileQBody<4, AUXM>::run(a, bx);
-    else if (a.pb == 2) ConvTileQBody<2, AUXM>::run(a, bx);
+    // (aux_mode 2 carries 56 more registers -- the x tile and two more sets of sums -- and does not fit 256 at
+    // pb = 4: its problems run at pb <= 2, see choose_pb)
+    if constexpr (AUXM != 2) {
+      if (a.pb == 4) { ConvTileQBody<4, AUXM>::run(a, bx); return; }
+    }
+    if (a.pb == 2) ConvTileQBody<2, AUXM>::run(a, bx);
     else ConvTileQBody<1, AUXM>::run(a, bx);
   }
 };
 
 static thread_local int g_q_budget = 0;        // MFMA budget (units of 42 per wave) per workgroup, 0 = per problem
 
-int choose_pb(const ssa_conv_desc& d) {
+int choose_pb(const ssa_conv_desc& d, int aux_mode) {
   static const int forced = getenv("SSA_TILE_Q_PB") ? atoi(getenv("SSA_TILE_Q_PB")) : 0;
   const int nchunk = d.Cin / 48;
   int pb = nchunk <= 2 ? 4 : (nchunk == 4 ? 2 : 1);
   if (forced == 1 || forced == 2 || forced == 4) pb = forced;
+  if (aux_mode == 2 && pb > 2) pb = 2;
   while (pb > 1 && 2 * pb >= d.H) pb >>= 1;     // half the rows still cover the image
   return pb;
 }
 
-void plan_q(const ssa_conv_desc& d, int budget, TileQArgs* a) {
+void plan_q(const ssa_conv_desc& d, int budget, int aux_mode, TileQArgs* a) {
   const int nchunk = d.Cin / 48;
-  a->pb = choose_pb(d);
+  a->pb = choose_pb(d, aux_mode);
   a->nt_total = d.Cout / 48;
   a->tiles_x = (d.W + 15) / 16;
   a->tiles_y = (d.H + 4 * a->pb - 1) / (4 * a->pb);
@@ -492,7 +543,7 @@ void plan_q(const ssa_conv_desc& d, int budget, TileQArgs* a) {
 template <int AUXM>
 int launch_q(const ssa_conv_desc& d, const TileQArgs& a0, hipStream_t s) {
   TileQArgs a = a0;
-  plan_q(d, g_q_budget, &a);
+  plan_q(d, g_q_budget, AUXM, &a);
   return ssa::submit<ConvTileQK<AUXM>>(a, a.nwg, 1, ConvTileQK<AUXM>::LDS, s);
 }
 
@@ -512,10 +563,10 @@ int ssa_conv_tile_q_strip(int budget) {
   return SSA_OK;
 }
 
-int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget) {
+int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget, int aux_mode) {
   if (!d || !ssa_conv2d_tile_q_supported(d)) return 0;
   TileQArgs a;
-  plan_q(*d, budget, &a);
+  plan_q(*d, budget, aux_mode, &a);
   return a.nwg;
 }
 

@@ -219,14 +219,14 @@ def test_q_strips_of_several_tiles_and_forced_wave_shapes():
     for budget in (0, 8, 24, 64):
         L.ssa_conv_tile_q_strip(budget)
         try:
-            n = L.ssa_conv_tile_q_wgs(ctypes.byref(d), budget)
+            n = L.ssa_conv_tile_q_wgs(ctypes.byref(d), budget, 0)
             y, _ = hb._conv_fwd(xd, C, wd, None, 1, 1, 1, False, False)
         finally:
             L.ssa_conv_tile_q_strip(0)
         _sync()
         ys.append(y)
         print("budget %d: %d workgroups" % (budget, n))
-    assert L.ssa_conv_tile_q_wgs(ctypes.byref(d), 64) < L.ssa_conv_tile_q_wgs(ctypes.byref(d), 8)
+    assert L.ssa_conv_tile_q_wgs(ctypes.byref(d), 64, 0) < L.ssa_conv_tile_q_wgs(ctypes.byref(d), 8, 0)
     for y in ys[1:]:
         assert torch.equal(y, ys[0])
     check_close("q strips", nchw(ys[0].float()), _oracle_conv(x, w))

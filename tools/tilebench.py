@@ -183,7 +183,7 @@ def main_q():
         L.ssa_conv_tile_q_strip(0)
         print("%3d @ %3dx%-3d   %8.1f | %s | %.2e   (%.0f TF/s at best; %d workgroups auto)" % (
             p.C, p.H, p.W, t_p, " ".join("%7.1f" % t for t in row), err, p.flops / min(row) / 1e6,
-            L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), 0)))
+            L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), 0, 0)))
     fl = sum(p.flops for p in probs)
     by = sum(p.bytes for p in probs)
 
@@ -205,7 +205,7 @@ def main_q():
         t = timeit(level_q, reps)
         best = min(best, (t, b))
         print("   q, budget %2d (%4d workgroups): %.1f us = %.0f TF/s, %.0f GB/s" % (
-            b, sum(L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), b) for p in probs), t, fl / t / 1e6, by / t / 1e3))
+            b, sum(L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), b, 0) for p in probs), t, fl / t / 1e6, by / t / 1e3))
     L.ssa_conv_tile_q_strip(best[1])
     for aux in (2, 1):
         print("   q budget %d, aux %d: %.1f us   (p: %.1f us)" % (best[1], aux, timeit(lambda: level_q(aux=aux), reps),
