@@ -15,9 +15,9 @@
 //     "unit" = one (tile, 48-channel chunk) = 14 k-steps = 42*PB MFMAs per wave, two filter stages of 21 KB through
 //     a ring of two LDS buffers behind counted barriers (three barriers per unit; conv_tile_p: four per 27 MFMAs);
 //     the 48-channel layers' whole filter slice (42 KB) IS the ring: loaded once per workgroup;
-//   * PB is chosen per PROBLEM at run time (one kernel, so a level's problems still share one grouped launch):
-//     4 for 48 / 96 channels, 2 for 192, 1 for 384 -- the chain of dependent units per tile stays at 2 x 168,
-//     4 x 84, 8 x 42 MFMAs instead of growing with the channel count;
+//   * PB is chosen per PROBLEM at run time (one kernel, so a level's problems still share one grouped launch): 2 up to
+//     192 channels, 1 for 384 (choose_pb: measured; 4 through SSA_TILE_Q_PB) -- the chain of dependent units per tile
+//     stays at 1-4 x 84 and 8 x 42 MFMAs instead of growing with the channel count;
 //   * the accumulator of a lane holds 4 consecutive channels of one pixel (filter as the A operand); the epilogue
 //     completes 16-byte pieces with v_permlane16_swap (channel blocks 0 / 1 against each other, block 2 of two pixel
 //     rows against each other) and stores from registers;
@@ -32,6 +32,14 @@
 namespace {
 
 constexpr int kStatReplicas = 8;   // as conv_tile.hip (ssa_bn_stat_replicas)
+
+// -DSSA_TILE_TIMING (experiment build, tools/expbuild.sh): s_memtime stamps of wave 0 of workgroup 0 at eight points of
+// each of its first 24 units, written through the `coef` pointer of a plain (aux_mode 0) launch (tools/tilebench.py --timing-q)
+#ifdef SSA_TILE_TIMING
+#define SSA_QSTAMP(k) do { if (tdbg && it < 24) { tlds[it * 8 + (k)] = (long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define SSA_QSTAMP(k) do { } while (0)
+#endif
 
 struct TileQArgs {
   const bf16_t* x; const uint4* wfrag; bf16_t* y; double* stats;
@@ -154,15 +162,24 @@ struct ConvTileQBody {
     const int cg = tid % CP, prow = tid / CP;
     uint4 v[IT];
     unsigned okmask = 0;                       // bit i: piece i lies inside the image
+    // per-thread constants of its pieces: halo coordinates (hy << 8 | hx, 0xffff: no such piece) and the 32-bit
+    // element offset relative to the tile's halo origin; a thread without an i-th piece (and, at the image border, a
+    // piece outside the image) loads the tile's own first pixel instead and is zeroed at staging time -- the loads
+    // issue back to back, unconditionally, as (wave-uniform 64-bit base) + (per-lane 32-bit offset): the phase stamps
+    // (profiles/r04_notes.md, call S) showed 1,000 clocks per unit of per-piece 64-bit address arithmetic here
     int hyx[IT];
+    unsigned rel[IT];
+    unsigned havemask = 0;
+    const unsigned rel_c = (unsigned)((W + 1) * ldx + cg * 8);      // halo pixel (1, 1) = output pixel (0, 0) of the tile
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int pix = prow + i * RP;
       const int hy = pix / HW_, hx = pix - hy * HW_;
       const bool have = stg && pix < NPIX;
       hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
+      rel[i] = have ? (unsigned)((hy * W + hx) * ldx + cg * 8) : rel_c;
+      havemask |= (have ? 1u : 0u) << i;
     }
-    const int rel_c = (W + 1) * ldx;                               // halo pixel (1, 1) = output pixel (0, 0) of the tile
     int f_b, f_ty, f_tx;
     {
       f_tx = t_begin % tiles_x;
@@ -173,14 +190,23 @@ struct ConvTileQBody {
     int c_b = f_b, c_ty = f_ty, c_tx = f_tx;
     auto fetch = [&](int cc) {
       const int x0 = f_tx * TW, y0 = f_ty * TH;
-      const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + cc * CK + cg * 8;
-      okmask = 0;
+      // wave-uniform: the tile's halo origin (one row above / one pixel left of the tile: possibly outside the buffer,
+      // never dereferenced there) and whether the whole halo lies inside the image
+      const bf16_t* xb = x + (((long)f_b * H + (y0 - 1)) * W + (x0 - 1)) * ldx + cc * CK;
+      const bool interior = x0 >= 1 && y0 >= 1 && x0 + TW + 1 <= W && y0 + TH + 1 <= H;
+      if (interior) {
+        okmask = havemask;
 #pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
-        const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? ((hyx[i] >> 8) * W + (hyx[i] & 255)) * ldx : rel_c));
-        okmask |= (ok ? 1u : 0u) << i;
+        for (int i = 0; i < IT; ++i) v[i] = *reinterpret_cast<const uint4*>(xb + rel[i]);
+      } else {
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
+          const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
+          okmask |= (ok ? 1u : 0u) << i;
+        }
       }
     };
     auto advance = [&](int* b, int* ty, int* tx) {
@@ -218,6 +244,14 @@ struct ConvTileQBody {
       }
     }
     uint4 auxv[AUX ? NPC : 1];
+    // tile row of piece p, and its element offsets in y / aux relative to the tile's first pixel (channel included)
+    auto prow_of = [&](int p) { return wave * PB + (p < NPA ? p : (PB >= 2 ? 2 * (p - NPA) + (g & 1) : 0)); };
+    unsigned poff[NPC], paoff[AUX ? NPC : 1];
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+      poff[p] = (unsigned)((prow_of(p) * W + px) * ldy + (p < NPA ? chA : chB));
+      if constexpr (AUX) paoff[p] = (unsigned)((prow_of(p) * W + px) * ldaux + (p < NPA ? chA : chB));
+    }
 
     // pixel fragment of k-step ks: 8 channels of (tap, channel) = flattened k-group ks*32 + 8*g of the halo pixel
     // (row + kh, px + kw); the padding groups (k >= 432) re-read the lane's k-group 16 below (their filter rows are
@@ -247,21 +281,26 @@ struct ConvTileQBody {
     fetch(0);
     int s = 0;                                         // global filter-stage counter: stage s lives in buffer s & 1
     int cc = 0;
+#ifdef SSA_TILE_TIMING
+    long* tdbg = (AUXM == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
+    long* tlds = reinterpret_cast<long*>(smem + ConvTileQBody<4, AUXM>::LDS);   // 1.5 KB past the launch's own LDS (the timing build asks for it)
+#endif
     for (int it = 0; it < n_iter; ++it) {
       // everyone is past the barrier that ended the previous unit's MFMAs: the halo image is free
+      SSA_QSTAMP(0);
       stage();
+      SSA_QSTAMP(1);
       if (it == 0) ssa_wait_vm_barrier<0, 0>();        // halo image visible + filter stage 0 landed
       else lds_barrier_q();                            // halo image visible
+      SSA_QSTAMP(2);
       const bool last_chunk = cc + 1 == nchunk;
       int ccn = cc + 1;
       if (last_chunk) { ccn = 0; if (it + 1 < n_iter) advance(&f_b, &f_ty, &f_tx); }
-      const int x0 = c_tx * TW, y0 = c_ty * TH + wave * PB;
-      const int ox = x0 + px;
-      const long img = (long)c_b * H * W;
-      // element offset of this lane's piece p (p < NPA: pixel row p, channels chA; else rows 2j / 2j + 1, channels chB)
-      auto piece_row = [&](int p) { return p < NPA ? y0 + p : y0 + (PB >= 2 ? 2 * (p - NPA) + (g & 1) : 0); };
-      auto piece_ok = [&](int p) { return piece_row(p) < H && ox < W && (p < NPA || b_lane); };
-      auto piece_pix = [&](int p) { return img + (long)min(piece_row(p), H - 1) * W + min(ox, W - 1); };
+      // this lane's piece p (p < NPA: pixel row p of the wave, channels chA; else rows 2j / 2j + 1, channels chB):
+      // (wave-uniform 64-bit element offset of the tile's first pixel) + (per-lane 32-bit offset, fixed for the kernel)
+      const int x0 = c_tx * TW, y0 = c_ty * TH;
+      const long tile0 = ((long)c_b * H + y0) * W + x0;
+      auto piece_ok = [&](int p) { return y0 + prow_of(p) < H && x0 + px < W && (p < NPA || b_lane); };
       if (cc == 0) {
 #pragma unroll
         for (int mb = 0; mb < 3; ++mb)
@@ -284,14 +323,16 @@ struct ConvTileQBody {
           fetch(ccn);
           if constexpr (AUX) {
             if (last_chunk) {
+              const bf16_t* ab = aux + tile0 * ldaux + cbase;      // (pieces outside the image re-read the tile's first pixel)
 #pragma unroll
               for (int p = 0; p < NPC; ++p)
-                auxv[p] = *reinterpret_cast<const uint4*>(aux + piece_pix(p) * ldaux + cbase + (p < NPA ? chA : chB));
+                auxv[p] = *reinterpret_cast<const uint4*>(ab + (piece_ok(p) ? paoff[p] : 0u));
             }
           }
           // the loads are ISSUED here, ahead of the MFMAs (left alone the compiler sinks them below the k-loop to re-use
           // their registers for fragments, and then waits vmcnt(0) -- i.e. for the DMAs just issued -- before the loop)
           asm volatile("" ::: "memory");
+          SSA_QSTAMP(3);
         }
         const unsigned char* Ac = Bs + (s & 1) * STAGE_BYTES + lane * 16;
         const unsigned char* Bc = smem + b_off;
@@ -364,14 +405,17 @@ struct ConvTileQBody {
         }
         // stage s + 1 landed (it was issued before this stage's loads); buffer s & 1 and, after the second stage,
         // the halo image are free
+        if (st == 0) SSA_QSTAMP(4);
         if (st == 0) {
           if (AUX && last_chunk) ssa_wait_vm_barrier<IT + NPC, 0>();
           else ssa_wait_vm_barrier<IT, 0>();
         } else {
           ssa_wait_vm_barrier<0, 0>();
         }
+        if (st == 0) SSA_QSTAMP(5);
         ++s;
       }
+      SSA_QSTAMP(6);
       if (last_chunk) {
         // ---- epilogue in registers: 4 channels per (block, pixel row) -> 16-byte pieces by row exchange -> HBM
         unsigned w[3][PB][2];
@@ -383,6 +427,7 @@ struct ConvTileQBody {
             w[mb][pb][1] = f2bf_pair(acc[mb][pb][2], acc[mb][pb][3]);
           }
         // one 16-byte piece: fused epilogue, statistics (S / Q = this lane's sums of the piece's 8 channels), store
+        bf16_t* yb = y + tile0 * ldy + cbase;
         auto finish = [&](uint4 o, const int p, const int ch, float (&S)[AUXM == 1 ? 1 : 8], float (&Q)[AUXM == 1 ? 1 : 8]) {
           const bool ok = piece_ok(p);
           if constexpr (AUXM == 1) {
@@ -418,7 +463,7 @@ struct ConvTileQBody {
               for (int j = 0; j < 8; ++j) { S[j] += f[j]; Q[j] += f[j] * f[j]; }
             }
           }
-          if (ok) *reinterpret_cast<uint4*>(y + piece_pix(p) * ldy + cbase + ch) = o;
+          if (ok) *reinterpret_cast<uint4*>(yb + poff[p]) = o;
         };
 #pragma unroll
         for (int p = 0; p < NPA; ++p) {
@@ -439,8 +484,13 @@ struct ConvTileQBody {
         }
         advance(&c_b, &c_ty, &c_tx);
       }
+      SSA_QSTAMP(7);
       cc = ccn;
     }
+#ifdef SSA_TILE_TIMING
+    if (tdbg)
+      for (int i = 0; i < 24 * 8; ++i) tdbg[i] = i < n_iter * 8 ? tlds[i] : 0;
+#endif
 
     // ---- statistics of the strip: 16 pixel lanes -> (block 2: the two lane rows of a channel group) -> wave ->
     // workgroup -> one fp64 atomic per channel
@@ -496,7 +546,11 @@ struct ConvTileQK {
   typedef TileQArgs Args;
   static constexpr int NT = 256;
   static constexpr int WPE = 2;                  // two workgroups per CU: <= 256 registers
+#ifdef SSA_TILE_TIMING
+  static constexpr size_t LDS = ConvTileQBody<4, AUXM>::LDS + 1536;
+#else
   static constexpr size_t LDS = ConvTileQBody<4, AUXM>::LDS;
+#endif
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
     // (aux_mode 2 carries 56 more registers -- the x tile and two more sets of sums -- and does not fit 256 at
     // pb = 4: its problems run at pb <= 2, see choose_pb)
@@ -511,9 +565,13 @@ struct ConvTileQK {
 static thread_local int g_q_budget = 0;        // MFMA budget (units of 42 per wave) per workgroup, 0 = per problem
 
 int choose_pb(const ssa_conv_desc& d, int aux_mode) {
-  static const int forced = getenv("SSA_TILE_Q_PB") ? atoi(getenv("SSA_TILE_Q_PB")) : 0;
+  const char* env = getenv("SSA_TILE_Q_PB");          // read per launch: experiments and tests switch it inside a process
+  const int forced = env ? atoi(env) : 0;
   const int nchunk = d.Cin / 48;
-  int pb = nchunk <= 2 ? 4 : (nchunk == 4 ? 2 : 1);
+  // measured (profiles/r04_notes.md, call R): 16 x 8-pixel tiles (pb = 2) beat 16 x 16 (pb = 4) for 48 / 96 channels
+  // too -- twice the workgroups for the small problems -- and 384 channels want the shortest chain (pb = 1); pb = 4 is
+  // reachable through SSA_TILE_Q_PB
+  int pb = nchunk <= 4 ? 2 : 1;
   if (forced == 1 || forced == 2 || forced == 4) pb = forced;
   if (aux_mode == 2 && pb > 2) pb = 2;
   while (pb > 1 && 2 * pb >= d.H) pb >>= 1;     // half the rows still cover the image

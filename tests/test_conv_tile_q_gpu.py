@@ -130,8 +130,8 @@ def _oracle_conv(x, w):
     return O.conv2d(x, w, None, 1, 1, 1)
 
 
-# (C, B, H, W): pb = 4 for 48 / 96 channels, 2 for 192, 1 for 384; ragged right / bottom edges; images lower than a
-# tile (pb halves); several tiles per strip
+# (C, B, H, W): pb = 2 up to 192 channels, 1 for 384 (test_q_forced_wave_shapes: the others); ragged right / bottom
+# edges; images lower than a tile (pb halves); several tiles per strip
 FWD_CASES = [(48, 1, 16, 16), (48, 2, 21, 37), (96, 1, 16, 32), (96, 1, 7, 19), (192, 1, 8, 16), (192, 1, 11, 18),
              (384, 1, 4, 16), (384, 1, 6, 17)]
 
@@ -205,9 +205,36 @@ def test_q_dgrad_epilogues_equal_the_default_kernel(C, B, H, W):
     assert err < 1e-4
 
 
-def test_q_strips_of_several_tiles_and_forced_wave_shapes():
+@pytest.mark.parametrize("pb", [4, 1])
+@pytest.mark.parametrize("C,B,H,W", [(48, 1, 21, 37), (96, 1, 18, 16)])
+def test_q_forced_wave_shapes(monkeypatch, pb, C, B, H, W):
+    """SSA_TILE_Q_PB (read per launch) forces the wave shape: 16 x 16-pixel tiles (pb = 4) and 16 x 4 (pb = 1) on the
+    problems that run at pb = 2 by default; forward + statistics, and the fused-sums data gradient (pb = 4 is not
+    compiled for aux_mode 2: it runs at 2)."""
+    monkeypatch.setenv("SSA_TILE_Q_PB", str(pb))
+    hb = _hb()
+    x = _rand(B, C, H, W, seed=71)
+    w = _rand(C, C, 3, 3, seed=72, scale=(2.0 / (9 * C)) ** 0.5)
+    xd, wd = _dev_nhwc(x), w.to(DEV)
+    hb.begin_step(torch.device(DEV))
+    y, stats = hb._conv_fwd(xd, C, wd, None, 1, 1, 1, False, True)
+    _sync()
+    check_close("q forced pb %d" % pb, nchw(y.float()), _oracle_conv(x, w))
+    yf = y.double().cpu().reshape(-1, C)
+    got = stats.double().cpu().view(hb.stat_replicas(), 2, C).sum(0)
+    want = torch.stack([yf.sum(0), (yf * yf).sum(0)])
+    scale = torch.stack([yf.abs().sum(0), (yf * yf).sum(0)]).clamp_min(1e-30)
+    assert ((got - want).abs() / scale).max().item() < 2e-5
+    hb._PENDING_STATS.clear()
+    monkeypatch.delenv("SSA_TILE_Q_PB")
+    y2, _ = hb._conv_fwd(xd, C, wd, None, 1, 1, 1, False, False)
+    _sync()
+    check_close("forced vs default wave shape", y.float(), y2.float(), 8e-3, 1e-4)
+
+
+def test_q_strips_of_several_tiles():
     """A strip budget that puts several tiles (and all chunks of each) on one workgroup; the result does not depend
-    on the budget.  (The wave shape is a property of the problem; SSA_TILE_Q_PB forces it for experiments.)"""
+    on the budget."""
     hb = _hb()
     C, B, H, W = 96, 1, 40, 24
     x = _rand(B, C, H, W, seed=41)
@@ -233,7 +260,7 @@ def test_q_strips_of_several_tiles_and_forced_wave_shapes():
 
 
 def test_q_grouped_level_mixes_wave_shapes():
-    """Four branches of a trunk level (48 / 96 / 192 / 384 channels: pb 4, 4, 2, 1) in ONE grouped launch, bit-identical
+    """Four branches of a trunk level (48 / 96 / 192 / 384 channels: pb 2, 2, 2, 1) in ONE grouped launch, bit-identical
     to the four separate launches."""
     hb = _hb()
     shapes = [(48, 32, 32), (96, 16, 16), (192, 8, 16), (384, 4, 16)]

@@ -12,9 +12,10 @@ for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
 import torch  # noqa: E402
 from semseg_amd import hip_backend as hb  # noqa: E402
 
-if "--timing" in sys.argv:
+if "--timing" in sys.argv or "--timing-q" in sys.argv or "--lib" in sys.argv:
     from semseg_amd import _lib
-    _lib.LIB_PATH = _lib.LIB_PATH.replace("libsemseg_hip.so", "libsemseg_hip_timing.so")
+    _name = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else ("timingq" if "--timing-q" in sys.argv else "timing")
+    _lib.LIB_PATH = _lib.LIB_PATH.replace("libsemseg_hip.so", "libsemseg_hip_%s.so" % _name)
 L = hb.lib()
 DEV = "cuda"
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())  # noqa: E731
@@ -219,8 +220,33 @@ def main_q():
     L.ssa_conv_tile_q_strip(0)
 
 
+def timing_q():
+    """Phase stamps (s_memtime) of wave 0 of workgroup 0 of conv_tile_q.hip from the -DSSA_TILE_TIMING build
+    (sh tools/expbuild.sh timingq conv_tile_q.hip -DSSA_TILE_TIMING)."""
+    names = ["start", "staged", "barY", "issued", "mfma0", "bar0", "mfma1+bar", "epilogue"]
+    for (C, H, W), budget in (((48, 256, 256), 32), ((96, 128, 128), 32), ((192, 64, 64), 32), ((384, 32, 32), 32), ((48, 256, 256), 4)):
+        p = Prob(C, H, W, 1)
+        dbg = torch.zeros(24 * 8, dtype=torch.int64, device=DEV)
+        L.ssa_conv_tile_q_strip(budget)
+        for _ in range(3):
+            hb.check(L.ssa_conv2d_tile_q(ctypes.byref(p.d), P(p.x), P(p.wq), P(p.yq), P(p.stats), None, C, P(dbg), 0, hb._s()), "tile_q")
+        torch.cuda.synchronize()
+        t = dbg.cpu().view(24, 8)
+        print("== %d @ %dx%d budget %d (SSA_TILE_Q_PB=%s): stamps in ticks of s_memtime relative to the unit's start" % (
+            C, H, W, budget, os.environ.get("SSA_TILE_Q_PB", "-")))
+        print("   it " + " ".join("%9s" % n for n in names) + "   next-start")
+        for i in range(24):
+            if int(t[i, 0]) == 0:
+                break
+            nxt = int(t[i + 1, 0]) - int(t[i, 0]) if i + 1 < 24 and int(t[i + 1, 0]) else -1
+            print("   %2d " % i + " ".join("%9d" % (int(t[i, k]) - int(t[i, 0])) for k in range(8)) + "   %d" % nxt)
+    L.ssa_conv_tile_q_strip(0)
+
+
 if __name__ == "__main__":
-    if "--q" in sys.argv:
+    if "--timing-q" in sys.argv:
+        timing_q()
+    elif "--q" in sys.argv:
         main_q()
     elif "--timing" in sys.argv:
         timing()
