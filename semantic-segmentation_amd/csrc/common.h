@@ -46,6 +46,12 @@ __device__ __forceinline__ void ssa_glds16_untracked(const void* gsrc, void* lds
 __device__ __forceinline__ void ssa_glds16_untracked_sv(const void* sbase, unsigned voff, void* lds_dst) {
   emu::global_load_lds16(reinterpret_cast<const unsigned char*>(sbase) + voff, lds_dst);
 }
+__device__ __forceinline__ unsigned ssa_lds_addr(const void* lds_ptr) {
+  return (unsigned)(reinterpret_cast<const unsigned char*>(lds_ptr) - emu::dyn_lds());
+}
+__device__ __forceinline__ void ssa_glds16_untracked_m0(const void* sbase, unsigned voff, unsigned lds_addr) {
+  emu::global_load_lds16(reinterpret_cast<const unsigned char*>(sbase) + voff, emu::dyn_lds() + lds_addr);
+}
 #else
 #define SSA_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 // D = A(32x16) * B(16x32) + C on one wave; lane l holds row/column l & 31, k = 8 * (l >> 5) + j
@@ -94,6 +100,15 @@ __device__ __forceinline__ void ssa_glds16_untracked_sv(const void* sbase, unsig
   const unsigned base = __builtin_amdgcn_readfirstlane(
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(base) : "memory");
+}
+// The same with the destination as a 32-bit LDS address (ssa_lds_addr(pointer), taken ONCE per kernel): the cast of a
+// generic pointer to the LDS address space is a null test + select every time it is written out, ~6 scalar instructions
+// per DMA, and a lone wave issues an instruction every 5-8 clocks (profiles/r04_notes.md, call T)
+__device__ __forceinline__ unsigned ssa_lds_addr(const void* lds_ptr) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)lds_ptr);
+}
+__device__ __forceinline__ void ssa_glds16_untracked_m0(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 // LDS written by some lanes of a wave, read by others of the SAME wave: the hardware runs a wave's LDS operations
 // in order, so only the compiler must not move the reads above the writes (the emulation runs lanes as

@@ -134,11 +134,11 @@ struct ConvTileP {
   // f of the wave relative to the stage's first k-step (tile- and stage-invariant, computed once per workgroup);
   // sbase = the filter + the stage's (chunk, first tap) k-step offset (wave-uniform)
   static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND],
-                                                      unsigned char* dst, int wave) {
+                                                      unsigned dst, int wave) {      // dst: LDS address (ssa_lds_addr)
 #pragma unroll
     for (int f = 0; f < ND; ++f) {
       const int fi = min(f * 4 + wave, NFRAG - 1);      // wave-uniform; the last fragments are issued twice
-      ssa_glds16_untracked_sv(sbase, voff[f], dst + (size_t)fi * 1024);
+      ssa_glds16_untracked_m0(sbase, voff[f], dst + (unsigned)fi * 1024u);
     }
   }
 
@@ -176,16 +176,19 @@ struct ConvTileP {
     // tile-invariant part of this thread's pieces: halo coordinates (hy << 8 | hx, 0xffff: no such piece) and the
     // element offset relative to the tile's first halo pixel; invalid lanes load the tile's own first pixel instead
     // (always inside the image) and are zeroed at staging time -- the loads issue back to back, unconditionally
-    int hyx[IT], rel[IT];
+    int hyx[IT];
+    unsigned rel[IT];
+    unsigned havemask = 0;
+    const unsigned rel_c = (unsigned)((W + 1) * ldx + cg * 8);      // halo pixel (1, 1) = output pixel (0, 0) of the tile
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int pix = prow + i * RP;
       const int hy = pix / HW_, hx = pix - hy * HW_;
       const bool have = stg && pix < NPIX;
       hyx[i] = have ? ((hy << 8) | hx) : 0xffff;
-      rel[i] = (hy * W + hx) * ldx;
+      rel[i] = have ? (unsigned)((hy * W + hx) * ldx + cg * 8) : rel_c;
+      havemask |= (have ? 1u : 0u) << i;
     }
-    const int rel_c = (W + 1) * ldx;                               // halo pixel (1, 1) = output pixel (0, 0) of the tile
     // tile walk without divisions: (image, tile row, tile column) of the tile whose halo is fetched next
     int f_b, f_ty, f_tx;
     {
@@ -196,16 +199,26 @@ struct ConvTileP {
     }
     int c_b = f_b, c_ty = f_ty, c_tx = f_tx;                       // ... and of the tile being computed
     // global -> registers: the halo of (the fetch tile, channel chunk cc)
+    // (wave-uniform 64-bit base: the tile's halo origin, possibly outside the buffer and never dereferenced there)
+    // + (per-lane 32-bit offset); a tile whose whole halo lies inside the image skips the per-piece bounds tests -- a
+    // lone wave issues an instruction every 5-8 clocks, so the ~35 instructions are ~200 clocks per unit
     auto fetch = [&](int cc) {
       const int x0 = f_tx * TW, y0 = f_ty * TH;
-      const bf16_t* xb = x + ((long)f_b * H * W + (long)(y0 - 1) * W + (x0 - 1)) * ldx + cc * CK + cg * 8;
-      okmask = 0;
+      const bf16_t* xb = x + (((long)f_b * H + (y0 - 1)) * W + (x0 - 1)) * ldx + cc * CK;
+      const bool interior = x0 >= 1 && y0 >= 1 && x0 + TW + 1 <= W && y0 + TH + 1 <= H;
+      if (interior) {
+        okmask = havemask;
 #pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
-        const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
-        okmask |= (ok ? 1u : 0u) << i;
+        for (int i = 0; i < IT; ++i) v[i] = *reinterpret_cast<const uint4*>(xb + rel[i]);
+      } else {
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+          const int iy = y0 - 1 + (hyx[i] >> 8), ix = x0 - 1 + (hyx[i] & 255);
+          const bool ok = hyx[i] != 0xffff && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+          v[i] = *reinterpret_cast<const uint4*>(xb + (ok ? rel[i] : rel_c));
+          okmask |= (ok ? 1u : 0u) << i;
+        }
       }
     };
     auto advance = [&](int* b, int* ty, int* tx) {
@@ -266,8 +279,9 @@ struct ConvTileP {
     }
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(wfrag);
     auto stage_base = [&](int cc_, int tap0) { return wbytes + (long)(tap0 * csteps_total + cc_ * CST) * 1024; };
-    stage_filter(stage_base(0, 0), voff, Bs, wave);
-    stage_filter(stage_base(0, TPC), voff, Bs + STAGE_BYTES, wave);
+    const unsigned bs_lds = ssa_lds_addr(Bs);          // LDS address of the filter ring, taken once
+    stage_filter(stage_base(0, 0), voff, bs_lds, wave);
+    stage_filter(stage_base(0, TPC), voff, bs_lds + STAGE_BYTES, wave);
     fetch(0);
     int s = 0;                                         // global filter-stage counter (streamed variant)
     int cc = 0;
@@ -299,7 +313,7 @@ struct ConvTileP {
           // stage s + 2 of the continuous filter stream (past the end of the strip: a stage nobody reads)
           const int cc2 = st + 2 < NSTAGE ? cc : ccn;
           const int tap2 = ((st + 2) % NSTAGE) * TPC;
-          stage_filter(stage_base(cc2, tap2), voff, Bs + ((s + 2) % 3) * STAGE_BYTES, wave);
+          stage_filter(stage_base(cc2, tap2), voff, bs_lds + ((s + 2) % 3) * STAGE_BYTES, wave);
         }
         if (st == 0) {
           // next unit's halo (the last unit re-reads its own: the count of loads in flight stays fixed) and this

@@ -125,11 +125,11 @@ struct ConvTileQBody {
   static_assert(IT <= 8, "halo pieces per thread");
 
   static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND],
-                                                      unsigned char* dst, int wave) {
+                                                      unsigned dst, int wave) {      // dst: LDS address (ssa_lds_addr)
 #pragma unroll
     for (int f = 0; f < ND; ++f) {
       const int fi = min(f * 4 + wave, NFRAG - 1);      // wave-uniform; the last fragments are issued twice
-      ssa_glds16_untracked_sv(sbase, voff[f], dst + (size_t)fi * 1024);
+      ssa_glds16_untracked_m0(sbase, voff[f], dst + (unsigned)fi * 1024u);
     }
   }
 
@@ -277,7 +277,8 @@ struct ConvTileQBody {
     auto stage_base = [&](int cc_, int st_) { return wbytes + (long)(cc_ * 2 + st_) * STAGE_BYTES; };
 
     // ---- prologue: filter stage 0 on its way into LDS, first halo into registers
-    stage_filter(stage_base(0, 0), voff, Bs, wave);
+    const unsigned bs_lds = ssa_lds_addr(Bs);          // LDS address of the filter ring, taken once
+    stage_filter(stage_base(0, 0), voff, bs_lds, wave);
     fetch(0);
     int s = 0;                                         // global filter-stage counter: stage s lives in buffer s & 1
     int cc = 0;
@@ -315,7 +316,7 @@ struct ConvTileQBody {
         // stage nobody reads); a resident slice is complete after the first two stages
         if (!resident || s == 0) {
           const int cc1 = st == 0 ? cc : ccn;
-          stage_filter(stage_base(cc1, st ^ 1), voff, Bs + ((s + 1) & 1) * STAGE_BYTES, wave);
+          stage_filter(stage_base(cc1, st ^ 1), voff, bs_lds + ((s + 1) & 1) * STAGE_BYTES, wave);
         }
         if (st == 0) {
           // next unit's halo (the last unit re-reads its own: the count of loads in flight stays fixed) and this
