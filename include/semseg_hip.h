@@ -158,6 +158,10 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag,
  * ssa_conv_tile_q_strip(budget): MFMAs per wave (in units of 42) a workgroup of the calling thread's NEXT launches
  * should carry, 0 = derive from each problem alone; ssa_conv_tile_q_wgs: the workgroups a problem launches at a budget
  * and aux_mode (aux_mode 2 runs at pb <= 2) -- for the caller that sizes a grouped level.                                                                      */
+/* ssa_conv_tile_q_config(1): the three-workgroups-per-CU form of the kernel (filter in three stages through two 15 KB
+ * buffers, pb <= 2, <= 168 registers; process-wide, set before the first launch; 0 = the default form).  Checked on
+ * the CPU emulation only so far.                                                                                    */
+int ssa_conv_tile_q_config(int three_per_cu);
 int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d);
 int ssa_conv_tile_q_strip(int budget);
 int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget, int aux_mode);

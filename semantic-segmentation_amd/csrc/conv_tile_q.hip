@@ -95,7 +95,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 #endif
 }
 
-template <int PB, int AUXM>
+// NST = filter stages per unit: 2 (7 + 7 k-steps: a ring of two 21 KB buffers, 64-78 KB of LDS, two workgroups per CU) or
+// 3 (5 + 5 + 4 k-steps: a ring of two 15 KB buffers, <= 51 KB at PB <= 2: THREE workgroups per CU)
+template <int PB, int AUXM, int NST = 2>
 struct ConvTileQBody {
   static constexpr bool AUX = AUXM != 0;
   static constexpr int NT = 256;
@@ -109,11 +111,15 @@ struct ConvTileQBody {
   static constexpr int IT = (NPIX + RP - 1) / RP;    // halo loads per thread and unit
   static constexpr int KS = 14;                      // k-steps of 32 per unit: 9 taps x 48 channels = 432, padded to 448
   static constexpr int KREAL = 9 * CK;
-  static constexpr int SKS = 7;                      // k-steps per filter stage
-  static constexpr int NFRAG = SKS * 3;              // 1 KiB filter fragments per stage (3 channel blocks of 16 per k-step)
+  static_assert(NST == 2 || NST == 3, "filter stages per unit");
+  static constexpr int SKS = NST == 2 ? 7 : 5;       // k-steps of the longest filter stage
+  // first k-step of stage st (st = NST: the end)
+  static constexpr int k0(int st) { return NST == 2 ? 7 * st : (st == 3 ? 14 : 5 * st); }
+  static constexpr int NFRAG = SKS * 3;              // 1 KiB filter fragments of the longest stage (3 channel blocks of 16 per k-step)
   static constexpr int ND = (NFRAG + 3) / 4;         // DMAs per wave and stage (the last ones duplicated: every wave issues ND)
-  static constexpr int STAGE_BYTES = NFRAG * 1024;
-  static constexpr int UNIT_BYTES = 2 * STAGE_BYTES; // filter bytes per (48-channel n-tile, chunk)
+  static constexpr int STAGE_BYTES = NFRAG * 1024;   // one ring buffer
+  static constexpr int UNIT_BYTES = 14 * 3 * 1024;   // filter bytes per (48-channel n-tile, chunk)
+  static_assert((ND - 1) * 4 <= (k0(NST) - k0(NST - 1)) * 3, "only the last DMA of a wave may be a duplicate");
   static constexpr int HALO_RAW = NPIX * PSB;
   static constexpr int HALO_BYTES = (HALO_RAW + 2 * CK * 4 + 1023) / 1024 * 1024;   // + the coefficient table of aux_mode 2
   static constexpr int NPA = PB;                     // 16-byte epilogue pieces per lane from channel blocks 0 / 1
@@ -121,15 +127,17 @@ struct ConvTileQBody {
   static constexpr int NPC = NPA + NPB;
   static constexpr size_t LDS = (size_t)HALO_BYTES + 2 * (size_t)STAGE_BYTES;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(NST == 2 || PB == 4 || LDS <= 53 * 1024, "three workgroups per CU");
   static_assert(4 * 2 * CK * 4 <= HALO_RAW, "statistics reduction does not fit");
   static_assert(IT <= 8, "halo pieces per thread");
 
-  static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND],
-                                                      unsigned dst, int wave) {      // dst: LDS address (ssa_lds_addr)
+  // nfrag = fragments of the stage being loaded; vlast = this lane's source offset of its last (possibly clamped) DMA
+  static __device__ __forceinline__ void stage_filter(const unsigned char* sbase, const unsigned (&voff)[ND], unsigned vlast,
+                                                      int nfrag, unsigned dst, int wave) {   // dst: LDS address (ssa_lds_addr)
 #pragma unroll
     for (int f = 0; f < ND; ++f) {
-      const int fi = min(f * 4 + wave, NFRAG - 1);      // wave-uniform; the last fragments are issued twice
-      ssa_glds16_untracked_m0(sbase, voff[f], dst + (unsigned)fi * 1024u);
+      const int fi = min(f * 4 + wave, nfrag - 1);      // wave-uniform; the last fragments are issued twice
+      ssa_glds16_untracked_m0(sbase, f == ND - 1 ? vlast : voff[f], dst + (unsigned)fi * 1024u);
     }
   }
 
@@ -155,7 +163,7 @@ struct ConvTileQBody {
     const int nchunk = Cin / CK;
     const int n_iter = (t_end - t_begin) * nchunk;
     if (n_iter <= 0) return;
-    const bool resident = nchunk == 1;                             // the ring holds the whole filter slice
+    const bool resident = nchunk == 1 && NST == 2;                 // the ring holds the whole filter slice
 
     // ---- staging role of this thread: channel group cg of halo pixels prow, prow + RP, ...
     const bool stg = tid < NA;
@@ -273,18 +281,25 @@ struct ConvTileQBody {
     unsigned voff[ND];
 #pragma unroll
     for (int f = 0; f < ND; ++f) voff[f] = (unsigned)((min(f * 4 + wave, NFRAG - 1) * 64 + lane) * 16);
+    // (the last stage of three is a k-step shorter: its last DMA clamps to fragment 11 instead of 14)
+    constexpr int NFRAG_LAST = (k0(NST) - k0(NST - 1)) * 3;
+    const unsigned voff_short = (unsigned)((min((ND - 1) * 4 + wave, NFRAG_LAST - 1) * 64 + lane) * 16);
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(a.wfrag) + (long)nt * nchunk * UNIT_BYTES;
-    auto stage_base = [&](int cc_, int st_) { return wbytes + (long)(cc_ * 2 + st_) * STAGE_BYTES; };
+    auto stage_base = [&](int cc_, int st_) { return wbytes + (long)cc_ * UNIT_BYTES + k0(st_) * 3 * 1024; };
+    auto load_stage = [&](int cc_, int st_, unsigned dst) {        // st_ is a compile-time constant at every call
+      const int nfrag = (k0(st_ + 1) - k0(st_)) * 3;
+      stage_filter(stage_base(cc_, st_), voff, nfrag == NFRAG ? voff[ND - 1] : voff_short, nfrag, dst, wave);
+    };
 
     // ---- prologue: filter stage 0 on its way into LDS, first halo into registers
     const unsigned bs_lds = ssa_lds_addr(Bs);          // LDS address of the filter ring, taken once
-    stage_filter(stage_base(0, 0), voff, bs_lds, wave);
+    load_stage(0, 0, bs_lds);
     fetch(0);
     int s = 0;                                         // global filter-stage counter: stage s lives in buffer s & 1
     int cc = 0;
 #ifdef SSA_TILE_TIMING
     long* tdbg = (AUXM == 0 && bx == 0 && tid == 0) ? reinterpret_cast<long*>(const_cast<float*>(coef)) : nullptr;
-    long* tlds = reinterpret_cast<long*>(smem + ConvTileQBody<4, AUXM>::LDS);   // 1.5 KB past the launch's own LDS (the timing build asks for it)
+    long* tlds = reinterpret_cast<long*>(smem + ConvTileQBody<4, AUXM, 2>::LDS);   // 1.5 KB past the launch's own LDS (the timing build asks for it)
 #endif
     for (int it = 0; it < n_iter; ++it) {
       // everyone is past the barrier that ended the previous unit's MFMAs: the halo image is free
@@ -311,12 +326,12 @@ struct ConvTileQBody {
             for (int r = 0; r < 4; ++r) acc[mb][pb][r] = 0.f;
       }
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
+      for (int st = 0; st < NST; ++st) {
         // stage s + 1 of the continuous filter stream into the buffer stage s - 1 left (past the end of the strip: a
         // stage nobody reads); a resident slice is complete after the first two stages
         if (!resident || s == 0) {
-          const int cc1 = st == 0 ? cc : ccn;
-          stage_filter(stage_base(cc1, st ^ 1), voff, bs_lds + ((s + 1) & 1) * STAGE_BYTES, wave);
+          if (st + 1 < NST) load_stage(cc, st + 1, bs_lds + ((s + 1) & 1) * STAGE_BYTES);
+          else load_stage(ccn, 0, bs_lds + ((s + 1) & 1) * STAGE_BYTES);
         }
         if (st == 0) {
           // next unit's halo (the last unit re-reads its own: the count of loads in flight stays fixed) and this
@@ -348,8 +363,9 @@ struct ConvTileQBody {
           for (int mb = 0; mb < 3; ++mb)
             fa[ksl & 1][mb] = *reinterpret_cast<const bf16x8_t*>(Ac + (ksl * 3 + mb) * 1024);
         };
+        const int nks = k0(st + 1) - k0(st);          // k-steps of this stage (a constant: st is unrolled)
         auto rd_b = [&](int ksl, int pb) {
-          fb[ksl % NFB][pb] = *reinterpret_cast<const bf16x8_t*>(Bc + offk(st * SKS + ksl) + pb * HW_ * PSB);
+          fb[ksl % NFB][pb] = *reinterpret_cast<const bf16x8_t*>(Bc + offk(k0(st) + ksl) + pb * HW_ * PSB);
         };
 #pragma unroll
         for (int pb = 0; pb < PB; ++pb) rd_b(0, pb);
@@ -357,7 +373,8 @@ struct ConvTileQBody {
         __builtin_amdgcn_sched_group_barrier(0x100, 3 + PB, 0);
 #pragma unroll
         for (int ksl = 0; ksl < SKS; ++ksl) {
-          if (ksl + 1 < SKS) {
+          if (ksl >= nks) break;
+          if (ksl + 1 < nks) {
             rd_a(ksl + 1);
             if constexpr (NFB == 2) {
 #pragma unroll
@@ -370,13 +387,13 @@ struct ConvTileQBody {
             for (int mb = 0; mb < 3; ++mb)
               acc[mb][pb] = ssa_mfma16(fa[ksl & 1][mb], fb[ksl % NFB][pb], acc[mb][pb]);     // D[channel][pixel]
             if constexpr (NFB == 1) {
-              if (ksl + 1 < SKS) rd_b(ksl + 1, pb);
+              if (ksl + 1 < nks) rd_b(ksl + 1, pb);
             }
           }
           // issue order of the k-step: the next k-step's 3 + PB fragment reads spread between this one's 3*PB MFMAs
           // (left alone the compiler shortens the fragments' live ranges by reading each one right in front of its
           // first MFMA, i.e. it exposes the LDS latency every three MFMAs)
-          if (ksl + 1 < SKS) {
+          if (ksl + 1 < nks) {
             if constexpr (PB == 4) {
 #pragma unroll
               for (int r = 0; r < 3; ++r) {
@@ -411,7 +428,7 @@ struct ConvTileQBody {
           if (AUX && last_chunk) ssa_wait_vm_barrier<IT + NPC, 0>();
           else ssa_wait_vm_barrier<IT, 0>();
         } else {
-          ssa_wait_vm_barrier<0, 0>();
+          ssa_wait_vm_barrier<0, 0>();     // (nothing was issued after this stage's DMAs)
         }
         if (st == 0) SSA_QSTAMP(5);
         ++s;
@@ -563,7 +580,26 @@ struct ConvTileQK {
   }
 };
 
+// The three-workgroups-per-CU form (ssa_conv_tile_q_config(1)): the same bodies with the filter in three stages of
+// 5 + 5 + 4 k-steps through two 15 KB buffers -- 51 KB of LDS at pb = 2 --, pb <= 2, <= 168 registers.  The 48-channel
+// slice is no longer resident (42 KB > the ring).  NOT yet run on the device: built and checked on the CPU emulation
+// at the end of round 4 (profiles/r04_notes.md: what the two-per-CU form's phase stamps ask for).
+template <int AUXM>
+struct ConvTileQ3K {
+  typedef TileQArgs Args;
+  static constexpr int NT = 256;
+  // three workgroups per CU: <= 168 registers (aux_mode 2 -- the x tile and two more sets of sums -- needs 183: it is
+  // compiled for two waves per SIMD and lives with the occupancy its registers allow)
+  static constexpr int WPE = AUXM == 2 ? 2 : 3;
+  static constexpr size_t LDS = ConvTileQBody<2, AUXM, 3>::LDS;
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int /*by*/, const int /*gx*/) {
+    if (a.pb == 2) ConvTileQBody<2, AUXM, 3>::run(a, bx);
+    else ConvTileQBody<1, AUXM, 3>::run(a, bx);
+  }
+};
+
 static thread_local int g_q_budget = 0;        // MFMA budget (units of 42 per wave) per workgroup, 0 = per problem
+static int g_q_three = 0;                      // ssa_conv_tile_q_config: 1 = the three-workgroups-per-CU form
 
 int choose_pb(const ssa_conv_desc& d, int aux_mode) {
   const char* env = getenv("SSA_TILE_Q_PB");          // read per launch: experiments and tests switch it inside a process
@@ -574,7 +610,7 @@ int choose_pb(const ssa_conv_desc& d, int aux_mode) {
   // reachable through SSA_TILE_Q_PB
   int pb = nchunk <= 4 ? 2 : 1;
   if (forced == 1 || forced == 2 || forced == 4) pb = forced;
-  if (aux_mode == 2 && pb > 2) pb = 2;
+  if ((aux_mode == 2 || g_q_three) && pb > 2) pb = 2;
   while (pb > 1 && 2 * pb >= d.H) pb >>= 1;     // half the rows still cover the image
   return pb;
 }
@@ -587,9 +623,10 @@ void plan_q(const ssa_conv_desc& d, int budget, int aux_mode, TileQArgs* a) {
   a->tiles_y = (d.H + 4 * a->pb - 1) / (4 * a->pb);
   a->total_tiles = d.B * a->tiles_x * a->tiles_y;
   if (budget <= 0) {
-    // a launch of its own: ~2 workgroups per CU from this problem alone
+    // a launch of its own: ~2 (3) workgroups per CU from this problem alone
     const long total = (long)a->total_tiles * a->nt_total * nchunk * a->pb;
-    budget = (int)((total + 511) / 512);
+    const int slots = g_q_three ? 768 : 512;
+    budget = (int)((total + slots - 1) / slots);
   }
   int tpw = budget / (nchunk * a->pb);
   if (tpw < 1) tpw = 1;
@@ -603,6 +640,7 @@ template <int AUXM>
 int launch_q(const ssa_conv_desc& d, const TileQArgs& a0, hipStream_t s) {
   TileQArgs a = a0;
   plan_q(d, g_q_budget, AUXM, &a);
+  if (g_q_three) return ssa::submit<ConvTileQ3K<AUXM>>(a, a.nwg, 1, ConvTileQ3K<AUXM>::LDS, s);
   return ssa::submit<ConvTileQK<AUXM>>(a, a.nwg, 1, ConvTileQK<AUXM>::LDS, s);
 }
 
@@ -615,6 +653,11 @@ int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d) {
   if (d->W < 16) return 0;                    // 16-pixel-wide tiles; narrower images stay on conv_tile.hip
   if (d->Cout % 48) return 0;
   return d->Cin == 48 || d->Cin == 96 || d->Cin == 192 || d->Cin == 384;
+}
+
+int ssa_conv_tile_q_config(int three_per_cu) {
+  g_q_three = three_per_cu ? 1 : 0;
+  return SSA_OK;
 }
 
 int ssa_conv_tile_q_strip(int budget) {

@@ -563,12 +563,21 @@ def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
 
 
 # ---- 48-channel-block geometry of the trunk conv (csrc/conv_tile_q.hip): opt-in until it has been measured
-_TILE_Q = os.environ.get("SSA_TILE_Q", "0") == "1"
-_TILE_Q_WGS = int(os.environ.get("SSA_TILE_Q_WGS", "512"))      # most workgroups a grouped level may launch (2 per CU)
+# SSA_TILE_Q=1: two workgroups per CU (measured); =3: the three-per-CU form (ssa_conv_tile_q_config(1);
+# checked on the CPU emulation, first device numbers in profiles/r04_notes.md)
+_TILE_Q_MODE = os.environ.get("SSA_TILE_Q", "0")
+_TILE_Q = _TILE_Q_MODE in ("1", "3")
+_TILE_Q_WGS = int(os.environ.get("SSA_TILE_Q_WGS", "768" if _TILE_Q_MODE == "3" else "512"))   # most workgroups of a grouped level
+_TILE_Q_CONFIGURED = [False]
 
 
 def tile_q_supported(d):
-    return _TILE_Q and bool(lib().ssa_conv2d_tile_q_supported(ctypes.byref(d)))
+    if not _TILE_Q:
+        return False
+    if _TILE_Q_MODE == "3" and not _TILE_Q_CONFIGURED[0]:
+        check(lib().ssa_conv_tile_q_config(1), "ssa_conv_tile_q_config")
+        _TILE_Q_CONFIGURED[0] = True
+    return bool(lib().ssa_conv2d_tile_q_supported(ctypes.byref(d)))
 
 
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs

@@ -8,6 +8,7 @@ Same tolerance as tests/test_kernels_gpu.py (16-bit operands rounded before both
 rounding of the output): max error <= 1e-2 max|ref|, mean error <= 4e-3 mean|ref|.  Runs on the CPU emulation of
 the kernels under SSA_EMU=1 (tests/test_emu_selected_cpu.py runs a selection in the default CPU suite)."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -24,12 +25,20 @@ def _hb():
     return hip_backend
 
 
+# SSA_TILE_Q_THREE=1: the same tests on the three-workgroups-per-CU form of the kernel (ssa_conv_tile_q_config(1): filter
+# in three stages through two 15 KB buffers, pb <= 2) -- run on the CPU emulation by tests/test_emu_selected_cpu.py; the
+# form has not been on the device yet, so the GPU suite does not select it
+THREE = os.environ.get("SSA_TILE_Q_THREE", "0") == "1"
+
+
 @pytest.fixture(autouse=True)
 def _q_on(monkeypatch):
     hb = _hb()
     monkeypatch.setattr(hb, "_TILE_Q", True)
     hb.clear_pack_cache()
+    hb.lib().ssa_conv_tile_q_config(1 if THREE else 0)
     yield
+    hb.lib().ssa_conv_tile_q_config(0)
     hb.clear_pack_cache()
 
 
@@ -211,6 +220,8 @@ def test_q_forced_wave_shapes(monkeypatch, pb, C, B, H, W):
     """SSA_TILE_Q_PB (read per launch) forces the wave shape: 16 x 16-pixel tiles (pb = 4) and 16 x 4 (pb = 1) on the
     problems that run at pb = 2 by default; forward + statistics, and the fused-sums data gradient (pb = 4 is not
     compiled for aux_mode 2: it runs at 2)."""
+    if THREE and pb == 4:
+        pytest.skip("the three-per-CU form runs at pb <= 2")
     monkeypatch.setenv("SSA_TILE_Q_PB", str(pb))
     hb = _hb()
     x = _rand(B, C, H, W, seed=71)

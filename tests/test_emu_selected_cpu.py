@@ -26,9 +26,23 @@ SELECTION = [
 ]
 
 
+# (file, -k expression, extra environment): the three-workgroups-per-CU form of csrc/conv_tile_q.hip (not yet run on the
+# device: ssa_conv_tile_q_config(1)) through the same test file
+SELECTION_ENV = [
+    ("tests/test_conv_tile_q_gpu.py", "48-1-16-16 or 48-2-21-37 or 96-1-7-19 or 192-1-11-18 or 384-1-4-16 or grouped or strips",
+     {"SSA_TILE_Q_THREE": "1"}),
+]
+
+
 def test_selected_kernel_tests_pass_on_the_emulated_kernels():
     env = dict(os.environ, SSA_EMU="1")
     env.pop("PYTEST_CURRENT_TEST", None)
+    for path, expr, extra in SELECTION_ENV:
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, path), "-q", "-x", "-m", "gpu", "-k", expr,
+                            "-p", "no:cacheprovider"], cwd=ROOT, env=dict(env, **extra), capture_output=True, text=True, timeout=900)
+        tail = "\n".join(r.stdout.splitlines()[-15:])
+        assert r.returncode == 0, "%s -k %r under SSA_EMU=1 %r:\n%s\n%s" % (path, expr, extra, tail, r.stderr[-2000:])
+        assert " passed" in tail and "failed" not in tail, tail
     for path, expr in SELECTION:
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, path), "-q", "-x", "-m", "gpu", "-k", expr,
                             "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

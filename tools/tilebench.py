@@ -169,7 +169,9 @@ def main_q():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
     level = [(48, 256, 256), (48, 128, 128), (96, 128, 128), (96, 64, 64), (192, 64, 64), (192, 32, 32), (384, 32, 32), (384, 16, 16)]
     probs = [Prob(C, H, W, i) for i, (C, H, W) in enumerate(level)]
-    print("wave shapes forced: SSA_TILE_Q_PB=%s" % os.environ.get("SSA_TILE_Q_PB", "-"))
+    three = "--three" in sys.argv          # the three-workgroups-per-CU form (ssa_conv_tile_q_config(1))
+    L.ssa_conv_tile_q_config(1 if three else 0)
+    print("wave shapes forced: SSA_TILE_Q_PB=%s; three workgroups per CU: %s" % (os.environ.get("SSA_TILE_Q_PB", "-"), three))
     print("%-16s %8s | %-44s | max |q - p| / max |p|" % ("problem", "p us", "q us by budget: auto " + " ".join("%6d" % b for b in (8, 16, 32, 64))))
     for p in probs:
         p.new()
