@@ -148,26 +148,6 @@ int ssa_conv_tile_strip(int units);
 int ssa_conv2d_tile_p(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias, void* y,
                       double* stats, const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
 
-/* The 48-channel-block geometry of the same convs (csrc/conv_tile_q.hip; opt-in: the host glue uses it under
- * SSA_TILE_Q=1): a wave computes (pb x 16 pixels) x 48 output channels with v_mfma_f32_16x16x32 (pb = 4 / 2 / 1 chosen
- * per problem from the channel count, one kernel for all), K flattened over (tap, channel) of 48-channel chunks, the
- * filter in two 21 KB stages per chunk through a ring of two LDS buffers, epilogue pieces completed with
- * v_permlane16_swap; two workgroups per CU.  Cin in {48, 96, 192, 384}, Cout % 48 == 0, no bias.  w_frag:
- * ssa_pack_filter mode 2 + 8 (forward) / 3 + 8 (data gradient): [Cout / 48][Cin / 48][14][3][64 lanes][8], see
- * frag_offset in csrc/conv_igemm.hip.  stats / aux / aux_mode / coef as ssa_conv2d_tile_aux.
- * ssa_conv_tile_q_strip(budget): MFMAs per wave (in units of 42) a workgroup of the calling thread's NEXT launches
- * should carry, 0 = derive from each problem alone; ssa_conv_tile_q_wgs: the workgroups a problem launches at a budget
- * and aux_mode (aux_mode 2 runs at pb <= 2) -- for the caller that sizes a grouped level.                                                                      */
-/* ssa_conv_tile_q_config(1): the three-workgroups-per-CU form of the kernel (filter in three stages through two 15 KB
- * buffers, pb <= 2, <= 168 registers; process-wide, set before the first launch; 0 = the default form).  Checked on
- * the CPU emulation only so far.                                                                                    */
-int ssa_conv_tile_q_config(int three_per_cu);
-int ssa_conv2d_tile_q_supported(const ssa_conv_desc* d);
-int ssa_conv_tile_q_strip(int budget);
-int ssa_conv_tile_q_wgs(const ssa_conv_desc* d, int budget, int aux_mode);
-int ssa_conv2d_tile_q(const ssa_conv_desc* d, const void* x, const void* w_frag, void* y, double* stats,
-                      const void* aux, int ldaux, const float* coef, int aux_mode, void* stream);
-
 /* Halo-chunk implicit GEMM for the large-channel 3x3 / 1x1 stride-1 "same" convs
  * of the OCR and attention heads (Cin >= 192, Cin % 48 == 0 or % 64 == 0):
  * 256-pixel x 128-channel workgroup tiles, the input halo tile of each 48/64

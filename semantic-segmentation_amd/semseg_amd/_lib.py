@@ -88,11 +88,6 @@ _SIGS = {
     "ssa_conv2d_tile_p_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv_tile_strip": ([c_int], c_int),
     "ssa_conv2d_tile_p": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
-    "ssa_conv2d_tile_q_supported": ([POINTER(ConvDesc)], c_int),
-    "ssa_conv_tile_q_strip": ([c_int], c_int),
-    "ssa_conv_tile_q_config": ([c_int], c_int),
-    "ssa_conv_tile_q_wgs": ([POINTER(ConvDesc), c_int, c_int], c_int),
-    "ssa_conv2d_tile_q": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_int, _P], c_int),
     "ssa_conv2d_halo_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),

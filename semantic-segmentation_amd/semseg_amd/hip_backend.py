@@ -533,7 +533,7 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     return y
 
 
-def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0, q=False):
+def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0):
     """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs; aux = fused epilogue tile of
     the data gradient, see ssa_conv2d_tile_aux) or conv_halo_gemm.hip (large-channel 3x3 / 1x1)."""
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
@@ -542,10 +542,7 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
     _note(2.0 * P * d.Cout * d.Cin * d.KH * d.KW,
           _conv_bytes(P, d.Cin, P, d.Cout, (d.KH, d.KW), 4 if d.out_f32 else 2) + (2.0 * P * d.Cout if mode else 0.0))
     L = lib()
-    if q:
-        check(L.ssa_conv2d_tile_q(ctypes.byref(d), _p(x), _p(wfrag), _p(y), _p(stats), _p(aux), ldaux, _p(coef), mode,
-                                  _s()), "ssa_conv2d_tile_q")
-    elif not halo and bias is None and tile_p_supported(d):
+    if not halo and bias is None and tile_p_supported(d):
         check(L.ssa_conv2d_tile_p(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats),
                                   _p(aux), ldaux, _p(coef), mode, _s()), "ssa_conv2d_tile_p")
     elif mode:
@@ -560,24 +557,6 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
 
 def _tile_conv_aux(d, x, wfrag, stats, aux, ldaux, coef, mode):
     return _tile_conv(d, x, wfrag, None, stats, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
-
-
-# ---- 48-channel-block geometry of the trunk conv (csrc/conv_tile_q.hip): opt-in until it has been measured
-# SSA_TILE_Q=1: two workgroups per CU (measured); =3: the three-per-CU form (ssa_conv_tile_q_config(1);
-# checked on the CPU emulation, first device numbers in profiles/r04_notes.md)
-_TILE_Q_MODE = os.environ.get("SSA_TILE_Q", "0")
-_TILE_Q = _TILE_Q_MODE in ("1", "3")
-_TILE_Q_WGS = int(os.environ.get("SSA_TILE_Q_WGS", "768" if _TILE_Q_MODE == "3" else "512"))   # most workgroups of a grouped level
-_TILE_Q_CONFIGURED = [False]
-
-
-def tile_q_supported(d):
-    if not _TILE_Q:
-        return False
-    if _TILE_Q_MODE == "3" and not _TILE_Q_CONFIGURED[0]:
-        check(lib().ssa_conv_tile_q_config(1), "ssa_conv_tile_q_config")
-        _TILE_Q_CONFIGURED[0] = True
-    return bool(lib().ssa_conv2d_tile_q_supported(ctypes.byref(d)))
 
 
 # ---- persistent halo-tile kernel (csrc/conv_tile_p.hip): the trunk's 48/96/192/384-channel 3x3 convs
@@ -606,21 +585,6 @@ def tile_strip(descs, mode=0):
     not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (three per CU;
     a level of more workgroups than slots runs as two rounds: profiles/r03_notes.md call D, r04_notes.md call C).
     Handed to the library for the launches issued inside the bracket (same thread)."""
-    dq = [d for d in descs if tile_q_supported(d)]
-    if dq:
-        # the same for the opt-in geometry: the smallest MFMA budget per workgroup whose workgroups fit two per CU
-        L = lib()
-        budget = 256
-        for b in range(4, 260, 4):
-            if sum(L.ssa_conv_tile_q_wgs(ctypes.byref(d), b, mode) for d in dq) <= _TILE_Q_WGS:
-                budget = b
-                break
-        L.ssa_conv_tile_q_strip(budget)
-        try:
-            yield
-        finally:
-            L.ssa_conv_tile_q_strip(0)
-        return
     ds = [d for d in descs if tile_p_supported(d)]
     if not ds:
         yield
@@ -661,10 +625,7 @@ def _conv_fwd(x, ldx, weight, b, stride, pad, dil, out_f32, want_stats):
     stats = None
     if want_stats and not out_f32 and not (_NO_IGEMM_STATS and not (use_tile or use_halo)):
         stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-    if use_tile and b is None and tile_q_supported(td):
-        wp, _ = _packed_filter(weight, 10, Cin, 0)
-        y = _tile_conv(td, x, wp, None, stats, q=True)
-    elif use_tile or use_halo:
+    if use_tile or use_halo:
         wp, _ = _packed_filter(weight, 2, Cin, 0)
         y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
     else:
@@ -697,9 +658,6 @@ def _conv_dgrad(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw, 
     use_halo = (not use_tile) and al and halo_supported(td)
     if mode:
         assert use_tile
-    if use_tile and tile_q_supported(td):
-        wpt, _ = _packed_filter(weight, 11, 0, cout_pad)
-        return _tile_conv(td, dyb, wpt, None, stats, aux=aux, ldaux=ldaux, coef=coef, mode=mode, q=True)
     if use_tile or use_halo:
         wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
         return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode)

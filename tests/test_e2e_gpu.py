@@ -202,9 +202,22 @@ def test_eval_nscale(setup):
     from semseg_amd.config import cfg
     from oracle_backend import OracleBackend
     from bf16_emu_backend import Bf16EmuBackend
-    sd, images, gts = setup
-    images = images[:1, :, :128, :192].contiguous()
+    from semseg_amd.loss import RMILoss as _RMI
+    from semseg_amd.network import ocrnet as _ocrnet
+    from test_parity_eval_gpu import _image, calibrate_eval_bn
+    sd, _, gts = setup
+    # A photograph-like (1/f) image and BatchNorm buffers calibrated over exactly the three passes under test
+    # (tests/test_parity_eval_gpu.py::calibrate_eval_bn): with white noise and the fixture's two-scale statistics the
+    # three passes sit at different activation levels and the attention logits are ill-conditioned (round-4 review).
+    images = _image(128, 192, 78)
     gts = gts[:1, :128, :192].contiguous()
+    cfg.MODEL.N_SCALES = [0.5, 1.0, 2.0]
+    try:
+        cal = _ocrnet.HRNet_Mscale(19, _RMI(num_classes=19, ignore_index=255))
+        cal.load_state_dict(sd)
+        sd = {k: v.clone() for k, v in calibrate_eval_bn(cal, images, "cpu").state_dict().items()}
+    finally:
+        cfg.MODEL.N_SCALES = None
 
     def run(backend, device):
         from semseg_amd.loss import RMILoss
@@ -225,18 +238,20 @@ def test_eval_nscale(setup):
 
     ref, emu, hip = run(OracleBackend(), "cpu"), run(Bf16EmuBackend(), "cpu"), run(ops.HipBackend(), "cuda")
     assert set(hip) == set(ref) and "pred_2.0x" in hip and "attn_0.5x" in hip
-    # The attention logits of the three passes are the ill-conditioned outputs of this random-weight network: WHICH
-    # pass amplifies the storage noise differs between two noisy runs (fp16 emulation: 0.012 / 0.043 for the 0.5x / 1.0x
-    # pass, the HIP path 0.052 / 0.041 -- while every op of that run holds one-rounding tolerance teacher-forced,
-    # tests/test_parity_eval_gpu.py::test_eval_mscale_three_scales_small).  The bound of an output is therefore 1.5 x
-    # the LARGEST emulation error among the outputs of its kind (attention maps; predictions, which blend them).
+    # Bound of an output: 1.5 x the storage emulation's own error on it + 5e-3.  The fp16 build alone keeps round 4's
+    # wider bound (1.5 x the LARGEST emulation error among the attention maps, for the attention maps and the
+    # prediction that blends them): its errors are 10x smaller, so which pass's attention conv amplifies them differs
+    # between two noisy runs (0.012 / 0.043 in the emulation, 0.052 / 0.041 on the device, every op teacher-forced
+    # within one rounding: test_eval_mscale_three_scales_small on the fp16 build).
+    from util import ACT_DTYPE
     ee_all = {k: _rel(emu[k], ref[k]) for k in ref}
     worst_attn = max(v for k, v in ee_all.items() if k.startswith("attn"))
     for k in sorted(ref):
         eh, ee = _rel(hip[k], ref[k]), ee_all[k]
         print("nscale %-10s rel err hip %.4f emu %.4f" % (k, eh, ee))
         assert torch.isfinite(hip[k]).all() and hip[k].shape == ref[k].shape
-        bound = 1.5 * max(ee, worst_attn if (k.startswith("attn") or k == "pred") else ee) + 5e-3
+        wide = ACT_DTYPE == torch.float16 and (k.startswith("attn") or k == "pred")
+        bound = 1.5 * max(ee, worst_attn if wide else ee) + 5e-3
         assert eh <= bound, (k, eh, ee, bound)
 
 

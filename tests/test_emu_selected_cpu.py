@@ -19,19 +19,10 @@ SELECTION = [
     ("tests/test_kernels_gpu.py", "probe or bn_train or bn_eval or bn_deferred or bilinear or maxpool or conv_channel_slice"),
     ("tests/test_kernels_gpu.py", "test_conv_fwd_bwd and (case1] or case10] or case19] or case32] or case33])"),
     ("tests/test_group_gpu.py", "upsample_cat"),
-    # the opt-in trunk-conv geometry (csrc/conv_tile_q.hip): lane maps, filter layout, one case per wave shape, the fused
-    # data-gradient epilogues against the default kernel, a grouped level of mixed wave shapes
-    ("tests/test_conv_tile_q_gpu.py", "probe or layout or 48-1-16-16 or 96-1-7-19 or 192-1-8-16 or 384-1-4-16 or grouped or "
-                                      "(forced and 48-1-21-37)"),
 ]
 
 
-# (file, -k expression, extra environment): the three-workgroups-per-CU form of csrc/conv_tile_q.hip (not yet run on the
-# device: ssa_conv_tile_q_config(1)) through the same test file
-SELECTION_ENV = [
-    ("tests/test_conv_tile_q_gpu.py", "48-1-16-16 or 48-2-21-37 or 96-1-7-19 or 192-1-11-18 or 384-1-4-16 or grouped or strips",
-     {"SSA_TILE_Q_THREE": "1"}),
-]
+SELECTION_ENV = []     # (file, -k expression, extra environment)
 
 
 def test_selected_kernel_tests_pass_on_the_emulated_kernels():

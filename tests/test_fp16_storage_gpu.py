@@ -50,12 +50,12 @@ def test_eval_end_to_end_on_the_fp16_build():
 @pytest.mark.gpu
 def test_eval_teacher_forced_on_the_fp16_build():
     """Teacher-forced evaluation, op by op at one-rounding tolerance, on the fp16 build: the hierarchical {0.5, 1, 2}
-    evaluation at 128 x 192 (135 ops, 859 comparisons).
-    OPEN (profiles/r04_notes.md, call S2): at BASELINE configs[1]'s 1 x 3 x 1024 x 2048 the fp16 build passes 276 of 277
-    comparisons; `ocr_attention` [1,256,512,256] has isolated elements 2.98e-2 of max|ref| off (mean error 2.5e-7, bound
-    2e-2; the bf16 build: 6e-3), not reproduced with synthetic operands of any magnitude (tools/debug_ocr_attn.py:
-    <= 7e-4).  Until that is understood the full-size case is not part of the fp16 claim."""
-    _run(["tests/test_parity_eval_gpu.py", "-k", "three_scales_small"], "fp16_eval_parity.log", 900)
+    evaluation at 128 x 192 (135 ops, 859 comparisons) and BASELINE configs[1] at 1 x 3 x 1024 x 2048 (277 comparisons).
+    Round 4 left the full-size case out: `ocr_attention` showed isolated elements 3e-2 off.  That was the TEST's regime,
+    not the kernel (round-4 review): uncalibrated BatchNorm buffers drove q.k^T to 1e8, the softmax was one-hot at every
+    pixel and fp32 summation order picked the row of V.  With calibrated buffers (calibrate_eval_bn) the harness asserts
+    the operand ranges and the op holds the one-rounding bound."""
+    _run(["tests/test_parity_eval_gpu.py", "-k", "three_scales_small or single_scale_1024x2048"], "fp16_eval_parity.log", 900)
 
 
 @pytest.mark.gpu

@@ -54,8 +54,6 @@ def test_grouped_launch_is_bit_identical_to_single_launches(level):
         flat += [x, w, None]
     for (C, H, W), w in zip(level, ws):
         hb._packed_filter(w, 2, C, 0)             # warm the filter cache: only conv launches are counted below
-        if hb._TILE_Q and C % 48 == 0:
-            hb._packed_filter(w, 10, C, 0)        # (the opt-in geometry's fragment order)
     lib().ssa_launch_count(1)
     grouped = hb.ConvGroupFn.apply(spec, *flat)
     n_grouped = lib().ssa_launch_count(1)

@@ -42,8 +42,6 @@ class DryLib:
             self.calls[name] += 1
             if name == "ssa_conv2d_tile_p":          # the persistent trunk conv: which epilogue it carried
                 self.calls["ssa_conv2d_tile_p:aux%d" % args[9]] += 1
-            if name == "ssa_conv2d_tile_q":          # its opt-in 48-channel-block geometry
-                self.calls["ssa_conv2d_tile_q:aux%d" % args[8]] += 1
             return 0
         return launch
 
@@ -211,32 +209,6 @@ def test_lockstep_grouping_and_gradient_arena_glue(dry):
         out = net({"images": inputs["images"]})
     assert tuple(out["pred"].shape) == (2, 19, 128, 128)
     assert not hip_backend._WGRAD_Q
-
-
-@pytest.mark.parametrize("mode", ["1", "3"])
-def test_opt_in_trunk_conv_geometry_glue(dry, monkeypatch, mode):
-    """SSA_TILE_Q=1 / 3: the trunk's 3x3 convs (forward, data gradient with both fused epilogues) go to
-    ssa_conv2d_tile_q with filters packed in its fragment order (ssa_pack_filter mode 2 / 3 + 8), the level's workgroup
-    budget is handed to ssa_conv_tile_q_strip, the three-per-CU form is configured once -- and nothing of them goes to
-    the default kernel any more, except the images narrower than 16 pixels and the one data gradient whose output
-    width is not a multiple of 48 (transition1[0], 256 -> 48 channels: its data gradient is a 48 -> 256 conv)."""
-    from semseg_amd import hip_backend
-    monkeypatch.setattr(hip_backend, "_TILE_Q", True)
-    monkeypatch.setattr(hip_backend, "_TILE_Q_MODE", mode)
-    monkeypatch.setattr(hip_backend, "_TILE_Q_CONFIGURED", [False])
-    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
-    inputs = _batch(2, 128, 128)
-    net(inputs).backward()
-    c = dry.calls
-    n_basic = sum(1 for m in net.modules() if type(m).__name__ == "BasicBlock")
-    q_aux = c["ssa_conv2d_tile_q:aux1"] + c["ssa_conv2d_tile_q:aux2"]
-    p_aux = sum(v for k, v in c.items() if k.startswith("ssa_conv2d_tile_p:") and not k.endswith("aux0"))
-    assert q_aux + p_aux + c["ssa_conv2d_tile_aux"] == 2 * 2 * n_basic, dict(c)
-    assert q_aux > 0 and c["ssa_conv2d_tile_q:aux0"] > 0 and c["ssa_conv_tile_q_strip"] > 0
-    assert p_aux == 0 and c["ssa_conv2d_tile_p"] == 2, "a 3x3 trunk conv went to the default kernel"   # one per scale pass
-    assert c["ssa_conv_tile_q_config"] == (1 if mode == "3" else 0)
-    for n, p in net.named_parameters():
-        assert p.grad is not None and p.grad.shape == p.shape, n
 
 
 def _dist_worker(rank, world, port, q):

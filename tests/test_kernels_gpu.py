@@ -45,6 +45,38 @@ def test_probe_mfma32(out_dir):
     check_close("mfma32", c_d, a @ b, 1e-5, 1e-5)
 
 
+def test_probe_mfma16():
+    """Lane map of v_mfma_f32_16x16x32 (csrc/common.h ssa_mfma16): A rows / B columns l & 15, k = 8 * (l >> 4) + j;
+    accumulator column l & 15, rows 4 * (l >> 4) + j."""
+    import ctypes
+    from semseg_amd._lib import lib, check
+    a = _rand(16, 32, seed=1)
+    b = _rand(32, 16, seed=2)       # asymmetric on purpose
+    a_d = a.to(DEV).to(ACT_DTYPE).contiguous()
+    bt_d = b.t().contiguous().to(DEV).to(ACT_DTYPE)
+    c_d = torch.zeros(16, 16, device=DEV)
+    check(lib().ssa_probe_mfma16(ctypes.c_void_p(a_d.data_ptr()), ctypes.c_void_p(bt_d.data_ptr()),
+                                 ctypes.c_void_p(c_d.data_ptr()), None), "probe")
+    torch.cuda.synchronize()
+    check_close("mfma16", c_d, a @ b, 1e-5, 1e-5)
+
+
+def test_probe_swap16():
+    """v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second."""
+    import ctypes
+    from semseg_amd._lib import lib, check
+    out = torch.zeros(64, 2, dtype=torch.int32, device=DEV)
+    check(lib().ssa_probe_swap16(ctypes.c_void_p(out.data_ptr()), None), "probe")
+    torch.cuda.synchronize()
+    want = []
+    for l in range(64):
+        if (l >> 4) & 1 == 0:
+            want.append((l, l ^ 16))                  # (own a, partner's a)
+        else:
+            want.append(((l ^ 16) + 100, l + 100))    # (partner's b, own b)
+    assert out.cpu().tolist() == [list(t) for t in want]
+
+
 def test_probe_tr16(out_dir):
     from semseg_amd._lib import lib, check
     import ctypes
