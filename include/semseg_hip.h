@@ -439,6 +439,20 @@ int ssa_softmax_lastdim_bwd(const float* sim, int ld, long P, int K, float scale
 int ssa_pack_matrix(const void* src, int src_dtype, int R, int C, int ld,
                     int transpose, void* dst, int rows_out, int Kpad, void* stream);
 
+/* Fused object attention (network/ocr_utils.py:100-113; csrc/ocr_attn.hip): out[p, :] = softmax_K(scale * q[p, :] k^T) v
+ * per image, one launch, sim / probs never leave the registers.  q: [P] pixel rows of Dch = 256 16-bit channels with
+ * pixel stride ldq, k / v: dense [K][256] 16-bit, out: [P] rows with stride ldo.  K <= 96 object regions
+ * (ssa_ocr_attn_supported; otherwise the caller runs the three-launch form on ssa_conv2d_igemm +
+ * ssa_softmax_lastdim_*).  Group-aware (the scale passes of a step share one launch).
+ * Backward: dq, and the two [P][Kpad] 16-bit matrices (Kpad = K rounded up to 32, padding = 0) the pixel reductions
+ * dv = probs^T dout and dk = dsim^T q are computed from (ssa_conv2d_wgrad with KH = KW = 1):
+ * probs = the forward's probabilities, dsim = scale * probs * (dprobs - <probs, dprobs>), dprobs = dout v^T.          */
+int ssa_ocr_attn_supported(int K, int Dch);
+int ssa_ocr_attn_fwd(const void* q, int ldq, const void* k, const void* v, long P, int K, int Dch, float scale,
+                     void* out, int ldo, void* stream);
+int ssa_ocr_attn_bwd(const void* q, int ldq, const void* k, const void* v, const void* dout, int lddo, long P, int K,
+                     int Dch, float scale, void* dq, int lddq, void* probs, void* dsim, void* stream);
+
 /* ----------------------------------------------------- scale attention -----
  * sigmoid of the attention logit (network/utils.py:363) and the two-scale
  * fusion of MscaleOCR.two_scale_forward, network/ocrnet.py:289-298 (K11):

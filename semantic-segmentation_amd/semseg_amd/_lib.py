@@ -139,6 +139,9 @@ _SIGS = {
     "ssa_softmax_lastdim_fwd": ([_P, c_int, c_long, c_int, c_float, _P, c_int, _P], c_int),
     "ssa_softmax_lastdim_bwd": ([_P, c_int, c_long, c_int, c_float, _P, c_int, _P, c_int, _P], c_int),
     "ssa_pack_matrix": ([_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P], c_int),
+    "ssa_ocr_attn_supported": ([c_int, c_int], c_int),
+    "ssa_ocr_attn_fwd": ([_P, c_int, _P, _P, c_long, c_int, c_int, c_float, _P, c_int, _P], c_int),
+    "ssa_ocr_attn_bwd": ([_P, c_int, _P, _P, _P, c_int, c_long, c_int, c_int, c_float, _P, c_int, _P, _P, _P], c_int),
     "ssa_sigmoid_fwd": ([_P, _P, c_long, _P], c_int),
     "ssa_sigmoid_bwd": ([_P, _P, _P, c_long, _P], c_int),
     "ssa_bcast_mul_fwd": ([_P, _P, _P, c_long, c_int, _P], c_int),

@@ -746,6 +746,9 @@ def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, di
 
 
 _WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
+# workgroup slots a weight-gradient launch is fitted to: 512 = two 64 KB workgroups per CU (the whole chip);
+# 256 = one per CU, which leaves every CU 96 KB of LDS and half its registers for the main stream's kernels
+_WGRAD_SLOTS = int(os.environ.get("SSA_WGRAD_SLOTS", "512"))
 
 
 def _fit_tile_strips(jobs, strip):
@@ -769,9 +772,9 @@ def _fit_tile_strips(jobs, strip):
         for i in range(0, len(lst), 16):
             chunk = lst[i:i + 16]
             best = None
-            for s_ in range(strip, 2 * strip + 1):
+            for s_ in range(strip, (2 if _WGRAD_SLOTS >= 512 else 6) * strip + 1):
                 wgs = sum(-(-t // s_) * p for _, t, p in chunk)
-                cost = -(-wgs // 512) * (s_ + 2.0)
+                cost = -(-wgs // _WGRAD_SLOTS) * (s_ + 2.0)
                 if best is None or cost < best[0] - 1e-9:
                     best = (cost, s_)
             for j, _, _ in chunk:
@@ -848,7 +851,7 @@ _SINCE_REDUCE = [0]        # layers flushed since the gradient sink was last han
 
 def _side_stream():
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
+        _SIDE["stream"] = torch.cuda.Stream(priority=int(os.environ.get("SSA_WGRAD_PRIO", "0")))
     return _SIDE["stream"]
 
 
@@ -1785,8 +1788,14 @@ class OcrGatherFn(torch.autograd.Function):
         return dfeats, dlogits
 
 
+_OCR_ATTN_FUSED = os.environ.get("SSA_OCR_ATTN_FUSED", "1") != "0"     # 0: the three-launch form (debugging)
+
+
 class OcrAttnFn(torch.autograd.Function):
-    """out = softmax_k(scale * q k^T) v per image.  q [B,H,W,D] bf16; k,v [B,K,D] bf16."""
+    """out = softmax_k(scale * q k^T) v per image (network/ocr_utils.py:100-113).  q [B,H,W,D] 16 bit; k,v [B,K,D].
+    One launch per image (csrc/ocr_attn.hip: sim and probs stay in registers); backward = one launch for dq plus the
+    two pixel reductions dv = probs^T dout, dk = dsim^T q on the weight-gradient kernel.  More than 96 object regions
+    or D != 256: matmul -> softmax -> matmul on the implicit-GEMM kernel with sim (fp32) and probs in HBM."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
@@ -1800,6 +1809,17 @@ class OcrAttnFn(torch.autograd.Function):
         Dp = _roundup(D, 32)
         dev = q.device
         out = torch.empty((B, H, W, D), dtype=ACT_DTYPE, device=dev)
+        fused = _OCR_ATTN_FUSED and bool(L.ssa_ocr_attn_supported(K, D)) and ldq % 8 == 0 and q.data_ptr() % 16 == 0
+        if fused:
+            k = k if k.dtype == ACT_DTYPE else k.to(ACT_DTYPE)
+            v = v if v.dtype == ACT_DTYPE else v.to(ACT_DTYPE)
+            for b in range(B):
+                _note(4.0 * H * W * K * D, 2.0 * H * W * 2 * D + 4.0 * K * D)
+                check(L.ssa_ocr_attn_fwd(_p(q[b]), ldq, _p(k[b]), _p(v[b]), H * W, K, D, float(scale), _p(out[b]), D, _s()),
+                      "ssa_ocr_attn_fwd")
+            ctx.save_for_backward(q, k, v)
+            ctx.meta = (ldq, float(scale), True)
+            return out
         sim = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         for b in range(B):
             wk = _pack_matrix(k[b], K, D, D, False, K, Dp)                 # [K][Dp]
@@ -1810,14 +1830,18 @@ class OcrAttnFn(torch.autograd.Function):
             wv = _pack_matrix(v[b], K, D, D, True, D, Kp)                  # [D][Kp]: v^T
             out[b] = _igemm(probs, Kp, (1, H, W, Kp), wv, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
         ctx.save_for_backward(q, k, v, sim)
-        ctx.meta = (ldq, float(scale))
+        ctx.meta = (ldq, float(scale), False)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         L = lib()
-        q, k, v, sim = ctx.saved_tensors
-        ldq, scale = ctx.meta
+        ldq, scale, fused = ctx.meta
+        if fused:
+            q, k, v = ctx.saved_tensors
+            sim = None
+        else:
+            q, k, v, sim = ctx.saved_tensors
         B, H, W, D = q.shape
         K = k.shape[1]
         Kp = _roundup(K, 32)
@@ -1832,16 +1856,21 @@ class OcrAttnFn(torch.autograd.Function):
         dv = torch.empty((B, K, D), dtype=torch.float32, device=dev)
         for b in range(B):
             probs = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
-            check(L.ssa_softmax_lastdim_fwd(_p(sim[b]), K, HW, K, scale, _p(probs), Kp, _s()),
-                  "ssa_softmax_lastdim_fwd")
-            wv = _pack_matrix(v[b], K, D, D, False, K, Dp)                 # [K][Dp]
-            dprobs = _igemm(dout[b], lddo, (1, H, W, D), wv, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True)
-            dv[b] = _wgrad(dout[b], lddo, (1, H, W, D), probs, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
             dsim = torch.empty((HW, Kp), dtype=ACT_DTYPE, device=dev)
-            check(L.ssa_softmax_lastdim_bwd(_p(sim[b]), K, HW, K, scale, _p(dprobs), K, _p(dsim), Kp, _s()),
-                  "ssa_softmax_lastdim_bwd")
-            wk = _pack_matrix(k[b], K, D, D, True, D, Kp)                  # [D][Kp]: k^T
-            dq[b] = _igemm(dsim, Kp, (1, H, W, Kp), wk, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+            if fused:
+                _note(8.0 * HW * K * D, 2.0 * HW * (3 * D + 2 * Kp) + 4.0 * K * D)
+                check(L.ssa_ocr_attn_bwd(_p(q[b]), ldq, _p(k[b]), _p(v[b]), _p(dout[b]), lddo, HW, K, D, scale,
+                                         _p(dq[b]), D, _p(probs), _p(dsim), _s()), "ssa_ocr_attn_bwd")
+            else:
+                check(L.ssa_softmax_lastdim_fwd(_p(sim[b]), K, HW, K, scale, _p(probs), Kp, _s()),
+                      "ssa_softmax_lastdim_fwd")
+                wv = _pack_matrix(v[b], K, D, D, False, K, Dp)                 # [K][Dp]
+                dprobs = _igemm(dout[b], lddo, (1, H, W, D), wv, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True)
+                check(L.ssa_softmax_lastdim_bwd(_p(sim[b]), K, HW, K, scale, _p(dprobs), K, _p(dsim), Kp, _s()),
+                      "ssa_softmax_lastdim_bwd")
+                wk = _pack_matrix(k[b], K, D, D, True, D, Kp)                  # [D][Kp]: k^T
+                dq[b] = _igemm(dsim, Kp, (1, H, W, Kp), wk, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+            dv[b] = _wgrad(dout[b], lddo, (1, H, W, D), probs, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
             dk[b] = _wgrad(q[b], ldq, (1, H, W, D), dsim, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
         return dq, dk.to(k.dtype), dv.to(v.dtype), None
 

@@ -585,10 +585,16 @@ def test_ocr_gather():
     check_close("gather_dlogits", nchw(ld.grad), lr.grad, 2e-2, 8e-3)
 
 
-def test_ocr_attention():
+@pytest.mark.parametrize("K,H,W,fused", [(19, 20, 24, True), (65, 9, 31, True), (19, 3, 5, True), (96, 8, 16, True),
+                                          (19, 20, 24, False), (150, 6, 11, True)])
+def test_ocr_attention(K, H, W, fused, monkeypatch):
+    """ObjectAttentionBlock's softmax(q k^T / sqrt(256)) v (network/ocr_utils.py:100-113): the fused kernel
+    (csrc/ocr_attn.hip; 19 = Cityscapes, 65 = Mapillary -> 3 region blocks, 96 = its limit, pixel counts that are not
+    multiples of the 128-pixel workgroup tile) and the three-launch form (forced, and what 150 regions fall back to)."""
     from oracle import ops as O
     hb = _hb()
-    B, D, K, H, W = 2, 256, 19, 20, 24
+    monkeypatch.setattr(hb, "_OCR_ATTN_FUSED", fused)
+    B, D = 2, 256
     q = _rand(B, H * W, D, seed=1)
     k = _rand(B, K, D, seed=2)
     v = _rand(B, K, D, seed=3)
@@ -602,7 +608,8 @@ def test_ocr_attention():
     od = hb.OcrAttnFn.apply(qd, kd, vd, D ** -0.5)
     od.backward(g.view(B, H, W, D).to(DEV).to(ACT_DTYPE))
     torch.cuda.synchronize()
-    check_close("attn_fwd", od.float().view(B, H * W, D), out, 2e-2, 8e-3)
+    # one rounding of the output (the probabilities are rounded to 16 bit on both paths before the second product)
+    check_close("attn_fwd", od.float().view(B, H * W, D), out, 1e-2, 4e-3)
     check_close("attn_dq", qd.grad.float().view(B, H * W, D), qr.grad, 3e-2, 1.5e-2)
     check_close("attn_dk", kd.grad.float(), kr.grad, 3e-2, 1.5e-2)
     check_close("attn_dv", vd.grad.float(), vr.grad, 2e-2, 8e-3)

@@ -61,14 +61,33 @@ def calibrate_eval_bn(net, image, device):
     from oracle_backend import OracleBackend
 
     class _Calib(OracleBackend):
+        """Every BatchNorm normalises by the statistics of its own input (what training mode does), computed here with
+        torch.var_mean -- MIOpen's training-mode BatchNorm is not involved (it crashed on the [1, 65, 1, 256] proxy
+        tensors of the Mapillary head) -- and the per-call (n, mean, M2) are merged over the calls (Chan et al.)."""
+
         def __init__(self):
             self.acc = {}
 
         def _batch_norm_act(self, x, bn, residual=None, relu=False, post=None):
-            xd = x.detach().double().flatten(0, 2)
-            n, s, q = self.acc.get(id(bn), (0, 0.0, 0.0))
-            self.acc[id(bn)] = (n + xd.shape[0], s + xd.sum(0), q + (xd * xd).sum(0))
-            return super()._batch_norm_act(x, bn, residual, relu, post)
+            xf = x.detach().float()
+            var, mean = torch.var_mean(xf, dim=(0, 1, 2), unbiased=False)
+            n = xf.numel() // xf.shape[-1]
+            m2 = var.double() * n
+            if id(bn) in self.acc:
+                n0, mean0, m20 = self.acc[id(bn)]
+                d = mean.double() - mean0
+                tot = n0 + n
+                self.acc[id(bn)] = (tot, mean0 + d * (n / tot), m20 + m2 + d * d * (n0 * n / tot))
+            else:
+                self.acc[id(bn)] = (n, mean.double(), m2)
+            y = (xf - mean) * torch.rsqrt(var + bn.eps) * bn.weight.detach().float() + bn.bias.detach().float()
+            if residual is not None:
+                y = y + residual
+            if relu:
+                y = torch.relu(y)
+            if post is not None:
+                y = y * post[:, None, None, :]
+            return y.to(x.dtype)
 
     prev = ops._BACKEND
     cal = _Calib()
@@ -76,15 +95,12 @@ def calibrate_eval_bn(net, image, device):
     bns = [m for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     try:
         net.eval().to(device)
-        for m in bns:
-            m.train()
         with torch.no_grad():
             net({"images": image.to(device)})
             for m in bns:
-                n, s, q = cal.acc[id(m)]
-                mean = s / n
+                n, mean, m2 = cal.acc[id(m)]
                 m.running_mean.copy_(mean)
-                m.running_var.copy_((q / n - mean * mean).clamp_min(0) * (n / max(n - 1, 1)))
+                m.running_var.copy_(m2 / max(n - 1, 1))
     finally:
         net.eval()
         ops._set_backend_for_tests(prev)
@@ -165,18 +181,24 @@ def test_device_oracle_equals_cpu_oracle():
     try:
         net = ocrnet.HRNet(19, None)
         net.load_state_dict(parity_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=0))
-        net.eval()
         img = _image(256, 384, 5)
+        calibrate_eval_bn(net, img, "cpu")          # (the regime of the tests below; it restores the backend it found)
+        net.eval()
         with torch.no_grad():
             a = net({"images": img})["pred"].float()
             b = net.cuda()({"images": img.cuda()})["pred"].float().cpu()
+            t = net.cpu().double()({"images": img.double()})["pred"].float()     # the same operators in fp64: the truth
     finally:
         ops._set_backend_for_tests(prev)
         torch.backends.cudnn.allow_tf32 = tf32
         cfg.MODEL.N_SCALES, cfg.MODEL.BNFUNC = saved
-    err = float((a - b).abs().max() / (a.abs().max() + 1e-30))
-    print("device oracle vs CPU oracle: max |d pred| / max |pred| = %.2e" % err)
-    assert err <= 1e-4, err
+    scale = float(t.abs().max()) + 1e-30
+    e_cpu, e_dev, e_ab = (float((x - y).abs().max()) / scale for x, y in ((a, t), (b, t), (a, b)))
+    print("max |d pred| / max |pred|: CPU fp32 vs fp64 %.2e, device fp32 vs fp64 %.2e, device vs CPU %.2e" % (e_cpu, e_dev, e_ab))
+    # the calibrated random-weight network amplifies a relative perturbation ~100x (measured: 1e-6 on the image ->
+    # 1.3e-4 on pred), so two fp32 runs that differ in summation order sit ~4e-5 from the fp64 result and from each other
+    assert e_dev <= 3.0 * e_cpu + 2e-5, (e_dev, e_cpu)
+    assert e_ab <= 1e-3, e_ab
 
 
 def test_eval_mscale_three_scales_small():
