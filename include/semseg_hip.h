@@ -488,6 +488,10 @@ int ssa_loss_finalize(const double* acc, double denom_add, float* loss, void* st
 /* g[i] *= upstream[0] * coef / (acc[1] + denom_add)                            */
 int ssa_scale_grad(float* g, long n, const float* upstream, double coef,
                    const double* acc, double denom_add, void* stream);
+/* dst[i] = src[i] * upstream[0] * coef / (acc[1] + denom_add): the same without touching src (the un-normalised
+ * gradient the forward saved stays valid; the backward needs no copy of it)       */
+int ssa_scale_grad_to(const float* src, float* dst, long n, const float* upstream, double coef,
+                      const double* acc, double denom_add, void* stream);
 
 /* RMILoss.rmi_lower_bound, loss/rmi.py:139-215 + loss/rmi_utils.py:15-56,
  * 95-107 (K15).  Fused: sigmoid*mask+1e-6 -> 4x4/4 avg pool (pad 2) ->

@@ -133,11 +133,18 @@ __global__ void loss_finalize_kernel(const double* __restrict__ acc, double deno
   loss[0] = (float)(acc[0] / (acc[1] + denom_add));
 }
 
-__global__ void scale_grad_kernel(float* __restrict__ g, long n, const float* __restrict__ upstream,
+// dst = src * upstream * coef / (acc[1] + denom_add)     (src may be dst; otherwise the two do not overlap)
+__global__ void scale_grad_kernel(const float* src, float* dst, long n, const float* __restrict__ upstream,
                                   double coef, const double* __restrict__ acc, double denom_add) {
   const float s = (float)((double)upstream[0] * coef / (acc[1] + denom_add));
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    g[i] *= s;
+  const long n4 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0 ? n >> 2 : 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(src)[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = src[i] * s;
 }
 
 // ------------------------------------------------------------------- RMI
@@ -565,13 +572,18 @@ int ssa_loss_finalize(const double* acc, double denom_add, float* loss, void* st
   return SSA_OK;
 }
 
-int ssa_scale_grad(float* g, long n, const float* upstream, double coef, const double* acc,
-                   double denom_add, void* stream) {
-  if (!g || !upstream || !acc || n <= 0) return SSA_EINVAL;
-  hipLaunchKernelGGL(scale_grad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n,
+int ssa_scale_grad_to(const float* src, float* dst, long n, const float* upstream, double coef, const double* acc,
+                      double denom_add, void* stream) {
+  if (!src || !dst || !upstream || !acc || n <= 0) return SSA_EINVAL;
+  hipLaunchKernelGGL(scale_grad_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
                      upstream, coef, acc, denom_add);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
+}
+
+int ssa_scale_grad(float* g, long n, const float* upstream, double coef, const double* acc,
+                   double denom_add, void* stream) {
+  return ssa_scale_grad_to(g, g, n, upstream, coef, acc, denom_add, stream);
 }
 
 int ssa_rmi_pool(const float* logits, int ld, const int64_t* labels, int B, int H, int W, int C,

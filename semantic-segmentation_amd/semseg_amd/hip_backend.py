@@ -518,11 +518,13 @@ def _conv_bytes(P_in, Cin, P_out, Cout, k, out_bytes=2):
 
 
 def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
-           cfg=-1, stats=None):
-    """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout]."""
+           cfg=-1, stats=None, out=None):
+    """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout] (`out`: a dense tensor of that size to write)."""
     B, H, W, Cin = geom_in
     Ho, Wo = geom_out
-    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE, device=x.device)
+    y = out if out is not None else torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else ACT_DTYPE,
+                                                device=x.device)
+    assert y.is_contiguous() and y.numel() == B * Ho * Wo * Cout
     d = ConvDesc(B, H, W, Cin, ldx, Ho, Wo, Cout, Cout, k[0], k[1], stride, pad, dil, int(transposed),
                  Kpad, int(out_f32), cfg)
     # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
@@ -1774,8 +1776,7 @@ class OcrGatherFn(torch.autograd.Function):
                 check(L.ssa_softmax_hw_probs(_p(logits[b]), ldl, HW, K, _p(rowstat[b]), _p(probs), Kp, _s()),
                       "ssa_softmax_hw_probs")
                 wp = _pack_matrix(dctx[b], K, C, C, True, C, Kp)          # [C][Kp]: dctx^T
-                dfeats[b] = _igemm(probs, Kp, (1, H, W, Kp), wp, Kp, None, (H, W), C, (1, 1), 1, 0, 1, False,
-                                   False)[0]
+                _igemm(probs, Kp, (1, H, W, Kp), wp, Kp, None, (H, W), C, (1, 1), 1, 0, 1, False, False, out=dfeats[b])
             if dlogits is not None:
                 Cp = _roundup(C, 32)
                 wp = _pack_matrix(dctx[b], K, C, C, False, K, Cp)         # [K][Cp]
@@ -1823,12 +1824,12 @@ class OcrAttnFn(torch.autograd.Function):
         sim = torch.empty((B, H, W, K), dtype=torch.float32, device=dev)
         for b in range(B):
             wk = _pack_matrix(k[b], K, D, D, False, K, Dp)                 # [K][Dp]
-            sim[b] = _igemm(q[b], ldq, (1, H, W, D), wk, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True)[0]
+            _igemm(q[b], ldq, (1, H, W, D), wk, Dp, None, (H, W), K, (1, 1), 1, 0, 1, False, True, out=sim[b])
             probs = torch.empty((H * W, Kp), dtype=ACT_DTYPE, device=dev)
             check(L.ssa_softmax_lastdim_fwd(_p(sim[b]), K, H * W, K, float(scale), _p(probs), Kp, _s()),
                   "ssa_softmax_lastdim_fwd")
             wv = _pack_matrix(v[b], K, D, D, True, D, Kp)                  # [D][Kp]: v^T
-            out[b] = _igemm(probs, Kp, (1, H, W, Kp), wv, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+            _igemm(probs, Kp, (1, H, W, Kp), wv, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False, out=out[b])
         ctx.save_for_backward(q, k, v, sim)
         ctx.meta = (ldq, float(scale), False)
         return out
@@ -1869,7 +1870,7 @@ class OcrAttnFn(torch.autograd.Function):
                 check(L.ssa_softmax_lastdim_bwd(_p(sim[b]), K, HW, K, scale, _p(dprobs), K, _p(dsim), Kp, _s()),
                       "ssa_softmax_lastdim_bwd")
                 wk = _pack_matrix(k[b], K, D, D, True, D, Kp)                  # [D][Kp]: k^T
-                dq[b] = _igemm(dsim, Kp, (1, H, W, Kp), wk, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False)[0]
+                _igemm(dsim, Kp, (1, H, W, Kp), wk, Kp, None, (H, W), D, (1, 1), 1, 0, 1, False, False, out=dq[b])
             dv[b] = _wgrad(dout[b], lddo, (1, H, W, D), probs, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
             dk[b] = _wgrad(q[b], ldq, (1, H, W, D), dsim, Kp, Kp, (H, W), (1, 1), 1, 0, 1, K, D).view(K, D)
         return dq, dk.to(k.dtype), dv.to(v.dtype), None
@@ -1997,8 +1998,8 @@ class CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, up):
         dl, acc = ctx.saved_tensors
         up = up.float().contiguous()
-        g = dl.clone()
-        check(lib().ssa_scale_grad(_p(g), g.numel(), _p(up), 1.0, _p(acc), 0.0, _s()), "ssa_scale_grad")
+        g = torch.empty_like(dl)
+        check(lib().ssa_scale_grad_to(_p(dl), _p(g), g.numel(), _p(up), 1.0, _p(acc), 0.0, _s()), "ssa_scale_grad_to")
         return g, None, None
 
 
@@ -2046,14 +2047,14 @@ class BceRmiFn(torch.autograd.Function):
         up = up.float().contiguous()
         if not ctx.do_rmi:
             dl, acc = ctx.saved_tensors
-            g = dl.clone()
-            check(L.ssa_scale_grad(_p(g), g.numel(), _p(up), 1.0, _p(acc), 1.0, _s()), "ssa_scale_grad")
+            g = torch.empty_like(dl)
+            check(L.ssa_scale_grad_to(_p(dl), _p(g), g.numel(), _p(up), 1.0, _p(acc), 1.0, _s()), "ssa_scale_grad_to")
             return g, None, None, None
         dl, acc, logits, labels, ppr, pla, gmat = ctx.saved_tensors
         B, H, W, C = logits.shape
         Hp, Wp = ppr.shape[1], ppr.shape[2]
-        g = dl.clone()
-        check(L.ssa_scale_grad(_p(g), g.numel(), _p(up), ctx.lam, _p(acc), 1.0, _s()), "ssa_scale_grad")
+        g = torch.empty_like(dl)
+        check(L.ssa_scale_grad_to(_p(dl), _p(g), g.numel(), _p(up), ctx.lam, _p(acc), 1.0, _s()), "ssa_scale_grad_to")
         dpool = torch.empty_like(ppr)
         check(L.ssa_rmi_bwd_pooled(_p(ppr), _p(pla), _p(gmat), B * C, Hp, Wp, _p(dpool), _s()), "ssa_rmi_bwd_pooled")
         coef = (1.0 - ctx.lam) / (9.0 * B)
