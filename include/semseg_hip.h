@@ -289,7 +289,11 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
                        const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long* num_batches_tracked, float momentum,
                        float eps, float* coef, float* pass_stats, int relu,
-                       const float* post, long pix_per_img, void* stream);
+                       const float* post, long pix_per_img, void* sign_mask, void* stream);
+/* sign_mask (optional, [P][C/8] bytes): bit j of byte (p, g) = z[p][8g + j] > 0 as stored.  Handed to the two
+ * backward passes below in place of z: behind a residual add the ReLU mask cannot be recomputed from x alone
+ * (mask_scale / mask_shift), and reading 1 byte instead of 16 per piece takes 28 MB off the 118 MB a trunk
+ * level's bn2 backward moves.                                                                               */
 typedef struct ssa_bn_update_job {
   float* running_mean;
   float* running_var;
@@ -323,7 +327,7 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz,
                       const void* z, int ldz, long P, int C, const float* mean,
                       const float* invstd, int relu, const float* post,
                       long pix_per_img, double* sums, int nrep, int zero_sums,
-                      const float* mask_scale, const float* mask_shift, void* stream);
+                      const float* mask_scale, const float* mask_shift, const void* sign_mask, void* stream);
 /* backward pass 2: dx = gamma*invstd*(g - sum_g/N - xhat*sum_gxhat/N);
  * dres (optional) = g.  sums may have been all-reduced; count is global.
  * dgamma/dbeta (optional): = param_grad_scale * sums[C:2C] / sums[0:C]
@@ -337,7 +341,7 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      int nrep, double count, int relu, const float* post,
                      long pix_per_img, float* dgamma, float* dbeta,
                      float param_grad_scale, const float* mask_scale,
-                     const float* mask_shift, int accumulate_param_grads, void* stream);
+                     const float* mask_shift, int accumulate_param_grads, const void* sign_mask, void* stream);
 /* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);

@@ -163,12 +163,27 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (invstd_out) invstd_out[c] = (float)invstd;
 }
 
-// z = post * act(scale * x + shift + residual): the arithmetic shared by the eval and the training apply
+// bit j of the result = element j of a packed 8-element piece is > 0 (as stored: after the rounding to 16 bits)
+__device__ __forceinline__ unsigned positive_bits(const uint4& pk) {
+  const unsigned w[4] = {pk.x, pk.y, pk.z, pk.w};
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lo = w[i] & 0xffffu, hi = w[i] >> 16;
+    m |= (((lo & 0x7fffu) != 0 && !(lo & 0x8000u)) ? 1u : 0u) << (2 * i);
+    m |= (((hi & 0x7fffu) != 0 && !(hi & 0x8000u)) ? 1u : 0u) << (2 * i + 1);
+  }
+  return m;
+}
+
+// z = post * act(scale * x + shift + residual): the arithmetic shared by the eval and the training apply.
+// mrow (training, ReLU behind a residual add): one byte per pixel and 8-channel group, bit j = z_j > 0 -- the
+// backward passes read this byte instead of the 16 bytes of z (the mask is all they want of it).
 template <int ROWS>
 __device__ __forceinline__ void bn_apply_rows(const RowSet<ROWS>& rs, const uint4 (&v)[ROWS], const uint4 (&rv)[ROWS],
                                               bool has_res, const float (&a)[8], const float (&b)[8], int relu,
                                               const float* __restrict__ post, long pix_per_img, long p0, int C, int cg,
-                                              bf16_t* __restrict__ zb, int ldz) {
+                                              bf16_t* __restrict__ zb, int ldz, unsigned char* __restrict__ mrow = nullptr) {
 #pragma unroll
   for (int u = 0; u < ROWS; ++u) {
     float f[8];
@@ -190,7 +205,11 @@ __device__ __forceinline__ void bn_apply_rows(const RowSet<ROWS>& rs, const uint
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] *= pp[j];
     }
-    if ((rs.ok >> u) & 1u) *reinterpret_cast<uint4*>(zb + (long)rs.off[u] * ldz) = pack8(f);
+    if ((rs.ok >> u) & 1u) {
+      const uint4 pk = pack8(f);
+      *reinterpret_cast<uint4*>(zb + (long)rs.off[u] * ldz) = pk;
+      if (mrow) mrow[(long)rs.off[u] * (C >> 3)] = (unsigned char)positive_bits(pk);
+    }
   }
 }
 
@@ -237,7 +256,7 @@ __device__ __forceinline__ void bn_apply_train_body(
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
-    long pix_per_block, const int bx) {
+    long pix_per_block, unsigned char* __restrict__ mask, const int bx) {
   SSA_DYN_LDS(float, sh);                 // [2C]: scale, shift for this launch
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
@@ -293,7 +312,8 @@ __device__ __forceinline__ void bn_apply_train_body(
     b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
   }
   for (long p0 = pb;;) {
-    bn_apply_rows<ROWS>(rs, v, rv, res != nullptr, a, b, relu, post, pix_per_img, p0, C, cg, z + p0 * ldz + cg * 8, ldz);
+    bn_apply_rows<ROWS>(rs, v, rv, res != nullptr, a, b, relu, post, pix_per_img, p0, C, cg, z + p0 * ldz + cg * 8, ldz,
+                        mask ? mask + p0 * VC + cg : nullptr);
     p0 += (long)RP * ROWS;
     if (p0 >= pe) break;
     rs.init(p0, pe, pr, RP, true);
@@ -305,7 +325,7 @@ __device__ __forceinline__ void bn_apply_train_body(
 // masked gradient g = post * dz where the ReLU let it through (mask from z, or recomputed from x)
 __device__ __forceinline__ void bn_bwd_mask(float (&g)[8], const float (&xv)[8], const uint4& zraw, bool use_z, int relu,
                                             bool mask_from_x, const float (&ma)[8], const float (&mb)[8],
-                                            const float* __restrict__ pp) {
+                                            const float* __restrict__ pp, bool use_bits = false, unsigned bits = 0) {
   if (pp) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] *= pp[j];
@@ -313,6 +333,9 @@ __device__ __forceinline__ void bn_bwd_mask(float (&g)[8], const float (&xv)[8],
   if (relu && mask_from_x) {          // z = relu(scale*x + shift), z not read
 #pragma unroll
     for (int j = 0; j < 8; ++j) g[j] = (xv[j] * ma[j] + mb[j]) > 0.f ? g[j] : 0.f;
+  } else if (relu && use_bits) {      // the forward's sign byte (bn_apply_rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
   } else if (relu && use_z) {
     float zv[8];
     unpack8(zraw, zv);
@@ -321,19 +344,28 @@ __device__ __forceinline__ void bn_bwd_mask(float (&g)[8], const float (&xv)[8],
   }
 }
 
+// the sign bytes of a thread's rows (masked rows read the chunk's first pixel, like the data loads)
+template <int ROWS>
+__device__ __forceinline__ void load_sign_bytes(const RowSet<ROWS>& rs, const unsigned char* __restrict__ base, int VC,
+                                                unsigned (&mk)[ROWS]) {
+#pragma unroll
+  for (int u = 0; u < ROWS; ++u) mk[u] = base[(long)rs.off[u] * VC];
+}
+
 template <int ROWS>
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
     const float* __restrict__ invstd, int relu, const float* __restrict__ post, long pix_per_img,
     double* __restrict__ sums, int nrep, long pix_per_block, const float* __restrict__ mscale,
-    const float* __restrict__ mshift, const int bx) {
+    const float* __restrict__ mshift, const unsigned char* __restrict__ mask, const int bx) {
   SSA_DYN_LDS(float, sh);
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
   const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
-  const bool use_z = relu && !mscale;
+  const bool use_bits = relu && !mscale && mask != nullptr;
+  const bool use_z = relu && !mscale && !use_bits;
   float sg[8], sgx[8], mu[8], is[8], ma[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; ma[j] = 0.f; mb[j] = 0.f; }
@@ -344,9 +376,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
     RowSet<ROWS> rs;
     rs.init(p0, pe, pr, RP, active);
     uint4 gv[ROWS], xr[ROWS], zr[ROWS];
+    unsigned mk[ROWS];
     rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
     rs.load(x + p0 * ldx + cg * 8, ldx, xr);
     if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
+    if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk);
     if (!have_coef) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
@@ -362,7 +396,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
       unpack8(gv[u], g);
       unpack8(xr[u], xv);
       const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
-      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp);
+      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp, use_bits, use_bits ? mk[u] : 0u);
       const float keep = ((rs.ok >> u) & 1u) ? 1.f : 0.f;      // masked rows re-read the chunk's first pixel
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -384,22 +418,26 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     const double* __restrict__ sums, int nrep, double count, int relu,
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
-    const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg, const int bx) {
+    const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg,
+    const unsigned char* __restrict__ mask, const int bx) {
   SSA_DYN_LDS(float, sh);                 // [7C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N, mask scale, mask shift
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
   const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
-  const bool use_z = relu && !mscale;
+  const bool use_bits = relu && !mscale && mask != nullptr;
+  const bool use_z = relu && !mscale && !use_bits;
   const long pb = bx * pix_per_block;
   const long pe = min(P, pb + pix_per_block);
   // ---- the first chunk's loads, then the coefficient prologue while they are in flight
   RowSet<ROWS> rs;
   rs.init(pb, pe, pr, RP, active);
   uint4 gv[ROWS], xr[ROWS], zr[ROWS];
+  unsigned mk[ROWS];
   rs.load(dz + pb * lddz + cg * 8, lddz, gv);
   rs.load(x + pb * ldx + cg * 8, ldx, xr);
   if (use_z) rs.load(z + pb * ldz + cg * 8, ldz, zr);
+  if (use_bits) load_sign_bytes<ROWS>(rs, mask + pb * VC + cg, VC, mk);
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     replica_sums(sums, nrep, C, c, &s1, &s2);
@@ -440,7 +478,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
       unpack8(gv[u], g);
       unpack8(xr[u], xv);
       const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
-      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp);
+      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp, use_bits, use_bits ? mk[u] : 0u);
       const bool ok = (rs.ok >> u) & 1u;
       if (dres && ok) *reinterpret_cast<uint4*>(dres + (p0 + rs.off[u]) * lddres + cg * 8) = pack8(g);
       float o[8];
@@ -457,6 +495,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
     rs.load(x + p0 * ldx + cg * 8, ldx, xr);
     if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
+    if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk);
   }
 }
 
@@ -501,24 +540,24 @@ template <int ROWS>
 struct BnApplyTrainK {
   struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const double* sums; const float* gamma;
                 const float* beta; float* running_mean; float* running_var; long* nbt; float* coef;
-                float* pass_stats; const float* post; double count; long P, pix_per_img, ppb;
+                float* pass_stats; const float* post; unsigned char* mask; double count; long P, pix_per_img, ppb;
                 int ldx, ldr, ldz, C, nrep, relu; float momentum, eps; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
     bn_apply_train_body<ROWS>(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.gamma,
                               a.beta, a.running_mean, a.running_var, a.nbt, a.momentum, a.eps, a.coef,
-                              a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, bx);
+                              a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, a.mask, bx);
   }
 };
 template <int ROWS>
 struct BnBwdReduceK {
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
-                const float* post; double* sums; const float* mscale; const float* mshift;
+                const float* post; double* sums; const float* mscale; const float* mshift; const unsigned char* mask;
                 long P, pix_per_img, ppb; int ldx, lddz, ldz, C, relu, nrep; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
     bn_bwd_reduce_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
-                             a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, bx);
+                             a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, a.mask, bx);
   }
 };
 template <int ROWS>
@@ -526,13 +565,13 @@ struct BnBwdApplyK {
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; bf16_t* dx; bf16_t* dres;
                 const float* gamma; const float* mean; const float* invstd; const double* sums;
                 const float* post; float* dgamma; float* dbeta; const float* mscale; const float* mshift;
-                double count; long P, pix_per_img, ppb; int ldx, lddz, ldz, lddx, lddres, C, nrep, relu;
+                const unsigned char* mask; double count; long P, pix_per_img, ppb; int ldx, lddz, ldz, lddx, lddres, C, nrep, relu;
                 float param_grad_scale; int accumulate_pg; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
     bn_bwd_apply_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
                             a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
-                            a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, bx);
+                            a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, a.mask, bx);
   }
 };
 
@@ -655,13 +694,14 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
                        const float* beta, float* running_mean, float* running_var,
                        long* num_batches_tracked, float momentum, float eps, float* coef,
                        float* pass_stats, int relu, const float* post, long pix_per_img,
-                       void* stream) {
+                       void* sign_mask, void* stream) {
   if (!x || !z || !sums || !coef || !ok_c(C) || !ok_p(P) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
   const Grid g = plan_grid(P, C, apply_rows());
   return SSA_BN_SUBMIT(BnApplyTrainK, g, ({(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta,
-                                           running_mean, running_var, num_batches_tracked, coef, pass_stats, post, count,
+                                           running_mean, running_var, num_batches_tracked, coef, pass_stats, post,
+                                           (unsigned char*)sign_mask, count,
                                            P, pix_per_img, g.ppb, ldx, ldr, ldz, C, nrep, relu, momentum, eps}),
                        2 * C * sizeof(float), (hipStream_t)stream);
 }
@@ -678,8 +718,8 @@ int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_chann
 int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
                       long P, int C, const float* mean, const float* invstd, int relu,
                       const float* post, long pix_per_img, double* sums, int nrep, int zero_sums,
-                      const float* mask_scale, const float* mask_shift, void* stream) {
-  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale) || nrep < 1 ||
+                      const float* mask_scale, const float* mask_shift, const void* sign_mask, void* stream) {
+  if (!x || !dz || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale && !sign_mask) || nrep < 1 ||
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || (z && ldz % 8)) return SSA_EINVAL;
@@ -690,7 +730,8 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
   }
   const Grid g = plan_reduce_grid(P, C);
   return SSA_BN_SUBMIT(BnBwdReduceK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums,
-                                          mask_scale, mask_shift, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep}),
+                                          mask_scale, mask_shift, (const unsigned char*)sign_mask, P, pix_per_img, g.ppb, ldx,
+                                          lddz, ldz, C, relu, nrep}),
                        16 * (NT + 1) * sizeof(float), s);
 }
 
@@ -699,14 +740,15 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
                      const float* mean, const float* invstd, const double* sums, int nrep,
                      double count, int relu, const float* post, long pix_per_img, float* dgamma,
                      float* dbeta, float param_grad_scale, const float* mask_scale,
-                     const float* mask_shift, int accumulate_param_grads, void* stream) {
-  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale) || nrep < 1 ||
+                     const float* mask_shift, int accumulate_param_grads, const void* sign_mask, void* stream) {
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ok_c(C) || !ok_p(P) || (relu && !z && !mask_scale && !sign_mask) || nrep < 1 ||
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C, bwd_rows());
   return SSA_BN_SUBMIT(BnBwdApplyK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres,
-                                         gamma, mean, invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift, count, P,
+                                         gamma, mean, invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift,
+                                         (const unsigned char*)sign_mask, count, P,
                                          pix_per_img, g.ppb, ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale,
                                          accumulate_param_grads}), 7 * C * sizeof(float), (hipStream_t)stream);
 }

@@ -102,7 +102,7 @@ _SIGS = {
     "ssa_pad_cast_f32_bf16": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_stats": ([_P, c_long, c_int, c_int, _P, c_int, _P], c_int),
     "ssa_bn_apply_train": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, c_int, c_double, _P, _P, _P, _P,
-                            _P, c_float, c_float, _P, _P, c_int, _P, c_long, _P], c_int),
+                            _P, c_float, c_float, _P, _P, c_int, _P, c_long, _P, _P], c_int),
     "ssa_bn_update_running_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_pack_filters_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_pack_tile_channels": ([c_int, c_int], c_int),
@@ -113,9 +113,9 @@ _SIGS = {
     "ssa_bn_apply": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
                       c_long, _P], c_int),
     "ssa_bn_bwd_reduce": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,
-                           c_long, _P, c_int, c_int, _P, _P, _P], c_int),
+                           c_long, _P, c_int, c_int, _P, _P, _P, _P], c_int),
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
-                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P], c_int),
+                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
     "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
     "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),

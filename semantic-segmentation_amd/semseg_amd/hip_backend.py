@@ -1074,8 +1074,13 @@ def _bn_take_stats(jobs):
     return out
 
 
-def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts):
-    """Training-mode normalisation of N problems: returns (zs, coefs, counts, worlds)."""
+_BN_SIGN_MASK = os.environ.get("SSA_BN_SIGN_MASK", "1") != "0"
+
+
+def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts, masks=None):
+    """Training-mode normalisation of N problems: returns (zs, coefs, counts, worlds).
+    masks: a list to receive, per problem, the sign bytes of z ([P, C/8] uint8) where the backward will want a ReLU mask
+    it cannot recompute from x (ReLU behind a residual add or a Dropout2d mask), else None."""
     L = lib()
     n = len(xs)
     stats = _bn_take_stats(list(zip(xs, ldxs)))
@@ -1095,11 +1100,17 @@ def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts):
             coef = torch.empty((4, C), dtype=torch.float32, device=x.device)  # scale, shift, mean, invstd
             z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=x.device)
             res, ldr = ress[i] if ress[i] is not None else (None, 0)
+            mask = None
+            if masks is not None and _BN_SIGN_MASK and m.relu and (res is not None or posts[i] is not None):
+                mask = torch.empty((P, C // 8), dtype=torch.uint8, device=x.device)
+            if masks is not None:
+                masks.append(mask)
             _note(0.0, 2.0 * P * C * (2 + (1 if res is not None else 0)))
             check(L.ssa_bn_apply_train(_p(x), ldxs[i], _p(res), ldr, _p(z), C, P, C, _p(stats[i][0]), stats[i][1],
                                        counts[i], _p(gammas[i]), _p(betas[i]), _p(m.running_mean), _p(m.running_var),
                                        _p(m.nbt), float(m.momentum),
-                                       float(m.eps), _p(coef), _p(m.pass_stats), int(m.relu), _p(posts[i]), H * W, _s()),
+                                       float(m.eps), _p(coef), _p(m.pass_stats), int(m.relu), _p(posts[i]), H * W,
+                                       _p(mask), _s()),
                   "ssa_bn_apply_train")
             zs.append(z)
             coefs.append(coef)
@@ -1130,7 +1141,7 @@ def _bn_bwd(jobs):
                 _note(0.0, 4.0 * B * H * W * C)
                 check(L.ssa_bn_bwd_reduce(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, B * H * W, C, _p(coef[2]),
                                           _p(coef[3]), int(j["relu"]), _p(j["pst"]), H * W, _p(j["sums"]), j["nrep"], 0,
-                                          _p(msc), _p(msh), _s()), "ssa_bn_bwd_reduce")
+                                          _p(msc), _p(msh), _p(j.get("mask")), _s()), "ssa_bn_bwd_reduce")
     sync = [j for j in jobs if j["training"] and j["world"]]
     if sync:
         _allreduce_sums([j["sums"] for j in sync])
@@ -1176,7 +1187,8 @@ def _bn_bwd(jobs):
             check(L.ssa_bn_bwd_apply(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, _p(dx), C, _p(dres), C, P, C,
                                      _p(g), _p(coef[2]), _p(coef[3]), _p(use_sums), j["nrep"], j["count"], int(j["relu"]),
                                      _p(j["pst"]), H * W, _p(pg_g) if fuse_pg else None, _p(pg_b) if fuse_pg else None,
-                                     pscale, _p(msc), _p(msh), accumulate if fuse_pg else 0, _s()), "ssa_bn_bwd_apply")
+                                     pscale, _p(msc), _p(msh), accumulate if fuse_pg else 0, _p(j.get("mask")), _s()),
+                  "ssa_bn_bwd_apply")
             out.append((dx, dres, ret_g, ret_b))
     for sums, C, tmp, pg_g, pg_b in tails:
         if tmp is None:
@@ -1215,9 +1227,11 @@ class BnActGroupFn(torch.autograd.Function):
             posts.append(post.float().contiguous() if post is not None else None)
         training = [m.training for m in metas]
         assert all(training) or not any(training), "one grouped BatchNorm call mixes training and eval layers"
+        masks = []
         if training[0]:
-            zs, coefs, counts, worlds = _bn_train_fwd(xs, ldxs, metas, gs, bs, ress, posts)
+            zs, coefs, counts, worlds = _bn_train_fwd(xs, ldxs, metas, gs, bs, ress, posts, masks)
         else:
+            masks = [None] * n
             zs, coefs, counts, worlds = [], [], [], [0] * n
             for i in range(n):
                 C = xs[i].shape[3]
@@ -1242,7 +1256,9 @@ class BnActGroupFn(torch.autograd.Function):
         for i in range(n):
             relu = metas[i].relu
             mask_from_x = relu and ress[i] is None and posts[i] is None
-            saved += [xs[i], zs[i] if (relu and not mask_from_x) else None, gs[i], coefs[i], posts[i]]
+            # (the sign bytes stand in for z where they were written: z is then neither kept for nor read by the backward)
+            saved += [xs[i], masks[i] if masks[i] is not None else (zs[i] if (relu and not mask_from_x) else None), gs[i],
+                      coefs[i], posts[i]]
             info.append((ldxs[i], relu, metas[i].training, worlds[i], ress[i] is not None, counts[i], mask_from_x))
         ctx.save_for_backward(*saved)
         ctx.info = info
@@ -1261,7 +1277,9 @@ class BnActGroupFn(torch.autograd.Function):
             x, z, g, coef, pst = saved[5 * i:5 * i + 5]
             ldx, relu, training, world, has_res, count, mask_from_x = info[i]
             dz, lddz = _dz_bf16(dzs[i], x.shape[3])
-            jobs.append(dict(x=x, ldx=ldx, dz=dz, lddz=lddz, z=z, coef=coef, g=g, gamma_param=ctx.params[i][0],
+            mask = z if (z is not None and z.dtype == torch.uint8) else None
+            z = None if mask is not None else z
+            jobs.append(dict(x=x, ldx=ldx, dz=dz, lddz=lddz, z=z, mask=mask, coef=coef, g=g, gamma_param=ctx.params[i][0],
                              beta_param=ctx.params[i][1], relu=relu, pst=pst, training=training, world=world,
                              count=count, has_res=has_res, mask_from_x=mask_from_x, sums=None))
             idx.append(i)
@@ -1332,12 +1350,15 @@ class BasicBlockGroupFn(torch.autograd.Function):
         with tile_strip(descs), group():
             for i in range(n):
                 y2s.append(_conv_fwd(a1s[i], a1s[i].shape[3], T[i][4], None, 1, 1, 1, False, True)[0])
+        masks2 = []
         outs, coef2, cnt2, wd2 = _bn_train_fwd(y2s, [y.shape[3] for y in y2s], [m[1] for m in metas],
                                                [f32(T[i][5]) for i in range(n)], [f32(T[i][6]) for i in range(n)],
-                                               [(xs[i], ldxs[i]) for i in range(n)], [None] * n)
+                                               [(xs[i], ldxs[i]) for i in range(n)], [None] * n, masks2)
         saved = []
         for i in range(n):
-            saved += [xs[i], y1s[i], a1s[i], y2s[i], outs[i], coef1[i], coef2[i], T[i][1], T[i][4], f32(T[i][2]), f32(T[i][5])]
+            # slot 4: the block output's sign bytes (the ReLU mask of bn2's backward), or the output itself
+            saved += [xs[i], y1s[i], a1s[i], y2s[i], masks2[i] if masks2[i] is not None else outs[i], coef1[i], coef2[i],
+                      T[i][1], T[i][4], f32(T[i][2]), f32(T[i][5])]
         ctx.save_for_backward(*saved)
         ctx.info = (ldxs, cnt1, wd1, cnt2, wd2)
         ctx.params = [(T[i][2], T[i][3], T[i][5], T[i][6]) for i in range(n)]
@@ -1359,7 +1380,9 @@ class BasicBlockGroupFn(torch.autograd.Function):
             x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
             C = y2.shape[3]
             dz, lddz = _dz_bf16(douts[i], C)
-            jobs2.append(dict(x=y2, ldx=C, dz=dz, lddz=lddz, z=out, coef=c2, g=g2, gamma_param=ctx.params[i][2],
+            mask2 = out if out.dtype == torch.uint8 else None
+            jobs2.append(dict(x=y2, ldx=C, dz=dz, lddz=lddz, z=None if mask2 is not None else out, mask=mask2, coef=c2,
+                              g=g2, gamma_param=ctx.params[i][2],
                               beta_param=ctx.params[i][3], relu=True, pst=None, training=True, world=wd2[i],
                               count=cnt2[i], has_res=True, mask_from_x=False, sums=None))
         r2 = _bn_bwd(jobs2)          # (dy2, g, None, None)

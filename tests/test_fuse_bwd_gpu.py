@@ -55,7 +55,7 @@ def test_aux_bn_backward_sums(B, H, W, C):
     P = B * H * W
     check(lib().ssa_bn_bwd_reduce(x.data_ptr(), C, ref.data_ptr(), C, None, C, P, C, coef[2].data_ptr(),
                                   coef[3].data_ptr(), 1, None, H * W, sums2.data_ptr(), nrep, 0,
-                                  coef[0].data_ptr(), coef[1].data_ptr(),
+                                  coef[0].data_ptr(), coef[1].data_ptr(), None,
                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "ssa_bn_bwd_reduce")
     torch.cuda.synchronize()
     assert torch.equal(out, ref)                                  # dz itself is untouched

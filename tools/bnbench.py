@@ -39,24 +39,27 @@ class Prob:
         self.beta = torch.rand(C, device=DEV) - 0.5
         self.coef = torch.empty(4, C, device=DEV)
         self.pg = torch.zeros(2, C, device=DEV)
+        self.mask = torch.zeros(self.P * (C // 8), dtype=torch.uint8, device=DEV)      # sign bytes of z (bn2 levels)
+        self.use_mask = os.environ.get("SSA_BN_SIGN_MASK", "1") != "0"
 
     def apply(self, res):
         hb.check(L.ssa_bn_apply_train(P(self.x), self.C, P(self.res) if res else None, self.C, P(self.z), self.C, self.P, self.C,
                                       P(self.stats), self.nrep, float(self.P), P(self.gamma), P(self.beta), None, None, None,
-                                      0.1, 1e-5, P(self.coef), None, 1, None, self.P, hb._s()), "apply")
+                                      0.1, 1e-5, P(self.coef), None, 1, None, self.P, P(self.mask) if (res and self.use_mask) else None, hb._s()), "apply")
 
     def reduce(self, from_x):
         msc, msh = (self.coef[0], self.coef[1]) if from_x else (None, None)
         hb.check(L.ssa_bn_bwd_reduce(P(self.x), self.C, P(self.dz), self.C, None if from_x else P(self.z), self.C, self.P, self.C,
                                      P(self.coef[2]), P(self.coef[3]), 1, None, self.P, P(self.bsums), self.nrep, 0,
-                                     P(msc), P(msh), hb._s()), "reduce")
+                                     P(msc), P(msh), P(self.mask) if (self.use_mask and not from_x) else None, hb._s()), "reduce")
 
     def bapply(self, from_x, dres):
         msc, msh = (self.coef[0], self.coef[1]) if from_x else (None, None)
         hb.check(L.ssa_bn_bwd_apply(P(self.x), self.C, P(self.dz), self.C, None if from_x else P(self.z), self.C, P(self.dx), self.C,
                                     P(self.dres) if dres else None, self.C, self.P, self.C, P(self.gamma), P(self.coef[2]),
                                     P(self.coef[3]), P(self.bsums), self.nrep, float(self.P), 1, None, self.P, P(self.pg[0]),
-                                    P(self.pg[1]), 1.0, P(msc), P(msh), 1, hb._s()), "bapply")
+                                    P(self.pg[1]), 1.0, P(msc), P(msh), 1, P(self.mask) if (self.use_mask and not from_x) else None,
+                                    hb._s()), "bapply")
 
 
 def timeit(fn, reps):
