@@ -222,11 +222,15 @@ def main():
     images, gts = synth_batch(args.batch, args.crop, crop_w, rank, "cuda")
     inputs = {"images": images, "gts": gts}
     static_loss = torch.zeros((), device="cuda")
+    # fp16 storage (SSA_ACT_DTYPE=fp16, the reference's --fp16): apex's dynamic loss scaling on the device, inside the
+    # captured step (semseg_amd/amp.py); bf16 storage: scaler is None, scale_loss the identity
+    from semseg_amd import amp as samp
+    scaler = samp.attach_scaler(optim, torch.device("cuda")) if (samp.fp16_storage() and fused_sgd) else None
 
     def step():
         optim.zero_grad(set_to_none=True)
         loss = model(inputs)
-        loss.backward()
+        (scaler.scale(loss) if scaler is not None else loss).backward()
         optim.step()
         static_loss.copy_(loss.detach())
 
@@ -418,7 +422,7 @@ def main():
             "metric": "train images/sec HRNet-OCR-MScale 1024x1024 crop",
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp16" if samp.fp16_storage() else "bf16", "data": "synthetic",
             "config": {"workload": "train_cityscapes_sota: HRNet-OCR-MScale two-scale train step, RMI+BCE loss, "
                                    "crop %dx%d, batch %d/GPU, SGD, synthetic Cityscapes-shaped batch, random init"
                                    % (args.crop, crop_w, args.batch),
@@ -426,6 +430,7 @@ def main():
                        "hipgraph": graph is not None, "capture_error": capture_error, "loss": loss_val,
                        "eager_ms_per_step": eager_ms,
                        "optimizer": "ssa_sgd_momentum_step" if fused_sgd else "torch.optim.SGD(foreach)",
+                       "loss_scale": scaler.loss_scale() if scaler is not None else None,
                        "library_launches_per_step": launches_per_step,
                        "lib_sha": _lib_sha(),
                        # deferred weight gradients: flushed every N layers onto a side stream (a parallel branch of

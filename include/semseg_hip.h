@@ -564,10 +564,23 @@ int ssa_confusion_matrix(const float* logits, int ld, const int64_t* labels, lon
  * single entries of it.  Up to 96 tensors go into one launch (pointers travel as
  * kernel arguments, so a captured graph owns them).  lr_dev, when not NULL, is a
  * device float read at run time instead of `lr` -- a captured step then follows the
- * LR schedule without re-capture.                                                    */
+ * LR schedule without re-capture.
+ * amp_state (optional): the loss-scaling record of fp16 training, 4 device floats {scale, found_inf, clean steps,
+ * 1 / scale}: every gradient is multiplied by amp_state[3] on the way in, and when amp_state[1] != 0 (an inf / nan
+ * was found by ssa_amp_check_grads) the call changes NOTHING -- apex.amp's skipped step (train.py:503-505).          */
 int ssa_sgd_momentum_step(void* const* params, const void* const* grads, void* const* bufs,
                           const int64_t* numel, int n_tensors, float lr, const float* lr_dev,
-                          float momentum, float weight_decay, int nesterov, void* stream);
+                          float momentum, float weight_decay, int nesterov, const float* amp_state,
+                          void* stream);
+/* Dynamic loss scaling (apex.amp's LossScaler, the reference's --fp16 path: train.py:380-381,503-505), capturable:
+ * ssa_amp_check_grads sets amp_state[1] = 1 if any element of the n_tensors dense fp32 gradient tensors (HOST arrays
+ * of device pointers / element counts, as above) is inf or nan;  ssa_amp_update then closes the step:
+ * found_inf: scale = max(scale * backoff, min_scale), clean steps = 0; else clean steps += 1 and, on reaching
+ * growth_interval, scale = min(scale * growth, max_scale), clean steps = 0; found_inf = 0; amp_state[3] = 1 / scale. */
+int ssa_amp_check_grads(const void* const* grads, const int64_t* numel, int n_tensors, float* amp_state,
+                        void* stream);
+int ssa_amp_update(float* amp_state, int growth_interval, float growth, float backoff, float min_scale,
+                   float max_scale, void* stream);
 
 /* fp32 elementwise out = a (+ | * | /) b (op 0 | 1 | 2) and its backward (da, db optional): the
  * attention normalisation and the attention-weighted sum over scales of the attention-to-scale

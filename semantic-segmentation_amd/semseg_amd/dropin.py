@@ -39,22 +39,41 @@ def _amp_shim():
         # iteration (4x the eager loop's speed at batch 1; a refused capture falls back to the eager step, logged
         # once).  SSA_GRAPHED_STEP=0: the plain objects.
         import os
+        import torch
+        from . import amp as samp
         on_gpu = any(p.is_cuda for p in model.parameters())
-        if os.environ.get("SSA_GRAPHED_STEP", "1") != "0" and on_gpu and optimizers is not None and \
-                not isinstance(optimizers, (list, tuple)):
+        # the fp16-storage build (`--fp16` under install(), or SSA_ACT_DTYPE=fp16): apex's dynamic loss scaler, on the
+        # device, inside the optimizer step (semseg_amd/amp.py); bf16 storage needs none
+        samp.initialize(model, optimizers, opt_level)
+        # The captured step goes back only where one process drives one GPU: with several visible GPUs and no process
+        # group the reference wraps the net in torch.nn.DataParallel (network/__init__.py:28), whose replicas would share
+        # ONE captured step on cuda:0 (advisor, round 4).
+        one_gpu_per_process = torch.cuda.device_count() == 1 or \
+            (torch.distributed.is_available() and torch.distributed.is_initialized())
+        if os.environ.get("SSA_GRAPHED_STEP", "1") != "0" and on_gpu and one_gpu_per_process and \
+                optimizers is not None and not isinstance(optimizers, (list, tuple)):
             from .graphed import graph_training
             return graph_training(model, optimizers)
         return model, optimizers
     amp.initialize = initialize
 
-    @contextlib.contextmanager
-    def scale_loss(loss, optimizers, **kw):   # bf16 needs no loss scaling
-        yield loss
+    def scale_loss(loss, optimizers, **kw):
+        from . import amp as samp
+        return samp.scale_loss(loss, optimizers, **kw)      # identity on the bf16 build; loss * S on the fp16 build
     amp.scale_loss = scale_loss
     return amp
 
 
+def _select_storage_from_argv():
+    """`--fp16` (train.py:200, scripts/train_*.yml `fp16: true`) selects the fp16-storage build of the library, which
+    is a property of the process: it has to be decided before semseg_amd._lib is imported."""
+    import os
+    if "SSA_ACT_DTYPE" not in os.environ and "--fp16" in sys.argv and "semseg_amd._lib" not in sys.modules:
+        os.environ["SSA_ACT_DTYPE"] = "fp16"
+
+
 def install(replace_apex=True):
+    _select_storage_from_argv()
     from . import nn as snn, parallel, network, loss
     from .network import ocrnet, hrnetv2, ocr_utils, utils as nutils, mynn, deepv3, mscale, mscale2, attnscale
     from .loss import criteria, optimizer

@@ -51,8 +51,9 @@ class GraphedTrainStep:
         self.optim.zero_grad(set_to_none=True)
         loss = self.net(static)
         loss = loss.mean()
-        loss.backward()
-        self.optim.step()
+        scaler = getattr(self.optim, "loss_scaler", None)       # fp16 training (semseg_amd/amp.py): backward on loss * S
+        (scaler.scale(loss) if scaler is not None else loss).backward()
+        self.optim.step()                                       # (un-scales, skips on overflow, updates S)
         loss_out.copy_(loss.detach())
 
     def _capture(self, inputs):
@@ -67,6 +68,8 @@ class GraphedTrainStep:
                   for p in params]
         bufs = list(self.net.buffers())
         snap_b = [b.detach().clone() for b in bufs]
+        scaler = getattr(self.optim, "loss_scaler", None)
+        snap_s = scaler.state.clone() if scaler is not None else None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -93,6 +96,8 @@ class GraphedTrainStep:
                             buf.zero_()             # a zero buffer is the optimizer's first-step state
                 for b, s0 in zip(bufs, snap_b):
                     b.copy_(s0)
+                if snap_s is not None:
+                    scaler.state.copy_(snap_s)
         return graph, static, loss_out
 
     def _run_eager(self, inputs):

@@ -35,13 +35,25 @@ from ._lib import ACT as _ACT_NAME     # storage format of the activations = the
 ACT_DTYPE = torch.float16 if _ACT_NAME == "fp16" else torch.bfloat16
 
 
+_FP16_TRAINING = [False]
+
+
+def enable_fp16_training(on=True):
+    """Called by semseg_amd.amp.attach_scaler: a dynamic loss scaler is in place, the criteria may run backward on the
+    fp16-storage build."""
+    _FP16_TRAINING[0] = bool(on)
+
+
 def _no_fp16_training():
-    """fp16 storage is the EVALUATION path this round: a 1024x1024 step's per-pixel loss gradients (~1e-6) underflow
-    fp16 without the loss scaling apex O1 applies (amp.scale_loss, train.py:504), which the captured step does not
-    carry yet.  The criteria of the operator surface (ops.HipBackend.cross_entropy / bce_rmi) raise rather than
-    train on flushed gradients; the kernels themselves are format-agnostic and tested in both formats."""
-    if _ACT_NAME == "fp16":
-        raise NotImplementedError("SSA_ACT_DTYPE=fp16 is the evaluation path; train with bf16 storage (the default)")
+    """fp16 storage without loss scaling cannot train: a 1024x1024 step's per-pixel loss gradients (~1e-6) underflow
+    fp16 on their way back.  The criteria of the operator surface (ops.HipBackend.cross_entropy / bce_rmi) raise
+    rather than train on flushed gradients unless a loss scaler has been attached to the optimizer
+    (semseg_amd.amp.initialize / attach_scaler -- what the reference's `amp.initialize(net, optim, opt_level)` does
+    under dropin.install(); train.py:380-381)."""
+    if _ACT_NAME == "fp16" and not _FP16_TRAINING[0]:
+        raise NotImplementedError("SSA_ACT_DTYPE=fp16 trains with dynamic loss scaling only: call "
+                                  "semseg_amd.amp.initialize(net, optimizer) (apex.amp.initialize under dropin.install()) "
+                                  "and run backward on amp.scale_loss(loss, optimizer)")
 
 
 def _s():

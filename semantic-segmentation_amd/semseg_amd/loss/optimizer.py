@@ -48,6 +48,7 @@ class FusedSGD(optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                                       nesterov=nesterov))
         self._lr_dev = {}          # group index -> (device scalar, value it holds)
+        self.loss_scaler = None    # semseg_amd.amp.LossScaler (fp16 training): un-scale, overflow test, skipped steps
 
     def _lr_scalar(self, gi, group, device, capturing):
         ent = self._lr_dev.get(gi)
@@ -73,6 +74,15 @@ class FusedSGD(optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        amp = self.loss_scaler
+        amp_ptr = amp.state.data_ptr() if amp is not None else None
+        if amp is not None:
+            # the overflow test covers EVERY gradient before any parameter moves (apex skips the whole step)
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                     for group in self.param_groups for p in group["params"] if p.grad is not None]
+            if grads:
+                with _launch_scope(grads[0].device) as (stream, _):
+                    amp.check(grads, stream)
         for gi, group in enumerate(self.param_groups):
             momentum = float(group["momentum"])
             by_device = {}
@@ -106,13 +116,29 @@ class FusedSGD(optim.Optimizer):
                     N = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
                     check(lib().ssa_sgd_momentum_step(P, G, Bf, N, n, float(group["lr"]), lr_dev.data_ptr(),
                                                       momentum, float(group["weight_decay"]),
-                                                      int(bool(group["nesterov"])), stream),
+                                                      int(bool(group["nesterov"])), amp_ptr, stream),
                           "ssa_sgd_momentum_step")
                 # the kernel wrote through raw pointers: tell autograd (saved-tensor checks) and the
                 # packed-filter cache (hip_backend.refresh_packed_filters keys on ._version) that
                 # the parameters and buffers changed
                 _mark_updated([p for p, _, _ in items] + [b for _, _, b in items if b is not None])
+        if amp is not None:
+            with _launch_scope(amp.state.device) as (stream, _):
+                amp.update(stream)
         return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self.loss_scaler is not None:
+            sd["loss_scaler"] = self.loss_scaler.state_dict()       # (apex keeps amp.state_dict() beside the optimizer's)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        ls = state_dict.pop("loss_scaler", None)
+        super().load_state_dict(state_dict)
+        if ls is not None and self.loss_scaler is not None:
+            self.loss_scaler.load_state_dict(ls)
 
 
 def _mark_updated(tensors):

@@ -1,0 +1,241 @@
+"""fp16 training = the reference's `--fp16` path (apex.amp dynamic loss scaling; train.py:380-381 `amp.initialize`,
+train.py:503-505 `amp.scale_loss`): semseg_amd/amp.py + csrc/optim.hip (ssa_amp_check_grads, the amp_state argument of
+ssa_sgd_momentum_step, ssa_amp_update).
+
+1. The scaler's arithmetic, through FusedSGD on plain fp32 tensors (independent of the storage build): un-scaled
+   updates are those of torch.optim.SGD on the true gradients; an inf or nan ANYWHERE skips the whole step (parameters
+   and momentum untouched) and halves the scale; `growth_interval` clean steps double it; bounds hold; the record
+   survives state_dict / load_state_dict; the whole sequence replays as a captured graph.
+2. On the fp16-storage build (child processes with SSA_ACT_DTYPE=fp16): the end-to-end training-step parity test
+   (tests/test_e2e_gpu.py::test_train_step: loss, per-parameter gradient cosines and norms against the fp32 oracle, bounded
+   by the fp16-storage emulation, which is scaled the same way), the teacher-forced 1024^2 step op by op, the
+   reference-style loop through the captured step with the scaler inside the graph, and the refusal without a scaler.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _pair(n_tensors=5, seed=3):
+    from semseg_amd.loss.optimizer import FusedSGD
+    from semseg_amd.amp import LossScaler
+    g = torch.Generator().manual_seed(seed)
+    init = [torch.randn(n, generator=g) for n in (7, 4096, 4097, 100003, 33)[:n_tensors]]
+    mine = [t.clone().to(DEV).requires_grad_(True) for t in init]
+    ref = [t.clone().to(DEV).requires_grad_(True) for t in init]
+    om = FusedSGD(mine, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    om.loss_scaler = LossScaler(torch.device(DEV), init_scale=1024.0, growth_interval=3)
+    orf = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    return g, mine, ref, om, orf
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def test_scaled_steps_equal_unscaled_sgd_and_scale_grows():
+    g, mine, ref, om, orf = _pair()
+    scales = []
+    for step in range(7):
+        S = om.loss_scaler.loss_scale()
+        scales.append(S)
+        for p, q in zip(mine, ref):
+            gr = torch.randn(p.shape, generator=g)
+            q.grad = gr.to(DEV)
+            p.grad = (gr * S).to(DEV)              # what backward of loss * S leaves
+        om.step()
+        orf.step()
+        _sync()
+        for p, q in zip(mine, ref):
+            assert torch.allclose(p.detach(), q.detach(), rtol=2e-6, atol=2e-7), step
+    # 3 clean steps -> x2, again after 3 more
+    assert scales == [1024.0, 1024.0, 1024.0, 2048.0, 2048.0, 2048.0, 4096.0], scales
+    st = om.loss_scaler.state.cpu().tolist()
+    assert st[1] == 0.0 and abs(st[3] * st[0] - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("bad", [float("inf"), float("-inf"), float("nan")])
+def test_overflow_skips_the_whole_step_and_halves_the_scale(bad):
+    g, mine, ref, om, orf = _pair()
+    for p in mine:                                   # one clean step first: momentum buffers exist
+        p.grad = torch.randn(p.shape, generator=g).to(DEV) * 1024.0
+    om.step()
+    _sync()
+    before = [p.detach().clone() for p in mine]
+    bufs = [om.state[p]["momentum_buffer"].clone() for p in mine]
+    for p in mine:
+        p.grad = torch.randn(p.shape, generator=g).to(DEV) * 1024.0
+    mine[3].grad[77777] = bad                        # one element of one tensor (in the scalar tail of a later launch chunk)
+    om.step()
+    _sync()
+    for p, b0, m0 in zip(mine, before, bufs):
+        assert torch.equal(p.detach(), b0) and torch.equal(om.state[p]["momentum_buffer"], m0)
+    st = om.loss_scaler.state.cpu().tolist()
+    assert st[0] == 512.0 and st[1] == 0.0 and st[2] == 0.0, st      # halved, flag cleared, clean-step count reset
+    # the next clean step moves the parameters again, un-scaled by the NEW scale
+    for p in mine:
+        p.grad = torch.ones_like(p) * 512.0
+    om.step()
+    _sync()
+    assert not torch.equal(mine[0].detach(), before[0])
+
+
+def test_scale_bounds_and_state_dict_round_trip():
+    from semseg_amd.loss.optimizer import FusedSGD
+    from semseg_amd.amp import LossScaler
+    p = torch.zeros(100, device=DEV, requires_grad=True)
+    opt = FusedSGD([p], lr=0.1, momentum=0.9)
+    opt.loss_scaler = LossScaler(torch.device(DEV), init_scale=2.0, growth_interval=1, min_scale=1.0, max_scale=4.0)
+    for _ in range(4):                               # grows 2 -> 4 and stays at the upper bound
+        p.grad = torch.ones_like(p)
+        opt.step()
+    assert opt.loss_scaler.loss_scale() == 4.0
+    for _ in range(5):                               # overflows: 4 -> 2 -> 1 and stays at the lower bound
+        p.grad = torch.full_like(p, float("inf"))
+        opt.step()
+    assert opt.loss_scaler.loss_scale() == 1.0
+    sd = opt.state_dict()
+    assert sd["loss_scaler"] == {"loss_scale": 1.0, "unskipped": 0}
+    q = torch.zeros(100, device=DEV, requires_grad=True)
+    opt2 = FusedSGD([q], lr=0.1, momentum=0.9)
+    opt2.loss_scaler = LossScaler(torch.device(DEV))
+    q.grad = torch.ones_like(q)
+    opt2.step()                                      # (momentum buffer exists: the state dicts have the same layout)
+    sd["loss_scaler"] = {"loss_scale": 256.0, "unskipped": 7}
+    opt2.load_state_dict(sd)
+    assert opt2.loss_scaler.state.cpu().tolist()[:3] == [256.0, 0.0, 7.0]
+
+
+def test_scaled_step_replays_as_a_graph():
+    """check -> update -> scale update inside one captured graph; the scale a replay uses is the previous replay's."""
+    if os.environ.get("SSA_EMU"):
+        pytest.skip("graph capture needs the device")
+    g, mine, ref, om, orf = _pair(n_tensors=3)
+    grads = [torch.zeros_like(p) for p in mine]
+    for p, gb in zip(mine, grads):
+        p.grad = gb
+        gb.fill_(1.0)
+    om.step()                                        # eager step: momentum buffers, device scalars
+    _sync()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        om.step()
+    _sync()
+    s0 = om.loss_scaler.loss_scale()
+    before = mine[0].detach().clone()
+    grads[1].fill_(float("nan"))
+    graph.replay()
+    _sync()
+    assert torch.equal(mine[0].detach(), before) and om.loss_scaler.loss_scale() == s0 / 2
+    for gb in grads:
+        gb.fill_(s0 / 2)                             # = a true gradient of 1 under the new scale
+    graph.replay()
+    _sync()
+    assert not torch.equal(mine[0].detach(), before) and om.loss_scaler.loss_scale() == s0 / 2
+
+
+# ------------------------------------------------------------------ the fp16-storage build (child processes)
+def _child(args, log, timeout=900, code=None):
+    env = dict(os.environ, SSA_ACT_DTYPE="fp16", SSA_PARITY_CROP="512")
+    env.pop("PYTEST_CURRENT_TEST", None)
+    cmd = [sys.executable, "-c", code] if code else \
+        [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-s"] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", log), "w") as f:
+        f.write(r.stdout[-200000:])
+        f.write(r.stderr[-20000:])
+    return r
+
+
+def _needs_device():
+    if os.environ.get("SSA_EMU"):
+        pytest.skip("child processes on the fp16 build need the device")
+
+
+def test_train_step_parity_on_the_fp16_build():
+    """tests/test_e2e_gpu.py::test_train_step with SSA_ACT_DTYPE=fp16: backward runs on loss * 2^16 (the scaler's initial
+    scale) on the HIP path AND in the fp16-storage emulation, gradients are un-scaled before they are compared with the
+    fp32 oracle's."""
+    _needs_device()
+    r = _child(["tests/test_e2e_gpu.py", "-k", "train_step"], "fp16_e2e_train.log")
+    tail = "\n".join(r.stdout.splitlines()[-25:])
+    assert r.returncode == 0 and " passed" in tail and " failed" not in tail, tail + r.stderr[-2000:]
+    assert "loss scale 65536" in r.stdout, r.stdout[-3000:]
+
+
+def test_teacher_forced_training_ops_on_the_fp16_build():
+    """Every operator of the training step, forward and backward, teacher-forced at one-rounding tolerance on the fp16
+    build (512^2 crop: the shapes of the 1024^2 step's 0.5x pass), upstream gradient = the loss scale."""
+    _needs_device()
+    r = _child(["tests/test_parity_1024_gpu.py", "-k", "teacher_forced"], "fp16_teacher_train.log", timeout=1200)
+    tail = "\n".join(r.stdout.splitlines()[-25:])
+    assert r.returncode == 0 and " passed" in tail and " failed" not in tail, tail + r.stderr[-2000:]
+
+
+def test_reference_loop_with_amp_on_the_fp16_build():
+    """amp.initialize + amp.scale_loss as the reference's loop calls them (through dropin's apex.amp), captured step with
+    the scaler inside the graph: losses are finite and fall, parameters move, the scale is the initial one (no
+    overflow at this size), an injected overflow is skipped."""
+    _needs_device()
+    code = r'''
+import os, sys
+sys.path[:0] = [%r, %r, %r]
+import torch
+import semseg_amd.dropin as dropin
+dropin.install()
+from apex import amp
+from semseg_amd import amp as samp
+from semseg_amd.config import cfg
+from semseg_amd.loss import RMILoss
+from semseg_amd.loss.optimizer import FusedSGD
+from semseg_amd.network import ocrnet
+import bench
+assert samp.fp16_storage()
+cfg.LOSS.SUPERVISED_MSCALE_WT = 0.05
+torch.manual_seed(0)
+net = ocrnet.HRNet_Mscale(19, RMILoss(num_classes=19, ignore_index=255)).cuda().train()
+optim = FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+net, optim = amp.initialize(net, optim, opt_level="O1")
+images, gts = bench.synth_batch(1, 256, 256, 0, "cuda")
+w0 = net.wrapped.backbone.conv1.weight.detach().clone()
+losses = []
+for it in range(4):
+    optim.zero_grad()
+    loss = net({"images": images, "gts": gts})
+    with amp.scale_loss(loss.mean(), optim) as scaled:
+        scaled.backward()
+    optim.step()
+    losses.append(float(loss))
+torch.cuda.synchronize()
+sc = samp.scaler_of(optim)
+print("LOSSES", losses, "SCALE", sc.loss_scale(), "REPLAYS", net._stepper.replays)
+assert all(l == l and abs(l) < 1e4 for l in losses) and losses[-1] < losses[0]
+assert not torch.equal(net.wrapped.backbone.conv1.weight.detach(), w0)
+assert sc.loss_scale() in (65536.0, 32768.0, 16384.0)
+print("AMP_LOOP_OK")
+''' % (ROOT, os.path.join(ROOT, "semantic-segmentation_amd"), os.path.join(ROOT, "tests"))
+    r = _child(None, "fp16_amp_loop.log", code=code)
+    assert "AMP_LOOP_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_training_without_a_scaler_is_refused_on_the_fp16_build():
+    _needs_device()
+    code = ("import os, sys; sys.path[:0] = [%r, %r]\n"
+            "import torch\n"
+            "from semseg_amd.loss import CrossEntropyLoss2d\n"
+            "x = torch.randn(1, 19, 8, 8, device='cuda', requires_grad=True)\n"
+            "try:\n"
+            "    CrossEntropyLoss2d(ignore_index=255).cuda()(x, torch.zeros(1, 8, 8, dtype=torch.long, device='cuda')).backward()\n"
+            "except NotImplementedError as e:\n    print('REFUSED', type(e).__name__)\n"
+            % (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")))
+    r = _child(None, "fp16_refused.log", timeout=300, code=code)
+    assert "REFUSED" in r.stdout, r.stdout + r.stderr[-2000:]

@@ -86,10 +86,19 @@ def _run(backend, sd, images, gts, train, device="cpu"):
                 out = net(inputs)
             return {k: v.float().cpu() for k, v in out.items()}
         loss = net(inputs)
-        loss.backward()
+        # fp16 storage (tests/test_amp_fp16_gpu.py runs this file with SSA_ACT_DTYPE=fp16): backward on loss * S with
+        # apex's initial scale, on the HIP path and in the storage emulation alike; gradients compared un-scaled
+        from util import ACT_DTYPE
+        S = 65536.0 if (ACT_DTYPE == torch.float16 and type(backend).__name__ != "OracleBackend") else 1.0
+        if S != 1.0:
+            print("loss scale %d (%s)" % (S, type(backend).__name__))
+            if device != "cpu":
+                from semseg_amd import hip_backend
+                hip_backend.enable_fp16_training()      # (the scaler's un-scaling is done by hand below)
+        (loss * S).backward()
         if device != "cpu":
             torch.cuda.synchronize()
-        grads = {n: p.grad.detach().float().cpu() for n, p in net.named_parameters() if p.grad is not None}
+        grads = {n: p.grad.detach().float().cpu() / S for n, p in net.named_parameters() if p.grad is not None}
         stats = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if "running_" in k}
         return float(loss.detach()), grads, stats
     finally:

@@ -65,10 +65,16 @@ def test_teacher_forced_ops_at_1024():
     ops._set_backend_for_tests(tb)
     hb.clear_pack_cache()
     hb.profile_begin()
+    # fp16 storage (tests/test_amp_fp16_gpu.py, SSA_ACT_DTYPE=fp16): the backward pass starts from the loss scale, as
+    # amp.scale_loss makes it -- the teacher's gradients (rounded to fp16 like the HIP path's) would flush otherwise
+    from util import ACT_DTYPE
+    S = 65536.0 if ACT_DTYPE == torch.float16 else 1.0
+    if S != 1.0:
+        hb.enable_fp16_training()
     try:
         loss = cpu_net({"images": images, "gts": gts})
         n_fwd = tb.rec.n_ops
-        loss.backward()
+        (loss * S).backward()
         torch.cuda.synchronize()
     finally:
         kernels = hb.profile_end()
