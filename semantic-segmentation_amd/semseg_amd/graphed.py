@@ -119,6 +119,12 @@ class GraphedTrainStep:
             try:
                 ent = self._capture(inputs)
             except Exception as e:          # noqa: BLE001 -- whatever refused the capture: run the same step eagerly
+                # ... on ONE rank only.  With several ranks a capture that raised on this rank (possibly half way through
+                # the warm-up steps' collectives) has already left the ranks' collective sequences out of step: falling
+                # back to eager launches here while the others replay a graph would hang the job instead of failing it.
+                if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                        torch.distributed.get_world_size() > 1:
+                    raise
                 self.eager_only = True
                 print("semseg_amd.graphed: hipGraph capture of the training step failed (%s: %s); the loop goes on with "
                       "eager launches of the same step" % (type(e).__name__, str(e)[:300]), file=sys.stderr, flush=True)
@@ -152,6 +158,12 @@ class _GraphedNet(nn.Module):
         self._modules = net._modules
         self._parameters = net._parameters
         self._buffers = net._buffers
+        # ... and the rest of the state the (load_)state_dict machinery consults: which buffers are non-persistent, the
+        # hooks registered on the wrapped net
+        for name in ("_non_persistent_buffers_set", "_state_dict_hooks", "_state_dict_pre_hooks",
+                     "_load_state_dict_pre_hooks", "_load_state_dict_post_hooks"):
+            if hasattr(net, name):
+                object.__setattr__(self, name, getattr(net, name))
         self.training = net.training
 
     @property
@@ -174,6 +186,14 @@ class _GraphedNet(nn.Module):
             return super().__getattr__(name)
         except AttributeError:
             return getattr(object.__getattribute__(self, "_net"), name)     # .module of the data-parallel wrapper etc.
+
+    def __setattr__(self, name, value):
+        # plain attributes set through the proxy (net.foo = x) belong to the wrapped net; tensors / modules go through
+        # nn.Module's registration, which lands in the SHARED dictionaries
+        if name == "training" or isinstance(value, (torch.Tensor, nn.Module)) or name.startswith("_"):
+            super().__setattr__(name, value)
+        else:
+            setattr(object.__getattribute__(self, "_net"), name, value)
 
 
 class _GraphedOptim:

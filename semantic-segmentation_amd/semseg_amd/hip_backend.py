@@ -594,7 +594,7 @@ def _tile_p_wgs(d, units):
 
 
 @contextlib.contextmanager
-def tile_strip(descs, mode=0):
+def tile_strip(descs):
     """Strip length of the persistent conv kernel for a level whose 3x3 problems are `descs` (those the kernel does
     not take count for nothing): the SHORTEST strips whose workgroups all fit on the chip at once (three per CU;
     a level of more workgroups than slots runs as two rounds: profiles/r03_notes.md call D, r04_notes.md call C).
@@ -1401,7 +1401,7 @@ class BasicBlockGroupFn(torch.autograd.Function):
         # ---- conv2 data gradient; its epilogue accumulates bn1's backward sums where it runs on the tile kernel
         da1 = {}
         sums1 = {}
-        with tile_strip(descs_bwd, mode=2), group():
+        with tile_strip(descs_bwd), group():
             for k, i in enumerate(act):
                 x, y1, a1, y2, out, c1, c2, w1, w2, g1, g2 = S[i]
                 dy2 = r2[k][0]

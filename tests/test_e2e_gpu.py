@@ -85,7 +85,6 @@ def _run(backend, sd, images, gts, train, device="cpu"):
             with torch.no_grad():
                 out = net(inputs)
             return {k: v.float().cpu() for k, v in out.items()}
-        loss = net(inputs)
         # fp16 storage (tests/test_amp_fp16_gpu.py runs this file with SSA_ACT_DTYPE=fp16): backward on loss * S with
         # apex's initial scale, on the HIP path and in the storage emulation alike; gradients compared un-scaled
         from util import ACT_DTYPE
@@ -95,6 +94,7 @@ def _run(backend, sd, images, gts, train, device="cpu"):
             if device != "cpu":
                 from semseg_amd import hip_backend
                 hip_backend.enable_fp16_training()      # (the scaler's un-scaling is done by hand below)
+        loss = net(inputs)
         (loss * S).backward()
         if device != "cpu":
             torch.cuda.synchronize()
