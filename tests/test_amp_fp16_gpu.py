@@ -226,7 +226,7 @@ assert all(l == l and abs(l) < 1e4 for l in losses), losses
 assert not torch.equal(net.wrapped.backbone.conv1.weight.detach(), w0), "every step was skipped"
 assert 8.0 <= sc.loss_scale() <= 65536.0, sc.loss_scale()
 assert losses[-1] < losses[0], losses
-skipped = sum(1 for a, b in zip(losses, losses[1:]) if a == b)
+skipped = sum(1 for a, b in zip(losses, losses[1:]) if abs(a - b) <= 2e-6 * abs(a))   # (same weights: equal to fp64-atomics noise)
 print("SKIPPED", skipped)
 assert skipped == round(16 - __import__("math").log2(sc.loss_scale())), (skipped, sc.loss_scale())   # one halving per skipped step
 assert net._stepper.replays == 14
