@@ -315,6 +315,23 @@ def main():
     ips = args.batch * world * args.steps / dt
     flop_scale = (args.crop / 1024.0) * (crop_w / 1024.0)
 
+    # What one SyncBN exchange costs on THIS job's communicator: 200 back-to-back in-place all-reduces of a level-sized
+    # fp64 record (8 replicas x 2 x 720 channels) on the compute stream, all ranks together; x the step's collective
+    # count = the time the step spends in exchanges no compute hides (they sit on the critical path of the level chain).
+    coll_us = None
+    if dist_on and backend == "nccl" and rccl.ENABLED:
+        rec = torch.zeros(8 * 2 * 720, dtype=torch.float64, device="cuda")
+        c_ = rccl.comm(0)
+        for _ in range(20):
+            c_.all_reduce_(rec)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            c_.all_reduce_(rec)
+        sync()
+        coll_us = (time.perf_counter() - t0) / 200 * 1e6
+        c_.calls -= 220
+
     roof = None
     recs = []
     if not args.no_roofline:
@@ -437,6 +454,10 @@ def main():
                        # the captured step); None = on the compute stream at the end of backward
                        "wgrad_side_stream_flush_at": hb._WGRAD_FLUSH_AT if hb._WGRAD_SIDE else None,
                        "collectives_per_step": collectives_per_step,
+                       # measured on this job's ranks (above): one level-sized fp64 all-reduce, and that x the count
+                       "syncbn_collective_us": coll_us,
+                       "collective_ms_per_step": (coll_us * collectives_per_step / 1e3)
+                       if (coll_us is not None and collectives_per_step) else None,
                        # gradient exchange: ranges of the arena are all-reduced on a communication stream while backward
                        # runs; what no compute can hide is the LAST range -- estimate = its bytes x 2 (ring all-reduce
                        # traffic per rank) / 300 GB/s of xGMI per GPU

@@ -42,7 +42,8 @@ LOSS_TOL = (1e-4, 1e-4)
 # running statistics an eval-mode random-weight network grows |x| to 1e3 over 300 layers, q.k^T reaches 1e8
 # and both OCR softmaxes are one-hot everywhere: the attention then selects a row of V by an argmax that
 # fp32 summation order decides -- a flake by construction.  The harness refuses that regime loudly.
-MAX_MEAN_ABS = 50.0             # mean |x| of every floating-point operand of every op
+MAX_MEAN_ABS = 200.0            # mean |x| of every floating-point operand of every op (ResNet-50 stacks reach ~50; the
+                                # degenerate regime of round 4 sat at 1e3 and rising)
 MAX_SOFTMAX_PEAK = 0.9          # median (over pixels / classes) of the largest softmax probability, OCR ops
 
 

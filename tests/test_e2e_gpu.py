@@ -269,8 +269,3 @@ def test_eval_nscale(setup):
     mh, me = sum(eh_all.values()) / len(eh_all), sum(ee_all.values()) / len(ee_all)
     print("nscale mean over the outputs: hip %.4f emu %.4f" % (mh, me))
     assert mh <= 1.25 * me + 5e-3, (mh, me)
-
-
-def test_smoke_entry():
-    import __graft_entry__ as g
-    g.smoke()

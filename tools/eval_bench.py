@@ -81,6 +81,12 @@ if __name__ == "__main__":
         run("configs[4] Mapillary-sized {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], H, W, iters,
             classes=65)
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "mapillary-ref":
+        # the reference's own recipe, scripts/eval_mapillary.yml:13-18: pre_size 2177 (a 4:3 Mapillary image becomes
+        # 1632 x 2177), n_scales 0.25,0.5,1.0,2.0 (the 2.0x pass is 3264 x 4354 = 14.2 Mpixel), fp16 -- on ONE GPU
+        run("configs[4] eval_mapillary.yml: pre_size 2177, {0.25,0.5,1.0,2.0}", "ocrnet.HRNet_Mscale",
+            [0.25, 0.5, 1.0, 2.0], 1632, 2177, iters, classes=65)
+        sys.exit(0)
     run("configs[1] HRNet-OCR single-scale eval", "ocrnet.HRNet", None, 1024, 2048, iters)
     run("configs[2] HRNet-OCR-MScale {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1024, 2048, iters)
     run("configs[4] Mapillary 65 classes {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1536, 2048, iters,
