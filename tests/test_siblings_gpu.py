@@ -48,7 +48,9 @@ def _with_backend(backend, fn):
         cfg.MODEL.N_SCALES = None
 
 
-@pytest.mark.parametrize("name", NAMES)
+# (ocrnet.HRNet -- the plain OCR network, a SIBLING only in the CPU wiring pins -- is the model of
+# tests/test_parity_eval_gpu.py::test_eval_hrnet_ocr_single_scale_1024x2048 and of every HRNet_Mscale scale pass)
+@pytest.mark.parametrize("name", [n for n in NAMES if n != "ocrnet.HRNet"])
 def test_sibling_eval_op_by_op(name):
     from semseg_amd import ops
     from oracle_backend import OracleBackend
