@@ -58,6 +58,7 @@ template <int CX, int MB, int NBW>
 struct ConvWgradTile {
   typedef WgradTileArgs Args;
   static constexpr int NT = 256;
+  static constexpr int MAXJOBS = 32;     // (group.h: twice the default -- the strips get longer, the partials fewer)
   static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
   const bf16_t* __restrict__ x = a.x;
   const bf16_t* __restrict__ dy = a.dy;

@@ -31,11 +31,18 @@ namespace ssa {
 
 constexpr int kKernargBudget = 3840;   // bytes of kernel arguments a grouped launch may use
 
+// A kernel struct may declare  static constexpr int MAXJOBS  = the most problems one of its grouped launches carries
+// (default 16; the weight-gradient tile kernel takes 32: twice the layers per launch = strips twice as long at the same
+// workgroup count = half the fp32 partials its reduce has to read back).
+template <class K, class = void> struct MaxJobs { static constexpr int value = 16; };
+template <class K> struct MaxJobs<K, std::void_t<decltype(K::MAXJOBS)>> { static constexpr int value = K::MAXJOBS; };
+
 template <class K>
 struct GroupLimits {
   static constexpr int per_job = (int)sizeof(typename K::Args) + 8;
   static constexpr int raw = (kKernargBudget - 16) / per_job;
-  static constexpr int jobs = raw > 16 ? 16 : (raw < 1 ? 1 : raw);
+  static constexpr int cap = MaxJobs<K>::value;
+  static constexpr int jobs = raw > cap ? cap : (raw < 1 ? 1 : raw);
 };
 
 template <class K>
@@ -94,6 +101,7 @@ struct GroupState {
 
 GroupState& group_state();      // per host thread (forward: main thread, backward: autograd thread)
 void count_launches(int n);     // library-wide launch counter (ssa_launch_count)
+int runtime_job_cap();          // SSA_GROUP_JOBS (default 32): run-time bound on the problems per grouped launch
 
 template <class K>
 int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
@@ -108,7 +116,7 @@ int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
 template <class K>
 int flush_bucket(Bucket& b, hipStream_t s) {
   typedef typename K::Args Args;
-  constexpr int J = GroupLimits<K>::jobs;
+  const int J = GroupLimits<K>::jobs < runtime_job_cap() ? GroupLimits<K>::jobs : runtime_job_cap();
   static size_t lds_single = 0, lds_grouped = 0;
   const int n = (int)b.gx.size();
   for (int j0 = 0; j0 < n; j0 += J) {

@@ -763,11 +763,13 @@ _WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
 # workgroup slots a weight-gradient launch is fitted to: 512 = two 64 KB workgroups per CU (the whole chip);
 # 256 = one per CU, which leaves every CU 96 KB of LDS and half its registers for the main stream's kernels
 _WGRAD_SLOTS = int(os.environ.get("SSA_WGRAD_SLOTS", "512"))
+# layers (problems) per grouped weight-gradient launch: csrc/group.h MAXJOBS of ConvWgradTile, bounded by SSA_GROUP_JOBS
+_WGRAD_GROUP = min(32, max(1, int(os.environ.get("SSA_GROUP_JOBS", "32"))))
 
 
 def _fit_tile_strips(jobs, strip):
     """Strip length (128-pixel tiles per workgroup) of the halo-staged weight-gradient launches, per launch: a grouped
-    launch carries up to 16 layers of one instantiation (csrc/group.h) and its workgroups are persistent, so a launch
+    launch carries up to 32 layers of one instantiation (csrc/group.h MAXJOBS) and its workgroups are persistent, so a launch
     of 552 or 640 workgroups runs as a full round on the chip's 512 slots (two 64 KB workgroups per CU) plus a tail
     round of the same length -- 96-105 us where 480 workgroups take 76 (profiles/r04_notes.md).  For every launch
     pick the strip length in [strip, 2*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
@@ -783,10 +785,12 @@ def _fit_tile_strips(jobs, strip):
         tiles = B * ((W + 31) // 32) * ((H + 3) // 4)
         groups.setdefault(min(Cin, 96), []).append((j, tiles, parts))
     for lst in groups.values():
-        for i in range(0, len(lst), 16):
-            chunk = lst[i:i + 16]
+        for i in range(0, len(lst), _WGRAD_GROUP):
+            chunk = lst[i:i + _WGRAD_GROUP]
             best = None
-            for s_ in range(strip, (2 if _WGRAD_SLOTS >= 512 else 6) * strip + 1):
+            # (twice the layers per launch want strips up to twice as long for the same workgroup count: that is the
+            # point -- a layer's fp32 partials, one block per workgroup, halve, and so does what WgradReduceK reads)
+            for s_ in range(strip, (2 if (_WGRAD_SLOTS >= 512 and _WGRAD_GROUP <= 16) else 6) * strip + 1):
                 wgs = sum(-(-t // s_) * p for _, t, p in chunk)
                 cost = -(-wgs // _WGRAD_SLOTS) * (s_ + 2.0)
                 if best is None or cost < best[0] - 1e-9:

@@ -302,6 +302,51 @@ def test_wgrad_tile_kernel(C, B, H, W):
     check_close("wgrad tile C=%d" % C, dw, w.grad, 2e-3, 5e-4)
 
 
+def test_wgrad_tile_grouped_launch_of_twenty_layers():
+    """One grouped launch carries up to 32 weight-gradient problems (csrc/group.h MAXJOBS of ConvWgradTile; 16 for every
+    other kernel): twenty 48-channel layers of different sizes inside one bracket -> ONE tile launch, one reduce launch
+    per 16 parameters, every layer's gradient against the oracle."""
+    import ctypes
+    from oracle import ops as O
+    from semseg_amd._lib import lib, check, ConvDesc
+    hb = _hb()
+    C, n = 48, 20
+    L = lib()
+    P = ctypes.c_void_p
+    keep, want = [], []
+    plans = []
+    for i in range(n):
+        H, W = 5 + (i % 4) * 3, 33 + 7 * (i % 3)
+        x = _rand(1, C, H, W, seed=300 + i)
+        gy = _rand(1, C, H, W, seed=400 + i)
+        w = torch.zeros(C, C, 3, 3, requires_grad=True)
+        O.conv2d(x, w, None, 1, 1, 1).backward(gy)
+        want.append(w.grad)
+        xd, gd = _to_dev_nhwc(x), nhwc(gy).to(DEV).to(ACT_DTYPE).contiguous()
+        d = ConvDesc(1, H, W, C, C, H, W, C, C, 3, 3, 1, 1, 1, 0, 0, 0, 2)        # strips of 2 tiles: several partials
+        ns, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        check(L.ssa_conv2d_wgrad_tile_plan(ctypes.byref(d), C, ctypes.byref(ns), ctypes.byref(ws)), "plan")
+        part = torch.empty(ws.value // 4, dtype=torch.float32, device=DEV)
+        dw = torch.empty(C, C, 3, 3, dtype=torch.float32, device=DEV)
+        keep += [xd, gd, part]
+        plans.append((d, xd, gd, ns.value, part, dw))
+    L.ssa_launch_count(1)
+    with hb.group():
+        for d, xd, gd, ns, part, dw in plans:
+            check(L.ssa_conv2d_wgrad_tile(ctypes.byref(d), P(xd.data_ptr()), P(gd.data_ptr()), C, C, ns,
+                                          P(part.data_ptr()), None), "ssa_conv2d_wgrad_tile")
+    n_tile = L.ssa_launch_count(1)
+    with hb.group():
+        for d, xd, gd, ns, part, dw in plans:
+            check(L.ssa_conv2d_wgrad_reduce(P(part.data_ptr()), ns, C, C, C, C, 3, 3, P(dw.data_ptr()), 0, None),
+                  "ssa_conv2d_wgrad_reduce")
+    n_red = L.ssa_launch_count(1)
+    torch.cuda.synchronize()
+    assert n_tile == 1 and n_red == 2, (n_tile, n_red)
+    for i, (pl, ref) in enumerate(zip(plans, want)):
+        check_close("grouped wgrad layer %d" % i, pl[5], ref, 2e-3, 5e-4)
+
+
 @pytest.mark.parametrize("Cin,Cout,k,stride,H,W", [(48, 96, 3, 2, 50, 70), (64, 256, 1, 1, 33, 47), (96, 48, 1, 1, 20, 24)])
 def test_conv_bn_fused_stats_igemm(Cin, Cout, k, stride, H, W):
     """Same as test_conv_bn_fused_stats for the shapes that run on the K-pipelined igemm kernel
