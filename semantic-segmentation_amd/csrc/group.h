@@ -101,7 +101,7 @@ struct GroupState {
 
 GroupState& group_state();      // per host thread (forward: main thread, backward: autograd thread)
 void count_launches(int n);     // library-wide launch counter (ssa_launch_count)
-int runtime_job_cap();          // SSA_GROUP_JOBS (default 32): run-time bound on the problems per grouped launch
+
 
 template <class K>
 int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
@@ -116,7 +116,7 @@ int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
 template <class K>
 int flush_bucket(Bucket& b, hipStream_t s) {
   typedef typename K::Args Args;
-  const int J = GroupLimits<K>::jobs < runtime_job_cap() ? GroupLimits<K>::jobs : runtime_job_cap();
+  constexpr int J = GroupLimits<K>::jobs;
   static size_t lds_single = 0, lds_grouped = 0;
   const int n = (int)b.gx.size();
   for (int j0 = 0; j0 < n; j0 += J) {

@@ -19,14 +19,6 @@ GroupState& group_state() {
 static std::atomic<long> g_launches{0};
 void count_launches(int n) { g_launches.fetch_add(n, std::memory_order_relaxed); }
 
-int runtime_job_cap() {
-  static const int cap = [] {
-    const char* v = getenv("SSA_GROUP_JOBS");
-    const int c = v ? atoi(v) : 32;
-    return c < 1 ? 1 : c;
-  }();
-  return cap;
-}
 
 // ---- per-launch profile
 struct ProfRec { const char* kernel; hipEvent_t e0, e1; int jobs; double flops, bytes; };

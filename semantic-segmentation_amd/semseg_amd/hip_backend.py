@@ -763,8 +763,7 @@ _WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
 # workgroup slots a weight-gradient launch is fitted to: 512 = two 64 KB workgroups per CU (the whole chip);
 # 256 = one per CU, which leaves every CU 96 KB of LDS and half its registers for the main stream's kernels
 _WGRAD_SLOTS = int(os.environ.get("SSA_WGRAD_SLOTS", "512"))
-# layers (problems) per grouped weight-gradient launch: csrc/group.h MAXJOBS of ConvWgradTile, bounded by SSA_GROUP_JOBS
-_WGRAD_GROUP = min(32, max(1, int(os.environ.get("SSA_GROUP_JOBS", "32"))))
+_WGRAD_GROUP = 32       # layers (problems) per grouped weight-gradient launch: csrc/group.h MAXJOBS of ConvWgradTile
 
 
 def _fit_tile_strips(jobs, strip):

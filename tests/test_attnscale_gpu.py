@@ -28,15 +28,11 @@ def test_attnscale_teacher_forced(name, scales, training):
         if k.startswith("scale_attn") and k.endswith("6.weight"):
             sd[k].mul_(0.05)                   # keep the sigmoid attention away from exact 0 (0/0 in the normalisation)
     images, gts = _synth(2, 128, 192, seed=17)
-    if not training:                           # eval: BN running statistics calibrated on this batch first
-        from oracle_backend import OracleBackend
-        from test_siblings_cpu import calibrate
-        prev0 = ops._BACKEND
-        ops._set_backend_for_tests(OracleBackend())
-        try:
-            calibrate(cpu_net, {"images": images, "gts": gts})
-        finally:
-            ops._set_backend_for_tests(prev0)
+    if not training:
+        # eval: BN running statistics calibrated on this batch first, POOLED over the three scale passes (the statistics
+        # of one pass put the others' activations at several hundred by layer4: tests/test_parity_eval_gpu.py)
+        from test_parity_eval_gpu import calibrate_eval_bn
+        calibrate_eval_bn(cpu_net, images, "cpu")
     hip_net = copy.deepcopy(cpu_net).cuda().train(training)
     tb = TeacherBackend(cpu_net, hip_net)
     prev = ops._BACKEND

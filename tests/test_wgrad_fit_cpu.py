@@ -31,7 +31,7 @@ def test_a_launch_of_ten_48_channel_layers_fits_one_round():
 
 
 def test_launches_are_fitted_separately_and_other_jobs_left_alone():
-    G = hb._WGRAD_GROUP                                  # layers per grouped launch (csrc/group.h MAXJOBS, SSA_GROUP_JOBS)
+    G = hb._WGRAD_GROUP                                  # layers per grouped launch (csrc/group.h MAXJOBS)
     a = [_J(96, 128, 128) for _ in range(G)]            # one launch of the 96-channel instantiation
     b = [_J(96, 64, 64) for _ in range(4)]              # the next one: 4 x 5 x 3 = 60 at strips of 8
     odd = _J(48, 256, 256)

@@ -12,9 +12,9 @@ for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
 import torch  # noqa: E402
 from semseg_amd import hip_backend as hb  # noqa: E402
 
-if "--timing" in sys.argv or "--timing-q" in sys.argv or "--lib" in sys.argv:
+if "--timing" in sys.argv or "--lib" in sys.argv:
     from semseg_amd import _lib
-    _name = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else ("timingq" if "--timing-q" in sys.argv else "timing")
+    _name = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else "timing"
     _lib.LIB_PATH = _lib.LIB_PATH.replace("libsemseg_hip.so", "libsemseg_hip_%s.so" % _name)
 L = hb.lib()
 DEV = "cuda"
@@ -30,8 +30,6 @@ class Prob:
         self.aux = torch.randn(1, H, W, C, generator=g).to(DEV).to(torch.bfloat16)
         self.w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
         self.wp, _ = hb._packed_filter(self.w, 2, C, 0)
-        self.wq, _ = hb._packed_filter(self.w, 10, C, 0)       # fragment order of conv_tile_q.hip
-        self.yq = torch.empty(1, H, W, C, device=DEV, dtype=torch.bfloat16)
         self.y = torch.empty(1, H, W, C, device=DEV, dtype=torch.bfloat16)
         self.stats = torch.zeros(hb.stat_replicas() * 2 * C, device=DEV, dtype=torch.float64)
         self.xf = torch.rand(5, C, device=DEV) + 0.5
@@ -48,13 +46,6 @@ class Prob:
         hb.check(L.ssa_conv2d_tile_p(ctypes.byref(self.d), P(self.x), P(self.wp), None, P(self.y), P(st),
                                      P(self.aux) if aux else None, self.C, P(self.coef) if aux == 2 else None, aux, hb._s()),
                  "tile_p")
-
-
-    def q(self, aux=0):
-        st = None if aux == 1 else self.stats
-        hb.check(L.ssa_conv2d_tile_q(ctypes.byref(self.d), P(self.x), P(self.wq), P(self.yq), P(st),
-                                     P(self.aux) if aux else None, self.C, P(self.coef) if aux == 2 else None, aux, hb._s()),
-                 "tile_q")
 
 
 def timeit(fn, reps):
@@ -163,94 +154,8 @@ def timing():
     L.ssa_conv_tile_strip(0)
 
 
-def main_q():
-    """conv_tile_q.hip (opt-in geometry) against conv_tile_p.hip: every problem alone, the 8- and 4-problem levels by
-    MFMA budget per workgroup; outputs compared element-wise first.  SSA_TILE_Q_PB=4|2|1 forces the wave shape."""
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
-    level = [(48, 256, 256), (48, 128, 128), (96, 128, 128), (96, 64, 64), (192, 64, 64), (192, 32, 32), (384, 32, 32), (384, 16, 16)]
-    probs = [Prob(C, H, W, i) for i, (C, H, W) in enumerate(level)]
-    three = "--three" in sys.argv          # the three-workgroups-per-CU form (ssa_conv_tile_q_config(1))
-    L.ssa_conv_tile_q_config(1 if three else 0)
-    print("wave shapes forced: SSA_TILE_Q_PB=%s; three workgroups per CU: %s" % (os.environ.get("SSA_TILE_Q_PB", "-"), three))
-    print("%-16s %8s | %-44s | max |q - p| / max |p|" % ("problem", "p us", "q us by budget: auto " + " ".join("%6d" % b for b in (8, 16, 32, 64))))
-    for p in probs:
-        p.new()
-        p.q()
-        torch.cuda.synchronize()
-        err = float((p.yq.float() - p.y.float()).abs().max() / p.y.float().abs().max())
-        t_p = timeit(p.new, reps)
-        row = [timeit(p.q, reps)]
-        for b in (8, 16, 32, 64):
-            L.ssa_conv_tile_q_strip(b)
-            row.append(timeit(p.q, reps))
-        L.ssa_conv_tile_q_strip(0)
-        print("%3d @ %3dx%-3d   %8.1f | %s | %.2e   (%.0f TF/s at best; %d workgroups auto)" % (
-            p.C, p.H, p.W, t_p, " ".join("%7.1f" % t for t in row), err, p.flops / min(row) / 1e6,
-            L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), 0, 0)))
-    fl = sum(p.flops for p in probs)
-    by = sum(p.bytes for p in probs)
-
-    def level_p(ps=probs, aux=0):
-        with hb.group():
-            for p in ps:
-                p.new(aux)
-
-    def level_q(ps=probs, aux=0):
-        with hb.group():
-            for p in ps:
-                p.q(aux)
-    L.ssa_conv_tile_strip(10)
-    t = timeit(level_p, reps)
-    print("level (8 problems, %.1f GFLOP, %.1f MB): p (strip units 10) %.1f us = %.0f TF/s" % (fl / 1e9, by / 1e6, t, fl / t / 1e6))
-    best = (1e9, 8)
-    for b in (4, 8, 12, 16, 24, 32, 48, 64):
-        L.ssa_conv_tile_q_strip(b)
-        t = timeit(level_q, reps)
-        best = min(best, (t, b))
-        print("   q, budget %2d (%4d workgroups): %.1f us = %.0f TF/s, %.0f GB/s" % (
-            b, sum(L.ssa_conv_tile_q_wgs(ctypes.byref(p.d), b, 0) for p in probs), t, fl / t / 1e6, by / t / 1e3))
-    L.ssa_conv_tile_q_strip(best[1])
-    for aux in (2, 1):
-        print("   q budget %d, aux %d: %.1f us   (p: %.1f us)" % (best[1], aux, timeit(lambda: level_q(aux=aux), reps),
-                                                                 timeit(lambda: level_p(aux=aux), reps)))
-    L.ssa_conv_tile_strip(2)
-    print("   stage-2 level (4 problems): p (strip units 2) %.1f us" % timeit(lambda: level_p(probs[:4]), reps))
-    for b in (4, 8, 16, 32):
-        L.ssa_conv_tile_q_strip(b)
-        print("   stage-2 level (4 problems): q budget %2d: %.1f us" % (b, timeit(lambda: level_q(probs[:4]), reps)))
-    L.ssa_conv_tile_strip(0)
-    L.ssa_conv_tile_q_strip(0)
-
-
-def timing_q():
-    """Phase stamps (s_memtime) of wave 0 of workgroup 0 of conv_tile_q.hip from the -DSSA_TILE_TIMING build
-    (sh tools/expbuild.sh timingq conv_tile_q.hip -DSSA_TILE_TIMING)."""
-    names = ["start", "staged", "barY", "issued", "mfma0", "bar0", "mfma1+bar", "epilogue"]
-    for (C, H, W), budget in (((48, 256, 256), 32), ((96, 128, 128), 32), ((192, 64, 64), 32), ((384, 32, 32), 32), ((48, 256, 256), 4)):
-        p = Prob(C, H, W, 1)
-        dbg = torch.zeros(24 * 8, dtype=torch.int64, device=DEV)
-        L.ssa_conv_tile_q_strip(budget)
-        for _ in range(3):
-            hb.check(L.ssa_conv2d_tile_q(ctypes.byref(p.d), P(p.x), P(p.wq), P(p.yq), P(p.stats), None, C, P(dbg), 0, hb._s()), "tile_q")
-        torch.cuda.synchronize()
-        t = dbg.cpu().view(24, 8)
-        print("== %d @ %dx%d budget %d (SSA_TILE_Q_PB=%s): stamps in ticks of s_memtime relative to the unit's start" % (
-            C, H, W, budget, os.environ.get("SSA_TILE_Q_PB", "-")))
-        print("   it " + " ".join("%9s" % n for n in names) + "   next-start")
-        for i in range(24):
-            if int(t[i, 0]) == 0:
-                break
-            nxt = int(t[i + 1, 0]) - int(t[i, 0]) if i + 1 < 24 and int(t[i + 1, 0]) else -1
-            print("   %2d " % i + " ".join("%9d" % (int(t[i, k]) - int(t[i, 0])) for k in range(8)) + "   %d" % nxt)
-    L.ssa_conv_tile_q_strip(0)
-
-
 if __name__ == "__main__":
-    if "--timing-q" in sys.argv:
-        timing_q()
-    elif "--q" in sys.argv:
-        main_q()
-    elif "--timing" in sys.argv:
+    if "--timing" in sys.argv:
         timing()
     else:
         main()
