@@ -1058,13 +1058,56 @@ def _allreduce_sums(sums_list):
 
 class BnMeta:
     """Non-tensor description of one BatchNorm call (built by the operator surface)."""
-    __slots__ = ("momentum", "eps", "training", "relu", "sync", "pass_stats", "running_mean", "running_var", "nbt")
+    __slots__ = ("momentum", "eps", "training", "relu", "sync", "pass_stats", "running_mean", "running_var", "nbt", "out")
 
     def __init__(self, momentum, eps, training, relu, sync, pass_stats, running_mean, running_var, nbt=None):
         # training: running_mean/var/nbt given = updated by the normalisation kernel itself (one pass
         # per layer and step only); pass_stats given = deferred to ssa_bn_update_running_batched
         self.momentum, self.eps, self.training, self.relu, self.sync = momentum, eps, training, relu, sync
         self.pass_stats, self.running_mean, self.running_var, self.nbt = pass_stats, running_mean, running_var, nbt
+        self.out = None       # where z goes: a [B,H,W,C] channel slice of a wider buffer (ops.cat_slots), else a new tensor
+
+
+def _bn_out(m, shape, device):
+    """(z, pixel stride of z) for a BatchNorm call: the caller's slot, or a fresh dense tensor."""
+    if m.out is None:
+        return torch.empty(shape, dtype=ACT_DTYPE, device=device), shape[3]
+    z = m.out
+    assert tuple(z.shape) == tuple(shape) and z.dtype == ACT_DTYPE and z.stride(3) == 1 and z.stride(2) % 8 == 0 and \
+        z.stride(1) == shape[2] * z.stride(2) and z.stride(0) == shape[1] * z.stride(1) and z.data_ptr() % 16 == 0, \
+        "output slot does not fit the result"
+    return z, z.stride(2)
+
+
+def adjacent_slices(a, b):
+    """a and b are neighbouring channel slices [.., :Ca] / [.., Ca:Ca+Cb] of one NHWC buffer whose pixels are exactly
+    Ca + Cb wide (what ops.cat_slots hands out)."""
+    if not (a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype and a.shape[:3] == b.shape[:3]):
+        return False
+    ld = a.shape[3] + b.shape[3]
+    try:
+        same = a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+    except Exception:       # noqa: BLE001
+        return False
+    return same and a.stride() == b.stride() and a.stride(3) == 1 and a.stride(2) == ld and \
+        a.stride(1) == a.shape[2] * ld and a.stride(0) == a.shape[1] * a.shape[2] * ld and \
+        b.storage_offset() == a.storage_offset() + a.shape[3]
+
+
+class CatViewFn(torch.autograd.Function):
+    """torch.cat((a, b), dim=3) for two tensors that already are neighbouring channel slices of one buffer: the dense
+    view of that buffer, no copy; backward = the two slices of the gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.split = a.shape[3]
+        B, H, W, Ca = a.shape
+        ld = Ca + b.shape[3]
+        return a.detach().as_strided((B, H, W, ld), (H * W * ld, W * ld, ld, 1), a.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., :ctx.split], g[..., ctx.split:]
 
 
 def _bn_take_stats(jobs):
@@ -1113,7 +1156,7 @@ def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts, masks=None):
             B, H, W, C = x.shape
             P = B * H * W
             coef = torch.empty((4, C), dtype=torch.float32, device=x.device)  # scale, shift, mean, invstd
-            z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=x.device)
+            z, ldz = _bn_out(m, (B, H, W, C), x.device)
             res, ldr = ress[i] if ress[i] is not None else (None, 0)
             mask = None
             if masks is not None and _BN_SIGN_MASK and m.relu and (res is not None or posts[i] is not None):
@@ -1121,7 +1164,7 @@ def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts, masks=None):
             if masks is not None:
                 masks.append(mask)
             _note(0.0, 2.0 * P * C * (2 + (1 if res is not None else 0)))
-            check(L.ssa_bn_apply_train(_p(x), ldxs[i], _p(res), ldr, _p(z), C, P, C, _p(stats[i][0]), stats[i][1],
+            check(L.ssa_bn_apply_train(_p(x), ldxs[i], _p(res), ldr, _p(z), ldz, P, C, _p(stats[i][0]), stats[i][1],
                                        counts[i], _p(gammas[i]), _p(betas[i]), _p(m.running_mean), _p(m.running_var),
                                        _p(m.nbt), float(m.momentum),
                                        float(m.eps), _p(coef), _p(m.pass_stats), int(m.relu), _p(posts[i]), H * W,
@@ -1260,9 +1303,9 @@ class BnActGroupFn(torch.autograd.Function):
                 for i in range(n):
                     x = xs[i]
                     B, H, W, C = x.shape
-                    z = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=x.device)
+                    z, ldz = _bn_out(metas[i], (B, H, W, C), x.device)
                     res, ldr = ress[i] if ress[i] is not None else (None, 0)
-                    check(L.ssa_bn_apply(_p(x), ldxs[i], _p(res), ldr, _p(z), C, B * H * W, C, _p(coefs[i][0]),
+                    check(L.ssa_bn_apply(_p(x), ldxs[i], _p(res), ldr, _p(z), ldz, B * H * W, C, _p(coefs[i][0]),
                                          _p(coefs[i][1]), int(metas[i].relu), _p(posts[i]), H * W, _s()), "ssa_bn_apply")
                     zs.append(z)
         # BN + ReLU without residual / mask: the backward recomputes the ReLU mask from x with the
@@ -1568,16 +1611,26 @@ def _dt(t):
     raise TypeError(t.dtype)
 
 
+_BILINEAR_ROWS = os.environ.get("SSA_BILINEAR_ROWS", "1") != "0"
+
+
 def _bilinear_bwd_group(jobs):
     """Backward of N bilinear resizes.  job = (dy_ptr, dy_dtype_code, lddy, B, Hi, Wi, C, Ho, Wo, dx).  Upsampling
     resizes (Ho >= 2 Hi and Wo >= 2 Wi) of 16-bit tensors with C % 8 == 0 -- the trunk's branch upsamples, 2x / 4x /
     8x -- run the separable form: all X passes of the level in one bracket, all Y passes in the next
-    (ssa_bilinear_bwd_x / _y; 607 -> 275 us per step).  The others take the one-pass gather: for the 19-channel fp32
-    logits the separable form measured SLOWER (scalar loads: 542 against 470 us per step, profiles/r04_notes.md)."""
+    (ssa_bilinear_bwd_x / _y; 607 -> 275 us per step).  Dense few-channel fp32 tensors (the 19 / 65-channel class logits,
+    4x and 2x to the crop) take the separable form as well since round 5: its per-element passes measured slower than
+    the gather on 76-byte pixels (round 4), the LDS-staged row pass + flat float4 row pass of csrc/resample.hip do not.
+    The others take the one-pass gather."""
     L = lib()
 
     def separable(j):
-        return j[1] == 0 and j[6] % 8 == 0 and j[2] % 8 == 0 and j[7] >= 2 * j[4] and j[8] >= 2 * j[5]
+        up = j[7] >= 2 * j[4] and j[8] >= 2 * j[5]
+        if j[1] == 0:
+            return j[6] % 8 == 0 and j[2] % 8 == 0 and up
+        # dense few-channel fp32 tensors (the class logits): gradient rows staged in LDS, flat float4 row pass
+        return _BILINEAR_ROWS and j[1] == 1 and up and j[2] == j[6] and j[6] <= 128 and (j[5] * j[6]) % 4 == 0 and \
+            j[9].dtype == torch.float32
     sep = [j for j in jobs if separable(j)]
     rest = [j for j in jobs if not separable(j)]
     tmps = []

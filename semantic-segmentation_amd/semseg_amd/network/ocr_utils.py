@@ -35,9 +35,10 @@ def _conv_bnrelu_stack(cin, cout, n):
     return nn.Sequential(*layers)
 
 
-def _run_stack(stack, x):
+def _run_stack(stack, x, out=None):
+    """conv-BN-ReLU stack; out: where the LAST layer's result goes (ops.cat_slots), default a new tensor."""
     for i in range(0, len(stack), 2):
-        x = conv_bn(stack[i], stack[i + 1][0], x, relu=True)
+        x = conv_bn(stack[i], stack[i + 1][0], x, relu=True, out=out if i + 2 >= len(stack) else None)
     return x
 
 
@@ -56,9 +57,9 @@ class ObjectAttentionBlock(nn.Module):
         self.f_down = _conv_bnrelu_stack(in_channels, key_channels, 1)
         self.f_up = _conv_bnrelu_stack(key_channels, in_channels, 1)
 
-    def forward(self, x, proxy):
+    def forward(self, x, proxy, out=None):
         """x / proxy: tensors, or lists of tensors (the scale passes; the 1x1 conv stacks then run
-        as grouped launches)."""
+        as grouped launches).  out: placement of the result (ops.cat_slots)."""
         B = ops.backend()
         q = _run_stack(self.f_pixel, x)                     # [B,H,W,D]
         k = _run_stack(self.f_object, proxy)                # [B,K,1,D]
@@ -68,7 +69,7 @@ class ObjectAttentionBlock(nn.Module):
             ctx = [B.ocr_attention(qi, ki.squeeze(2), vi.squeeze(2), scale) for qi, ki, vi in zip(q, k, v)]
         else:
             ctx = B.ocr_attention(q, k.squeeze(2), v.squeeze(2), scale)
-        return _run_stack(self.f_up, ctx)
+        return _run_stack(self.f_up, ctx, out=out)
 
 
 class SpatialOCR_Module(nn.Module):
@@ -91,11 +92,13 @@ class SpatialOCR_Module(nn.Module):
         keep = 1.0 - drop.p
         return (torch.rand(n, c, device=x.device) < keep).to(torch.float32) / keep
 
-    def forward(self, feats, proxy_feats, feats_cat=None):
+    def forward(self, feats, proxy_feats, feats_cat=None, context_out=None):
         """feats / proxy_feats: tensors, or lists of tensors (the scale passes).  feats_cat: a second handle of
-        `feats` for the concatenation (ops.fan_out, see OCR_block.forward); default: feats itself."""
+        `feats` for the concatenation (ops.fan_out, see OCR_block.forward); default: feats itself.  context_out: the
+        slot in front of feats' in a shared buffer (ops.cat_slots): torch.cat([context, feats], 1) of
+        network/ocr_utils.py:151 is then the buffer itself."""
         B = ops.backend()
-        context = self.object_context_block(feats, proxy_feats)
+        context = self.object_context_block(feats, proxy_feats, out=context_out)
         if feats_cat is None:
             feats_cat = feats
         if isinstance(feats, (list, tuple)):

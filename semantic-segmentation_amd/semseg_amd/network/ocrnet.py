@@ -60,12 +60,20 @@ class OCR_block(nn.Module):
         n = len(hl)
         pick = (lambda hs, j: [h[j] for h in hs]) if multi else (lambda hs, j: hs[0][j])
         hh = B.fan_out(hl, [2] * n)
-        feats = conv_bn(self.conv3x3_ocr[0], self.conv3x3_ocr[1][0], pick(hh, 0), relu=True)
+        # context and feats are written side by side into one buffer per scale pass: their concatenation in front of the
+        # 1x1 bottleneck (network/ocr_utils.py:151) is then that buffer (HIP backend; None elsewhere)
+        mid = self.conv3x3_ocr[0].out_channels
+        slots = B.cat_slots(hl, (mid, mid))
+        ctx_out = feats_out = None
+        if slots is not None:
+            ctx_out = [s_[0] for s_ in slots] if multi else slots[0][0]
+            feats_out = [s_[1] for s_ in slots] if multi else slots[0][1]
+        feats = conv_bn(self.conv3x3_ocr[0], self.conv3x3_ocr[1][0], pick(hh, 0), relu=True, out=feats_out)
         aux = conv_bn(self.aux_head[0], self.aux_head[1][0], pick(hh, 1), relu=True)
         aux_out = self.aux_head[2](aux, out_f32=True)              # [B,H,W,K] fp32
         fh = B.fan_out(list(feats) if multi else [feats], [3] * n)
         context = self.ocr_gather_head(pick(fh, 0), aux_out)
-        ocr_feats = self.ocr_distri_head(pick(fh, 1), context, feats_cat=pick(fh, 2))
+        ocr_feats = self.ocr_distri_head(pick(fh, 1), context, feats_cat=pick(fh, 2), context_out=ctx_out)
         oh = B.fan_out(list(ocr_feats) if multi else [ocr_feats], [2] * n)
         cls_out = self.cls_head(pick(oh, 0), out_f32=True)         # [B,H,W,K] fp32
         return cls_out, aux_out, pick(oh, 1)

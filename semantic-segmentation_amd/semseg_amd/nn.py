@@ -52,7 +52,7 @@ def BNReLU(ch):
     return nn.Sequential(Norm2d(ch), nn.ReLU())
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, post=None):
+def conv_bn(conv, bn, x, residual=None, relu=False, post=None, out=None):
     """conv -> norm (+ residual add, ReLU, Dropout2d mask) as one backend call, so
     the backend may fuse the batch statistics into the conv epilogue.
     `x` may be a LIST of independent problems (scale passes, resolution branches); `conv`, `bn`,
@@ -60,7 +60,9 @@ def conv_bn(conv, bn, x, residual=None, relu=False, post=None):
     and a list is returned (ops.BackendBase)."""
     for c in (conv if isinstance(conv, (list, tuple)) else (conv,)):
         assert c.groups == 1 and c.padding_mode == "zeros"
-    return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post)
+    if out is None:
+        return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post)
+    return ops.backend().conv_bn_act(conv, bn, x, residual, relu, post, out=out)      # (ops.cat_slots placement)
 
 
 def initialize_weights(*models):

@@ -43,7 +43,14 @@ class BackendBase:
         return [self._conv2d(xi, w, b, stride, padding, dilation, out_f32)
                 for xi, w, b in zip(x, _lst(weight, n), _lst(bias, n))]
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+    def cat_slots(self, like, widths):
+        """Output placement for a later `cat`: None here (the result is concatenated by a copy); the HIP backend hands
+        out channel slices of ONE buffer per problem of `like`, which `conv_bn_act(..., out=)` writes and `cat` then
+        recognises -- the concatenation costs nothing (SpatialOCR_Module: 2 x 134 MB per step at 1024 x 1024)."""
+        return None
+
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, out=None):
+        assert out is None, "output placement is the HIP backend's (cat_slots returns None here)"
         if not _is_list(x):
             return self._conv_bn_act(conv, bn, x, residual, relu, post)
         n = len(x)
@@ -146,30 +153,48 @@ class HipBackend(BackendBase):
         zs = self._bn_group(xs, _lst(bn, n), _lst(residual, n), _lst(relu, n), _lst(post, n))
         return zs if multi else zs[0]
 
-    def _bn_group(self, xs, bns, ress, relus, posts):
+    def _bn_group(self, xs, bns, ress, relus, posts, outs=None):
         metas = tuple(self._bn_meta(b, r) for b, r in zip(bns, relus))
+        if outs is not None:
+            for m, o in zip(metas, outs):
+                m.out = o
         flat = []
         for xi, b, r, po in zip(xs, bns, ress, posts):
             flat += [xi, b.weight, b.bias, r, po]
         return list(self.hb.BnActGroupFn.apply(metas, *flat))
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, out=None):
         """conv -> BatchNorm (+residual, ReLU, mask).  In training the conv epilogue accumulates
         the batch statistics, and the normalisation picks them up instead of re-reading the
-        conv output.  Lists = independent problems (grouped launches)."""
+        conv output.  Lists = independent problems (grouped launches).  out: where the result goes (a `cat_slots`
+        channel slice per problem) instead of a fresh tensor."""
         multi = _is_list(x)
         xs = list(x) if multi else [x]
-        zs = self._conv_bn_group(_lst(conv, len(xs)), _lst(bn, len(xs)), xs, residual, relu, post)
+        outs = None if out is None else (list(out) if multi else [out])
+        zs = self._conv_bn_group(_lst(conv, len(xs)), _lst(bn, len(xs)), xs, residual, relu, post, outs)
         return zs if multi else zs[0]
 
-    def _conv_bn_group(self, convs, bns, xs, residual=None, relu=False, post=None):
+    def cat_slots(self, like, widths):
+        multi = _is_list(like)
+        slots = []
+        for t in (like if multi else [like]):
+            B, H, W = t.shape[:3]
+            buf = torch.empty((B, H, W, sum(widths)), dtype=self.act_dtype, device=t.device)
+            views, off = [], 0
+            for w in widths:
+                views.append(buf[..., off:off + w])
+                off += w
+            slots.append(views)
+        return slots if multi else slots[0]
+
+    def _conv_bn_group(self, convs, bns, xs, residual=None, relu=False, post=None, outs=None):
         n = len(xs)
         spec = tuple((c.stride[0], c.padding[0], c.dilation[0], False, bool(b.training)) for c, b in zip(convs, bns))
         flat = []
         for xi, c in zip(xs, convs):
             flat += [xi, c.weight, c.bias]
         ys = self.hb.ConvGroupFn.apply(spec, *flat)
-        return self._bn_group(list(ys), bns, _lst(residual, n), _lst(relu, n), _lst(post, n))
+        return self._bn_group(list(ys), bns, _lst(residual, n), _lst(relu, n), _lst(post, n), outs)
 
     def basic_block(self, blocks, xs):
         ok = torch.is_grad_enabled() and all(
@@ -240,6 +265,8 @@ class HipBackend(BackendBase):
         return self.hb.GlobalAvgPoolFn.apply(x)
 
     def cat(self, tensors):
+        if len(tensors) == 2 and self.hb.adjacent_slices(tensors[0], tensors[1]):
+            return self.hb.CatViewFn.apply(tensors[0], tensors[1])      # both already lie in one buffer (cat_slots)
         return torch.cat(tensors, dim=3)      # pure data movement
 
     def to_act(self, x):

@@ -309,7 +309,8 @@ class TeacherBackend(BackendBase):
             xs, self._pp(*(ws + bs)), (F32_TOL if out_f32 else BF16_TOL, GRAD_TOL))
         return outs if multi else outs[0]
 
-    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None):
+    def conv_bn_act(self, conv, bn, x, residual=None, relu=False, post=None, out=None):
+        assert out is None                      # (cat_slots is the HIP backend's; this one returns None)
         multi = _is_list(x)
         xs = list(x) if multi else [x]
         n = len(xs)

@@ -354,3 +354,62 @@ def test_upsample_cat_equals_resize_then_cat():
     for ga, gb in zip(g_f, g_r):
         for a, b in zip(ga, gb):
             assert torch.equal(a.contiguous(), b.contiguous())
+
+
+# ----------------------------------------------------------------- concatenation without a copy (ops.cat_slots)
+@pytest.mark.parametrize("training", [True, False])
+def test_conv_bn_into_cat_slots_equals_torch_cat(training):
+    """SpatialOCR_Module's torch.cat([context, feats], 1) (network/ocr_utils.py:151): with ops.cat_slots the two
+    producers (conv + BatchNorm + ReLU, two scale passes as a list) write channel slices of ONE buffer per pass and the
+    concatenation is that buffer (hip_backend.CatViewFn) -- forward values, the consumer's output and every gradient
+    must equal the copying form bit for bit (same kernels, only the output pixel stride differs)."""
+    from semseg_amd import ops, nn as snn
+    hb = _hb()
+    be = ops.HipBackend()
+    torch.manual_seed(3)
+    ca, cb, cin = 24, 40, 32
+    shapes = [(1, 12, 20), (1, 6, 10)]                      # the 1.0x and the 0.5x pass
+    xs = [_rand(b, cin, h, w, seed=70 + i) for i, (b, h, w) in enumerate(shapes)]
+
+    def build():
+        torch.manual_seed(5)
+        convs = [snn.Conv2d(cin, ca, 1, bias=False), snn.Conv2d(cin, cb, 3, padding=1, bias=True),
+                 snn.Conv2d(ca + cb, 16, 1, bias=False)]
+        bns = [snn.BatchNorm2d(ca), snn.BatchNorm2d(cb), snn.BatchNorm2d(16)]
+        mods = torch.nn.ModuleList(convs + bns).to(DEV).train(training)
+        return mods[:3], mods[3:]
+
+    def run(use_slots):
+        convs, bns = build()
+        hb.clear_pack_cache()
+        hb.begin_step(torch.device(DEV))
+        xin = [_dev(x).requires_grad_(True) for x in xs]
+        slots = be.cat_slots(xin, (ca, cb)) if use_slots else None
+        a = be.conv_bn_act(convs[0], bns[0], xin, relu=True, **({"out": [s[0] for s in slots]} if slots else {}))
+        b = be.conv_bn_act(convs[1], bns[1], xin, relu=True, **({"out": [s[1] for s in slots]} if slots else {}))
+        cat = [be.cat([ai, bi]) for ai, bi in zip(a, b)]
+        if use_slots:
+            assert all(c.data_ptr() == s[0].data_ptr() and c.is_contiguous() for c, s in zip(cat, slots)), "a copy was made"
+        y = be.conv_bn_act(convs[2], bns[2], cat, relu=False)
+        be.end_forward()
+        outs = [t.detach().float().cpu() for t in list(a) + list(b) + list(cat) + list(y)]
+        grads = []
+        if training:
+            g = [_dev(_rand(*t.permute(0, 3, 1, 2).shape, seed=90 + i)) for i, t in enumerate(y)]
+            torch.autograd.backward(list(y), g)          # (the arena publishes the parameter gradients at its end)
+            if DEV == "cuda":
+                torch.cuda.synchronize()
+            grads = [t.grad.detach().float().cpu() for t in xin]
+            grads += [p.grad.detach().float().cpu() for m in list(convs) + list(bns) for p in m.parameters()
+                      if p.grad is not None]
+        elif DEV == "cuda":
+            torch.cuda.synchronize()
+        return outs, grads
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert len(o1) == len(o0) and len(g1) == len(g0) and (not training or len(g1) >= 2 + 5)
+    for i, (p, q) in enumerate(zip(o1, o0)):
+        assert torch.equal(p, q), ("forward tensor %d differs" % i, float((p - q).abs().max()))
+    for i, (p, q) in enumerate(zip(g1, g0)):
+        check_close("cat-slot gradient %d" % i, p, q, 1e-6, 1e-6)

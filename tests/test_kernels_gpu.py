@@ -556,7 +556,12 @@ def test_global_avg_pool():
 @pytest.mark.parametrize("C,hi,wi,ho,wo,f32", [(48, 16, 20, 64, 80, False), (96, 15, 9, 30, 18, False),
                                                (19, 32, 32, 128, 128, True), (1, 24, 40, 96, 160, True),
                                                (19, 64, 64, 32, 32, True), (192, 8, 8, 64, 64, False),
-                                               (19, 33, 45, 67, 91, True)])
+                                               (19, 33, 45, 67, 91, True),
+                                               # dense few-channel fp32 upsampling: the LDS-staged row pass of the separable
+                                               # backward (65 = Mapillary; rows of several segments at 2x and 4x; a ratio that
+                                               # is not an integer)
+                                               (65, 12, 20, 48, 80, True), (19, 6, 1100, 12, 2200, True),
+                                               (19, 5, 400, 20, 1600, True), (19, 8, 12, 21, 31, True)])
 def test_bilinear(C, hi, wi, ho, wo, f32):
     from oracle import ops as O
     hb = _hb()
