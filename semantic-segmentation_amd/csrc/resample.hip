@@ -397,78 +397,6 @@ struct BilinearBwdYK {
   }
 };
 
-// ---- the separable backward for DENSE few-channel fp32 tensors (the class logits [.., 19] / [.., 65] that the heads
-// upsample 4x and 2x to the crop: 80 MB of gradient per tensor at 1024 x 1024).  The per-element passes above read
-// 76-byte pixels with scalar loads (measured slower than the gather, round 4); here
-//   pass X: a workgroup stages a SEGMENT of one gradient row -- contiguous floats, pixel boundaries ignored, 16-byte
-//           loads -- in LDS and forms tmp[b, oy, ix, :] for the segment's input columns from there (bank = element index:
-//           consecutive (ix, c) of a wave fall in distinct banks); tmp is written with unit stride;
-//   pass Y: (ix, c) flattened is one contiguous vector per row, the row weights do not depend on it: float4 throughout.
-struct BilinearBwdXRowK {
-  struct Args { const float* dy; float* tmp; int B, Ho, Wo, C, Wi, seg, nseg; float sw; };
-  static constexpr int NT = 256;
-  static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    SSA_DYN_LDS(float, tile);
-    const int row = bx / a.nseg, sg = bx - row * a.nseg;          // row = (b, oy)
-    const int ix0 = sg * a.seg, ix1 = min(a.Wi, ix0 + a.seg);
-    int lo0, hi0, lo1, hi1;
-    cand_range(ix0, a.sw, a.Wo, &lo0, &hi0);
-    cand_range(ix1 - 1, a.sw, a.Wo, &lo1, &hi1);
-    const int xlo = lo0, xhi = hi1;
-    const long first = ((long)row * a.Wo + xlo) * a.C;            // first float of the segment
-    const long al = first & ~3L;                                   // ... rounded down to a 16-byte boundary (dy is 16-byte aligned)
-    const int skew = (int)(first - al);
-    const long row_end = ((long)a.B * a.Ho * a.Wo) * a.C;          // one past the tensor's last float
-    const int nfl = skew + (xhi - xlo + 1) * a.C;
-    const int n4 = (nfl + 3) >> 2;
-    for (int i = threadIdx.x; i < n4; i += NT) {
-      const long g = al + 4L * i;
-      float4 v;
-      if (g + 4 <= row_end) v = *reinterpret_cast<const float4*>(a.dy + g);
-      else { v.x = g < row_end ? a.dy[g] : 0.f; v.y = g + 1 < row_end ? a.dy[g + 1] : 0.f; v.z = g + 2 < row_end ? a.dy[g + 2] : 0.f; v.w = 0.f; }
-      *reinterpret_cast<float4*>(tile + 4 * i) = v;
-    }
-    __syncthreads();
-    const int nout = (ix1 - ix0) * a.C;
-    float* out = a.tmp + ((long)row * a.Wi + ix0) * a.C;
-    for (int idx = threadIdx.x; idx < nout; idx += NT) {
-      const int dix = idx / a.C, c = idx - dix * a.C;
-      const int ix = ix0 + dix;
-      int lo, hi;
-      cand_range(ix, a.sw, a.Wo, &lo, &hi);
-      float acc = 0.f;
-      for (int ox = lo; ox <= hi; ++ox) {
-        const float w = weight_for(ox, a.sw, a.Wi, ix);
-        if (w != 0.f) acc += w * tile[skew + (ox - xlo) * a.C + c];
-      }
-      out[idx] = acc;
-    }
-  }
-};
-
-struct BilinearBwdYFlatK {
-  struct Args { const float* tmp; float* dx; int B, Ho, Hi; long n4; float sh; };   // n4 = float4 per row (Wi * C / 4)
-  static constexpr int NT = 256;
-  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
-    const long n = (long)a.B * a.Hi * a.n4;
-    for (long i = bx * (long)NT + threadIdx.x; i < n; i += (long)gx * NT) {
-      const long q = i % a.n4;
-      const long t = i / a.n4;
-      const int iy = (int)(t % a.Hi), b = (int)(t / a.Hi);
-      int ylo, yhi;
-      cand_range(iy, a.sh, a.Ho, &ylo, &yhi);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int oy = ylo; oy <= yhi; ++oy) {
-        const float w = weight_for(oy, a.sh, a.Hi, iy);
-        if (w == 0.f) continue;
-        const float4 v = *reinterpret_cast<const float4*>(a.tmp + (((long)b * a.Ho + oy) * a.n4 + q) * 4);
-        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
-      }
-      *reinterpret_cast<float4*>(a.dx + (((long)b * a.Hi + iy) * a.n4 + q) * 4) = acc;
-    }
-  }
-};
-
 // ---- few-channel tensors (class logits [.., 19], attention maps [.., 1]; fp32 on this path): one
 // thread per PIXEL.  The source indices / weights are computed once per pixel instead of once per
 // element (and with 32-bit index arithmetic); the forward stages the 256-pixel block of outputs in LDS
@@ -596,18 +524,6 @@ int ssa_bilinear_bwd_x(const void* dy, int dy_dtype, int B, int Ho, int Wo, int 
     K::Args a{(const bf16_t*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
     return ssa::submit<K>(a, grid_for(n / kXRows + 1), 1, 0, s);
   }
-  if (dy_dtype == 1 && lddy == C && C <= 128 && (reinterpret_cast<uintptr_t>(dy) & 15u) == 0 && Wo >= 2 * Wi) {
-    // dense few-channel fp32 rows: segments of input columns whose gradient window fits 56 KB of LDS
-    const int win = (int)(2.f / sw) + 6;                           // gradient columns one input column can touch (+ margin)
-    int seg = (int)(((56 * 1024) / (4 * C) - win - 4) * sw);
-    if (seg >= 4) {
-      if (seg > Wi) seg = Wi;
-      const int nseg = (Wi + seg - 1) / seg;
-      const size_t lds = ((size_t)((int)(seg / sw) + win + 8) * C + 8) * sizeof(float);
-      BilinearBwdXRowK::Args a{(const float*)dy, tmp, B, Ho, Wo, C, Wi, seg, nseg, sw};
-      return ssa::submit<BilinearBwdXRowK>(a, B * Ho * nseg, 1, lds, s);
-    }
-  }
   if (dy_dtype == 1) {
     typedef BilinearBwdXK<float, 1> K;
     K::Args a{(const float*)dy, tmp, B, Ho, Wo, C, lddy, Wi, sw};
@@ -631,11 +547,6 @@ int ssa_bilinear_bwd_y(const float* tmp, int B, int Ho, int Wi, int C, void* dx,
     typedef BilinearBwdYK<bf16_t, 1> K;
     K::Args a{tmp, (bf16_t*)dx, B, Ho, Wi, C, Hi, lddx, sh};
     return ssa::submit<K>(a, grid_for(n), 1, 0, s);
-  }
-  if (dx_dtype == 1 && lddx == C && ((long)Wi * C) % 4 == 0 &&
-      ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(tmp)) & 15u) == 0) {
-    BilinearBwdYFlatK::Args a{tmp, (float*)dx, B, Ho, Hi, (long)Wi * C / 4, sh};
-    return ssa::submit<BilinearBwdYFlatK>(a, grid_for(n / 4), 1, 0, s);
   }
   if (dx_dtype == 1) {
     typedef BilinearBwdYK<float, 1> K;

@@ -1611,26 +1611,19 @@ def _dt(t):
     raise TypeError(t.dtype)
 
 
-_BILINEAR_ROWS = os.environ.get("SSA_BILINEAR_ROWS", "1") != "0"
-
-
 def _bilinear_bwd_group(jobs):
     """Backward of N bilinear resizes.  job = (dy_ptr, dy_dtype_code, lddy, B, Hi, Wi, C, Ho, Wo, dx).  Upsampling
     resizes (Ho >= 2 Hi and Wo >= 2 Wi) of 16-bit tensors with C % 8 == 0 -- the trunk's branch upsamples, 2x / 4x /
     8x -- run the separable form: all X passes of the level in one bracket, all Y passes in the next
-    (ssa_bilinear_bwd_x / _y; 607 -> 275 us per step).  Dense few-channel fp32 tensors (the 19 / 65-channel class logits,
-    4x and 2x to the crop) take the separable form as well since round 5: its per-element passes measured slower than
-    the gather on 76-byte pixels (round 4), the LDS-staged row pass + flat float4 row pass of csrc/resample.hip do not.
-    The others take the one-pass gather."""
+    (ssa_bilinear_bwd_x / _y; 607 -> 275 us per step).  The others take the one-pass gather: for the 19-channel fp32
+    logits the separable form measured SLOWER twice -- with per-element passes (scalar loads: 542 against 470 us per
+    step, profiles/r04_notes.md) and with a row pass that stages gradient rows in LDS plus a flat float4 column pass
+    (0.80 against 0.28 ms per step, profiles/r05_notes.md call G: 60 KB of LDS per workgroup and twelve candidate
+    weights per element cost more than the gather's re-reads, which hit L2)."""
     L = lib()
 
     def separable(j):
-        up = j[7] >= 2 * j[4] and j[8] >= 2 * j[5]
-        if j[1] == 0:
-            return j[6] % 8 == 0 and j[2] % 8 == 0 and up
-        # dense few-channel fp32 tensors (the class logits): gradient rows staged in LDS, flat float4 row pass
-        return _BILINEAR_ROWS and j[1] == 1 and up and j[2] == j[6] and j[6] <= 128 and (j[5] * j[6]) % 4 == 0 and \
-            j[9].dtype == torch.float32
+        return j[1] == 0 and j[6] % 8 == 0 and j[2] % 8 == 0 and j[7] >= 2 * j[4] and j[8] >= 2 * j[5]
     sep = [j for j in jobs if separable(j)]
     rest = [j for j in jobs if not separable(j)]
     tmps = []
