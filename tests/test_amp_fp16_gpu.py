@@ -144,7 +144,7 @@ def test_scaled_step_replays_as_a_graph():
 
 # ------------------------------------------------------------------ the fp16-storage build (child processes)
 def _child(args, log, timeout=900, code=None):
-    env = dict(os.environ, SSA_ACT_DTYPE="fp16", SSA_PARITY_CROP="512")
+    env = dict(os.environ, SSA_ACT_DTYPE="fp16")
     env.pop("PYTEST_CURRENT_TEST", None)
     cmd = [sys.executable, "-c", code] if code else \
         [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-s"] + args
@@ -174,8 +174,9 @@ def test_train_step_parity_on_the_fp16_build():
 
 def test_teacher_forced_training_ops_on_the_fp16_build():
     """Every operator of the training step, forward and backward, teacher-forced at one-rounding tolerance on the fp16
-    build (512^2 crop: the shapes of the 1024^2 step's 0.5x pass and its quarter-size 0.5x pass; the bf16 build runs the
-    1024^2 crop in tests/test_parity_1024_gpu.py), upstream gradient = the loss scale."""
+    build at the benchmarked 1024^2 crop (the harness' parameter-gradient bounds are calibrated there: at 512^2 the
+    sums run over a quarter of the pixels and five of 2,250 comparisons sit at 0.82-0.99 % mean error against the 0.8 %
+    bound, on either build), upstream gradient = the loss scale."""
     _needs_device()
     r = _child(["tests/test_parity_1024_gpu.py", "-k", "teacher_forced"], "fp16_teacher_train.log", timeout=1200)
     tail = "\n".join(r.stdout.splitlines()[-25:])
