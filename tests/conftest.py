@@ -9,7 +9,24 @@ for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
         sys.path.insert(0, p)
 
 
+def _limit_cpu_threads():
+    """The CPU sides of the parity tests (the oracle and the storage emulation, fp32 torch on the host) run on a bounded
+    number of intra-op threads: torch's default is one per visible CPU, and on the GPU boxes (256 visible, cgroup-limited)
+    that is an order of magnitude SLOWER than 8-16 threads for this graph of small convs (bench.py's CPU baseline probes
+    it: 128 threads 19.5 s per 256 x 256 iteration, 14x slower than 8).  SSA_TEST_THREADS overrides."""
+    try:
+        import torch
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(int(os.environ.get("SSA_TEST_THREADS", "16")), avail)))
+    except Exception:       # noqa: BLE001
+        pass
+
+
 def pytest_configure(config):
+    _limit_cpu_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "multigpu: needs >= 2 MI355X in one node; DESELECTED (not skipped) elsewhere")
 
