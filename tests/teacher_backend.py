@@ -30,8 +30,12 @@ GRAD_TOL = (2e-2, 6e-3)        # data gradients (bf16, through BN)
 # of a sum over as few as ~1,300 pixels (the 384-channel branch): measured up to 3.3 % of max|ref|.
 # Mean: TWO independent bf16 roundings meet here -- the teacher's reference gradient is itself rounded
 # to bf16 (the emulation rounds the gradient of a bf16-stored weight), the HIP side's dy is bf16 --
-# measured 0.2 % typical, 0.5 % in the tail of the 2,250 comparisons of a step.
-PARAM_TOL = (5e-2, 8e-3)
+# measured 0.2 % typical; the tail of the 2,250 comparisons of a step depends on the realisation (which pre-activations
+# sit within rounding of zero is decided by the teacher's last ulps, i.e. by the host's thread count and the crop): 0.5 %
+# at 1024^2 on 128 host threads, 0.86 % on 16 threads (one 384-channel filter of the smallest branch: 1,280 pixels per
+# sum), 0.99 % at a 512^2 crop -- every time at cosine >= 0.9999 and a norm ratio of 1.000.  1.2 % holds all of them; a
+# wrong weight-gradient kernel is two orders of magnitude beyond it.
+PARAM_TOL = (5e-2, 1.2e-2)
 OCR_ATTN_TOL = tuple([1e-2, 4e-3])     # = BF16_TOL by value (a separate object: see OCR_GATHER_TOL's note); valid in a sane softmax regime only
 OCR_GATHER_TOL = tuple([5e-3, 2e-3])   # (built at run time: CPython merges equal literal tuples, and `is BF16_TOL` selects F32_TOL)
 LOSS_TOL = (1e-4, 1e-4)
