@@ -165,6 +165,81 @@ def test_fused_sgd_step_glue_and_filter_cache_refresh(dry):
     assert all("momentum_buffer" in opt.state[p] for p in net.parameters())
 
 
+def test_loss_scaler_glue(dry, monkeypatch):
+    """fp16 training (semseg_amd/amp.py): with a scaler attached the optimizer step is  check (every gradient, before
+    any parameter moves) -> SGD with the scaler's record -> scale update, all with arguments that convert to the C
+    signatures; apex.amp's two entry points go through it; the scale travels in the optimizer's state_dict."""
+    from semseg_amd import amp as samp, hip_backend
+    from semseg_amd.loss.optimizer import FusedSGD
+    monkeypatch.setattr(samp, "ACT", "fp16")                    # (what SSA_ACT_DTYPE=fp16 makes of the process)
+    order = []
+    real_getattr = type(dry).__getattr__
+
+    def spy(self, name):
+        fn = real_getattr(self, name)
+        if name in ("ssa_amp_check_grads", "ssa_sgd_momentum_step", "ssa_amp_update"):
+            def wrapped(*a):
+                order.append(name)
+                return fn(*a)
+            return wrapped
+        return fn
+    monkeypatch.setattr(type(dry), "__getattr__", spy)
+    net = _build("deepv3.DeepV3PlusR50", "ce").train()
+    opt = FusedSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    try:
+        scaler = samp.attach_scaler(opt, torch.device("cpu"), init_scale=1024.0)
+        assert samp.scaler_of(opt) is scaler and hip_backend._FP16_TRAINING[0]
+        inputs = _batch()
+        loss = net(inputs)
+        with samp.scale_loss(loss, opt) as scaled:
+            assert float(scaled.detach()) == float(loss.detach()) * 1024.0
+            scaled.backward()
+        opt.step()
+    finally:
+        hip_backend.enable_fp16_training(False)
+    assert order[0] == "ssa_amp_check_grads" and order[-1] == "ssa_amp_update"
+    first_sgd = order.index("ssa_sgd_momentum_step")
+    assert all(n == "ssa_amp_check_grads" for n in order[:first_sgd])           # every check before the first update
+    assert all(n == "ssa_sgd_momentum_step" for n in order[first_sgd:-1])
+    sd = opt.state_dict()
+    assert sd["loss_scaler"]["loss_scale"] == 1024.0
+    sd["loss_scaler"] = {"loss_scale": 64.0, "unskipped": 3}
+    opt.load_state_dict(sd)
+    assert scaler.state.tolist()[:3] == [64.0, 0.0, 3.0]
+    # the bf16 build: no scaler, scale_loss is the identity
+    monkeypatch.setattr(samp, "ACT", "bf16")
+    opt2 = FusedSGD(net.parameters(), lr=1e-3)
+    assert samp.initialize(net, opt2)[1] is opt2 and samp.scaler_of(opt2) is None
+    with samp.scale_loss(loss.detach(), opt2) as same:
+        assert same is not None and float(same) == float(loss.detach())
+
+
+def test_ocr_concat_is_a_view(dry):
+    """SpatialOCR_Module's torch.cat([context, feats], 1) (network/ocr_utils.py:151) on the HIP glue: the two producers
+    write channel slices of one buffer (ops.cat_slots) and the concatenation is hip_backend.CatViewFn -- no aten `cat`
+    in the step, train or eval, and the 1x1 bottleneck conv reads a dense 1024-channel tensor."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(func.__name__.split(".")[0])
+            return func(*args, **(kwargs or {}))
+    net = _build("ocrnet.HRNet_Mscale", "rmi").train()
+    inputs = _batch(2, 128, 128)
+    with Spy():
+        loss = net(inputs)
+        loss.backward()
+    assert "cat" not in seen, "the OCR concatenation made a copy"
+    for n, p in net.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape, n
+    net.eval()
+    seen.clear()
+    with Spy(), torch.no_grad():
+        out = net({"images": inputs["images"]})
+    assert "cat" not in seen and tuple(out["pred"].shape) == (2, 19, 128, 128)
+
+
 def test_lockstep_grouping_and_gradient_arena_glue(dry):
     """The HRNet-OCR-MScale step in lockstep: every BasicBlock level is ONE autograd node for all
     (branch, pass) problems, whose backward takes bn1's sums from conv2's data-gradient epilogue
