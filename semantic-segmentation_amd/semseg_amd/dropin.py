@@ -13,7 +13,9 @@ time, so `train.py`, `config.py` and `scripts/*.yml` run unchanged:
         -> semseg_amd.loss.*         (train.py:45-46,341,378)
   apex.parallel.SyncBatchNorm / DistributedDataParallel, apex.amp
         -> semseg_amd.nn.SyncBatchNorm / semseg_amd.parallel.DistributedDataParallel /
-           a bf16 no-op amp shim     (config.py:218-220, network/__init__.py:37-39, train.py:381,504)
+           semseg_amd.amp behind apex.amp's names: `--fp16` selects the fp16-storage build of the library and
+           amp.initialize / amp.scale_loss carry apex's dynamic loss scaling (on the device, inside the captured step);
+           on the bf16 build they are the identity     (config.py:218-220, network/__init__.py:37-39, train.py:381,504)
 
 Configuration: the model factories (`--arch` targets), `get_loss` and `get_optimizer` registered by
 `install()` re-read the reference's global `cfg` every time they are called (`sync_config()`), so the
