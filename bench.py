@@ -265,10 +265,7 @@ def main():
         try:
             graph = torch.cuda.CUDAGraph()
             optim.zero_grad(set_to_none=True)
-            # (experiment: SSA_MAIN_PRIO=-1 captures the step on a high-priority stream; the weight-gradient branch
-            # keeps the default priority)
-            prio = int(os.environ.get("SSA_MAIN_PRIO", "0"))
-            with torch.cuda.graph(graph, stream=torch.cuda.Stream(priority=prio) if prio else None):
+            with torch.cuda.graph(graph):
                 step()
             torch.cuda.synchronize()
         except Exception as e:          # noqa: BLE001

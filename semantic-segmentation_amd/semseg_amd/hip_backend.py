@@ -760,9 +760,10 @@ def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, di
 
 
 _WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
-# workgroup slots a weight-gradient launch is fitted to: 512 = two 64 KB workgroups per CU (the whole chip);
-# 256 = one per CU, which leaves every CU 96 KB of LDS and half its registers for the main stream's kernels
-_WGRAD_SLOTS = int(os.environ.get("SSA_WGRAD_SLOTS", "512"))
+# workgroup slots a weight-gradient launch is fitted to: two 64 KB workgroups per CU = the whole chip.  (One per CU --
+# leaving every CU 96 KB of LDS and half its registers for the main branch's kernels -- measured the same step time:
+# profiles/r05_notes.md call B; the branches do not overlap however they are sized)
+_WGRAD_SLOTS = 512
 _WGRAD_GROUP = 32       # layers (problems) per grouped weight-gradient launch: csrc/group.h MAXJOBS of ConvWgradTile
 
 
@@ -789,7 +790,7 @@ def _fit_tile_strips(jobs, strip):
             best = None
             # (twice the layers per launch want strips up to twice as long for the same workgroup count: that is the
             # point -- a layer's fp32 partials, one block per workgroup, halve, and so does what WgradReduceK reads)
-            for s_ in range(strip, (2 if (_WGRAD_SLOTS >= 512 and _WGRAD_GROUP <= 16) else 6) * strip + 1):
+            for s_ in range(strip, 6 * strip + 1):
                 wgs = sum(-(-t // s_) * p for _, t, p in chunk)
                 cost = -(-wgs // _WGRAD_SLOTS) * (s_ + 2.0)
                 if best is None or cost < best[0] - 1e-9:
@@ -868,7 +869,7 @@ _SINCE_REDUCE = [0]        # layers flushed since the gradient sink was last han
 
 def _side_stream():
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream(priority=int(os.environ.get("SSA_WGRAD_PRIO", "0")))
+        _SIDE["stream"] = torch.cuda.Stream()
     return _SIDE["stream"]
 
 
