@@ -3,9 +3,9 @@
 
   configs[1]  HRNet-OCR, single scale, 1 x 3 x 1024 x 2048 (Cityscapes val)
   configs[2]  HRNet-OCR-MScale, scales {0.5, 1.0, 2.0} of a 1024 x 2048 image: the 2.0x pass is 2048 x 4096
-  configs[4]  Mapillary: 65 classes, scales {0.5, 1.0, 2.0} of a 960 x 1280 image (the 2.0x pass is 1920 x 2560 =
-              4.9 Mpixel: the 65-wide fp32 heads, the OCR gather / attention over 65 object regions, the n-block
-              tails of 65 output channels -- 0.32 G elements of logits; the reference's full-size recipe is a
+  configs[4]  Mapillary: 65 classes, scales {0.5, 1.0, 2.0} of a 1152 x 1536 image (the 2.0x pass is 2304 x 3072 =
+              7 Mpixel: the 65-wide fp32 heads, the OCR gather / attention over 65 object regions, the n-block
+              tails of 65 output channels -- 0.46 G elements of logits; the reference's full-size recipe is a
               once-per-round run of tools/eval_bench.py)
 
 Every operator call of the forward pass runs the HIP op on the teacher's (storage-rounded) inputs at its REAL shape
@@ -221,13 +221,13 @@ def test_eval_mscale_three_scales_1024x2048():
 
 
 def test_eval_mapillary_65_classes_three_scales():
-    """BASELINE configs[4]: 65 classes, {0.5, 1.0, 2.0} on a Mapillary-shaped (4:3) image.  960 x 1280, the 2.0x pass
-    1920 x 2560: the device teacher's fp32 convs (MIOpen) take 100 s at 1152 x 1536 and 140 s at 1536 x 2048 (round 4,
-    call H), which a suite that has to finish inside the driver's 1,200 s does not have; the shapes that matter -- 65-wide
-    heads and OCR regions (three region blocks of the fused attention kernel), n-block tails, 0.3 G-element logit
-    tensors -- are the same.  The reference's full recipe (eval_mapillary.yml: pre_size 2177, four scales, the 2.0x pass
-    14 Mpixel) runs once per round through `tools/eval_bench.py 3 mapillary-ref` (profiles/r05_eval_bench.json: time,
-    peak memory, finite outputs -- no teacher at that size)."""
-    tb, out = _teacher_eval("HRNet_Mscale", 65, [0.5, 1.0, 2.0], 960, 1280)
+    """BASELINE configs[4]: 65 classes, {0.5, 1.0, 2.0} on a Mapillary-shaped (4:3) image.  1152 x 1536, the 2.0x pass
+    2304 x 3072 = 7 Mpixel: the device teacher's fp32 convs (MIOpen, compiled at first use) take 100 s here and 140 s at
+    1536 x 2048 (round 4, call H); the shapes that matter -- 65-wide heads and OCR regions (three region blocks of the
+    fused attention kernel), n-block tails, 0.46 G-element logit tensors -- are the same.  The reference's full recipe
+    (eval_mapillary.yml: pre_size 2177, four scales, the 2.0x pass 14 Mpixel) runs once per round through
+    `tools/eval_bench.py 3 mapillary-ref` (profiles/r05_eval_bench.json: time, peak memory, finite outputs -- no teacher
+    at that size)."""
+    tb, out = _teacher_eval("HRNet_Mscale", 65, [0.5, 1.0, 2.0], 1152, 1536)
     for k in ("pred_0.5x", "pred_2.0x", "attn_1.0x"):
         assert k in out, sorted(out)
