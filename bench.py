@@ -22,6 +22,44 @@ for p in (ROOT, os.path.join(ROOT, "semantic-segmentation_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+
+def _early_args(argv):
+    """--dtype and --gpus, read before torch / the package are imported: the storage format selects which build of the
+    library the process loads (semseg_amd/_lib.py reads SSA_ACT_DTYPE at import), and a bare `python bench.py --gpus N`
+    (no torch.distributed.run around it) re-executes itself under the launcher."""
+    dtype, gpus = None, 1
+    for i, a in enumerate(argv):
+        if a == "--dtype" and i + 1 < len(argv):
+            dtype = argv[i + 1]
+        elif a.startswith("--dtype="):
+            dtype = a.split("=", 1)[1]
+        elif a == "--gpus" and i + 1 < len(argv):
+            gpus = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            gpus = int(a.split("=", 1)[1])
+    return dtype, gpus
+
+
+_DTYPE, _GPUS = _early_args(sys.argv[1:])
+if _GPUS > 1 and "WORLD_SIZE" not in os.environ and "--cpu-baseline-only" not in sys.argv:
+    # the contract's N > 1 launch is `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a bare
+    # `python bench.py --gpus N` (the shape of the driver's N = 1 command) becomes exactly that
+    import socket
+    with socket.socket() as _sk:
+        _sk.bind(("127.0.0.1", 0))
+        _port = _sk.getsockname()[1]
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(_GPUS),
+                              "--master-addr", "127.0.0.1", "--master-port", str(_port), os.path.abspath(__file__)]
+             + sys.argv[1:])
+# fp16 storage with dynamic loss scaling is the format of record: it is the reference's own arithmetic (every recipe sets
+# `fp16: true`, scripts/*.yml; train.py:380-381 apex O1), gfx950 runs fp16 MFMA at the bf16 rate, and it sits an order of
+# magnitude closer to the fp32 oracle than bf16 storage (DESIGN.md section 4).  --dtype bf16 (or SSA_ACT_DTYPE) selects
+# the other build; the default run reports the bf16 step beside the headline (value_bf16).
+if _DTYPE is not None:
+    os.environ["SSA_ACT_DTYPE"] = _DTYPE
+os.environ.setdefault("SSA_ACT_DTYPE", "fp16")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -95,6 +133,26 @@ def build_model(world):
 FORCE_DIST = os.environ.get("SSA_FORCE_DIST", "0") == "1"
 
 
+def secondary_run(args, dtype, timeout_s=420):
+    """The identical benchmark step on the other storage build, in a child process (no roofline leg, no CPU baseline)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dtype, "--gpus", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--crop", str(args.crop), "--crop-w", str(args.crop_w), "--batch", str(args.batch),
+           "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--eager-steps", "0"]
+    if args.no_graph:
+        cmd.append("--no-graph")
+    env = {k: v for k, v in os.environ.items() if k not in ("SSA_ACT_DTYPE", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                j = json.loads(line)
+                return {"value": j["value"], "ms_per_step": j["ms_per_step"], "dtype": j["dtype"], "loss": j["config"]["loss"]}
+        return {"value": None, "error": (out.stderr or out.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "secondary %s run exceeded %d s" % (dtype, timeout_s)}
+
+
 def cpu_baseline(timeout_s=240):
     """Run the CPU baseline in a child process under a hard time limit so that a
     misbehaving host (oversubscribed cores) can never stall the benchmark."""
@@ -157,7 +215,8 @@ def _cpu_baseline_impl(crop=1024, timed=3):
                       "bit-identical to them on fresh inputs, tests/test_oracle_golden.py) two-scale train step fwd+bwd, "
                       "fp32, the benchmarked workload itself: %d timed iters after 1 warm-up at %dx%d crop, batch 1 "
                       "(%.2f s/iter) on %d torch threads -- the fastest of 16/32/64/128 probed at 256x256, NOT all of "
-                      "the %d CPUs visible (more threads are slower for this graph)"
+                      "the %d CPUs visible (more threads are slower for this graph); the pool's hosts differ: the same "
+                      "code measured 0.151-0.166 images/s between rounds"
                       % (timed, crop, crop, per_iter, ncores, avail)}
 
 
@@ -173,6 +232,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--eager-steps", type=int, default=3, help="eager steps timed after the graph run (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("fp16", "bf16"), default=None, help="storage format = library build "
+                    "(default fp16 with dynamic loss scaling: the reference's --fp16; SSA_ACT_DTYPE is honoured too)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 step timed beside the fp16 headline")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -186,7 +248,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (
+        world, args.gpus, args.gpus)
     # SSA_BENCH_ONE_DEVICE / SSA_DIST_BACKEND: self-test of the N > 1 code path on a one-GPU box
     # (all ranks on cuda:0, gloo collectives, eager); the driver's multi-GPU runs use neither.
     torch.cuda.set_device(0 if os.environ.get("SSA_BENCH_ONE_DEVICE") else local_rank)
@@ -394,6 +457,27 @@ def main():
                            "lds_conflict_frac": v.get("lds_conflict_frac"), "waves_per_simd": v.get("waves_per_simd")}
                        for k, v in pj["kernels"].items() if k in CONV_FAMILIES}
             break
+        # north_star's own criterion: MFMA fraction over the 3x3 convolutions (forward, data and weight gradients) --
+        # the kernels that run ONLY 3x3 stride-1 layers: the trunk tile kernels, the head's halo GEMM, the two
+        # weight-gradient kernels; algorithmic FLOPs of their jobs / the sum of their launch durations / 2.5 PF.
+        # (4.962 TFLOP per image are 3x3; the stride-2 3x3 layers run on ConvIgemm / ConvWgradTr beside
+        # 1x1 layers and are left out of both sums.)  Durations are this eager leg's (each launch alone on the chip);
+        # inside the replayed step the weight-gradient stream shares the chip and the same kernels run 10-15 % longer.
+        k3 = {"us": 0.0, "flops": 0.0, "kernels": {}}
+        for r in recs:
+            base = r["kernel"].split("<")[0]
+            if family(r["kernel"]) == "ConvTile" or base in ("ConvHaloGemm3", "ConvHaloGemm3W", "ConvWgradHead3", "ConvWgradTile"):
+                t_us = max(r["total_us"] - empty_us * r["launches"], 0.05 * r["launches"])
+                k3["us"] += t_us
+                k3["flops"] += r["flops"]
+                e = k3["kernels"].setdefault(base, {"ms_per_step": 0.0, "tflop_per_step": 0.0})
+                e["ms_per_step"] += t_us / 2e3
+                e["tflop_per_step"] += r["flops"] / 2e12
+        for e in k3["kernels"].values():
+            e["mfma_frac"] = e["tflop_per_step"] * 1e12 / max(e["ms_per_step"] * 1e-3, 1e-9) / PEAK_BF16_MFMA
+        mfma_3x3 = {"frac": k3["flops"] / max(k3["us"] * 1e-6, 1e-9) / PEAK_BF16_MFMA if k3["us"] else None,
+                    "tflop_per_step": k3["flops"] / 2e12, "ms_per_step": k3["us"] / 2e3, "kernels": k3["kernels"],
+                    "target": 0.7}
         sec = d["us"] * 1e-6
         mfma_bound = d["flops"] / max(d["bytes"], 1.0) > PEAK_BF16_MFMA / PEAK_HBM
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": name,
@@ -402,7 +486,7 @@ def main():
                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
                 "frac": d["flops"] / sec / PEAK_BF16_MFMA if mfma_bound else d["bytes"] / sec / PEAK_HBM,
                 "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "mfma_busy_frac": mfma_busy, "pmc_conv_families": pmc_fam,
+                "mfma_busy_frac": mfma_busy, "pmc_conv_families": pmc_fam, "mfma_3x3": mfma_3x3,
                 "launches_per_step": d["launches"] // 2, "problems_per_launch": d["jobs"] / d["launches"],
                 "avg_launch_us": d["us"] / d["launches"], "flop_per_launch": d["flops"] / d["launches"],
                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -430,6 +514,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    # the same step on the other storage build (bf16, no loss scaling), timed in a child process at N = 1: one library
+    # build per process.  Reported beside the headline, never as `value`.
+    other = None
+    if rank == 0 and world == 1 and not args.no_secondary and not dist_on and samp.fp16_storage():
+        other = secondary_run(args, "bf16")
 
     if rank == 0:
         out = {
@@ -437,6 +526,11 @@ def main():
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16" if samp.fp16_storage() else "bf16", "data": "synthetic",
+            # the bf16-storage build of the same step (child process, N = 1 only); `value` is the fp16 step with the
+            # dynamic loss scaler inside the captured graph -- the reference's arithmetic (README.md "which number")
+            "value_bf16": other["value"] if other else None,
+            "ms_per_step_bf16": other.get("ms_per_step") if other else None,
+            "secondary_error": other.get("error") if other else None,
             "config": {"workload": "train_cityscapes_sota: HRNet-OCR-MScale two-scale train step, RMI+BCE loss, "
                                    "crop %dx%d, batch %d/GPU, SGD, synthetic Cityscapes-shaped batch, random init"
                                    % (args.crop, crop_w, args.batch),
@@ -460,10 +554,11 @@ def main():
                        # traffic per rank) / 300 GB/s of xGMI per GPU
                        "grad_exchanges_per_step": getattr(model, "exchanges", None) if dist_on else None,
                        "exposed_comm_ms_estimate": (getattr(model, "tail_elements", 0) * 4 * 2 / 300e9 * 1e3) if dist_on else None,
-                       "logit_tolerance": "north_star asks 1e-3 relative; bf16 storage gives ~1e-1 end to end on random "
-                                          "weights (the fp32-oracle-with-bf16-storage emulation gives the same); every op "
-                                          "holds one-bf16-rounding tolerance teacher-forced at this config "
-                                          "(tests/test_parity_1024_gpu.py, DESIGN.md section 4)"},
+                       "logit_tolerance": "north_star asks 1e-3 relative; 16-bit STORAGE of ~450 layers gives ~1.5e-2 "
+                                          "end to end in fp16 (this line's format; gradient cosine vs the fp32 oracle 0.99) "
+                                          "and ~1e-1 in bf16 on random weights -- the fp32-oracle-with-16-bit-storage "
+                                          "emulation gives the same; every op holds one-rounding tolerance teacher-forced "
+                                          "at this config (tests/test_parity_1024_gpu.py, DESIGN.md section 4)"},
             "model_flops_util": ips / world * FLOP_FWD_BWD_PER_IMAGE * flop_scale / PEAK_BF16_MFMA,
             "roofline": roof, "cpu_baseline": cpu,
         }

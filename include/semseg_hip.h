@@ -219,8 +219,7 @@ typedef struct ssa_pack_job {
   void* w_packed;
   long elem_begin;   /* unused by the kernel (reserved)                        */
   int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows;
-  int layout;        /* mode 2 / 3: 0 = fragments of conv_tile(_p).hip / conv_halo_gemm.hip, 1 = of conv_tile_q.hip
-                        (ssa_pack_filter: mode + 8)                                 */
+  int layout;        /* reserved, 0: mode 2 / 3 write the one fragment order of conv_tile(_p).hip / conv_halo_gemm.hip */
 } ssa_pack_job;
 int ssa_pack_filters_batched(const void* jobs_dev, int njobs, int blocks_per_job,
                              void* stream);
@@ -581,6 +580,12 @@ int ssa_amp_check_grads(const void* const* grads, const int64_t* numel, int n_te
                         void* stream);
 int ssa_amp_update(float* amp_state, int growth_interval, float growth, float backoff, float min_scale,
                    float max_scale, void* stream);
+/* The same update, additionally counting what apex LOGS ("Gradient overflow.  Skipping step", apex/amp/scaler.py):
+ * counters[0] += 1 and counters[1] += 1 on a skipped step, counters[1] = 0 on a clean one -- skipped steps in total and in
+ * a row (2 floats of device memory, or NULL).  A run whose gradients are genuinely nan pins the scale at min_scale and
+ * skips every step: the host reads this record (semseg_amd.amp.LossScaler.state_dict / .health) to say so. */
+int ssa_amp_update_counted(float* amp_state, float* counters, int growth_interval, float growth, float backoff,
+                           float min_scale, float max_scale, void* stream);
 
 /* fp32 elementwise out = a (+ | * | /) b (op 0 | 1 | 2) and its backward (da, db optional): the
  * attention normalisation and the attention-weighted sum over scales of the attention-to-scale

@@ -63,7 +63,7 @@ __device__ __forceinline__ f32x16_t ssa_mfma32(bf16x8_t a, bf16x8_t b, f32x16_t 
 #endif
 }
 // D = A(16x32) * B(32x16) + C on one wave; lane l holds row/column l & 15, k-group l >> 4 (8 consecutive k); D: column
-// l & 15, rows 4 * (l >> 4) + j  (conv_tile_q.hip; lane map pinned by ssa_probe_mfma16)
+// l & 15, rows 4 * (l >> 4) + j  (lane map pinned by ssa_probe_mfma16)
 __device__ __forceinline__ f32x4_t ssa_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 #ifdef SSA_ELEM_F16
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);

@@ -564,7 +564,7 @@ struct PackJob {           // mirror of ssa_pack_job (include/semseg_hip.h)
   const float* w;
   bf16_t* out;
   long elem_begin;         // first flat output element of this job in the batch
-  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout;   // layout: fragment order of mode 2 / 3
+  int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout;   // layout: reserved, 0 (one fragment order)
 };
 
 // Stride-2 data gradient by output parity (ssa_conv2d_dgrad_s2): dx[2m+p] along one axis of a 3-tap,
@@ -603,19 +603,10 @@ __device__ __forceinline__ bf16_t pack_one(const float* __restrict__ w, int Cout
 }
 
 // Element offset of (row r, k = tap * cpad + c) in the MFMA-fragment orders of mode 2 / 3.
-// layout 0 (conv_tile.hip, conv_tile_p.hip, conv_halo_gemm.hip): [n-block of 32][k-step of 16][lane][8] with
+// The one fragment order (conv_tile.hip, conv_tile_p.hip, conv_halo_gemm.hip): [n-block of 32][k-step of 16][lane][8] with
 //   row = nb*32 + (lane&31), k = ks*16 + 8*(lane>>5) + j;  ksteps = Kpad / 16.
-// layout 1 (conv_tile_q.hip; cpad a multiple of 48): [n-tile of 48][chunk of 48 channels][k-step of 32][block of 16
-//   rows][lane][8] with row = nt*48 + mb*16 + (lane&15), and inside the chunk the flattened kk = tap*48 + c%48 =
-//   ks*32 + 8*(lane>>4) + j; 14 k-steps per chunk, the last half k-step (kk >= 432) stays zero.
-__device__ __forceinline__ long frag_offset(int layout, int r, int k, int ksteps, int cpad) {
-  if (layout == 0)
-    return ((((long)(r >> 5) * ksteps + (k >> 4)) * 64) + (r & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
-  const int tap = k / cpad, c = k - tap * cpad;
-  const int cc = c / 48, kk = tap * 48 + (c - cc * 48);
-  const int nt = r / 48, rr = r - nt * 48;
-  const int nchunk = cpad / 48;
-  return ((((((long)nt * nchunk + cc) * 14 + (kk >> 5)) * 3 + (rr >> 4)) * 64) + ((kk & 31) >> 3) * 16 + (rr & 15)) * 8 + (kk & 7);
+__device__ __forceinline__ long frag_offset(int /*layout*/, int r, int k, int ksteps, int /*cpad*/) {
+  return ((((long)(r >> 5) * ksteps + (k >> 4)) * 64) + (r & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
 }
 
 // All filters of the network in one launch: blockIdx.y = job, grid-stride in x.
@@ -625,16 +616,6 @@ __device__ __forceinline__ void pack_index(long i, int Kpad, int mode, int layou
   if (mode < 2 || mode >= 4) {
     *r = (int)(i / Kpad);
     *k = (int)(i - (long)*r * Kpad);
-  } else if (layout == 1) {
-    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
-    long blk = i >> 9;
-    const int nchunk = cpad / 48;
-    const int mb = (int)(blk % 3); blk /= 3;
-    const int ks = (int)(blk % 14); blk /= 14;
-    const int cc = (int)(blk % nchunk), nt = (int)(blk / nchunk);
-    const int kk = ks * 32 + 8 * (l >> 4) + j;
-    *r = nt * 48 + mb * 16 + (l & 15);
-    *k = kk >= 432 ? 9 * cpad : (kk / 48) * cpad + cc * 48 + kk % 48;
   } else {
     const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
     const long blk = i >> 9;
@@ -692,7 +673,6 @@ __global__ __launch_bounds__(256) void pack_filters_batched_kernel(const PackJob
                    : (transposed ? j.w[((long)c * j.Cin + r) * taps + tsrc] : j.w[((long)r * j.Cin + c) * taps + tsrc]);
         }
       }
-      if (j.layout == 1 && j.mode >= 2 && k >= taps * cpad) continue;      // (Kpad counts the padding k-steps: left zero)
       const long o = j.mode < 2 ? (long)r * j.Kpad + k : frag_offset(j.layout, r, k, ksteps, cpad);
       j.out[o] = f2bf(v);
     }
@@ -956,9 +936,7 @@ int ssa_conv2d_igemm_tile(const ssa_conv_desc* dp) {
 int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW,
                     int cin_pad, int cout_pad, int Kpad, int mode, void* stream) {
   if (!w_oihw || !w_packed || mode < 0) return SSA_EINVAL;
-  // mode 2 / 3 + 8: the fragment order of conv_tile_q.hip (frag_offset layout 1)
-  const int layout = (mode == 10 || mode == 11) ? 1 : 0;
-  if (layout) mode -= 8;
+  const int layout = 0;
   if (mode > 7) return SSA_EINVAL;
   if (mode >= 4 && (KH != 3 || KW != 3)) return SSA_EINVAL;
   int rows = (mode & 1) == 0 && mode < 4 ? Cout : Cin;
@@ -966,10 +944,6 @@ int ssa_pack_filter(const float* w_oihw, void* w_packed, int Cout, int Cin, int 
   if (mode >= 4) kneed = (long)(1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) * cout_pad;
   if (mode < 2 || mode >= 4) {
     if (Kpad % BK || Kpad < kneed) return SSA_EINVAL;
-  } else if (layout == 1) {
-    const int cpad = (mode & 1) == 0 ? cin_pad : cout_pad;
-    if (KH != 3 || KW != 3 || cpad % 48 || Kpad != cpad / 48 * 448) return SSA_EINVAL;
-    rows = (rows + 47) / 48 * 48;
   } else {
     if (Kpad != kneed || Kpad % 16) return SSA_EINVAL;
     rows = (rows + 31) / 32 * 32;

@@ -103,21 +103,34 @@ GroupState& group_state();      // per host thread (forward: main thread, backwa
 void count_launches(int n);     // library-wide launch counter (ssa_launch_count)
 
 
-template <class K>
-int ensure_lds(const void* fn, size_t lds, size_t* set_to) {
-  if (lds > 64 * 1024 && lds > *set_to) {
+// The dynamic-LDS limit of a kernel is a property of (function, DEVICE): the raised limit is remembered per device
+// (hipFuncSetAttribute applies to the current device's code object only; one process normally drives one GPU, but a
+// process that touches two must raise the limit on each).
+constexpr int kMaxDevices = 16;
+struct LdsLimit { size_t set_to[kMaxDevices] = {}; };
+
+inline int raise_lds_limit(const void* fn, size_t lds, size_t threshold, LdsLimit* lim) {
+  if (lds <= threshold) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  if (lds > lim->set_to[dev]) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    *set_to = lds;
+    lim->set_to[dev] = lds;
   }
   return 0;
+}
+
+template <class K>
+int ensure_lds(const void* fn, size_t lds, LdsLimit* lim) {
+  return raise_lds_limit(fn, lds, 64 * 1024, lim);
 }
 
 template <class K>
 int flush_bucket(Bucket& b, hipStream_t s) {
   typedef typename K::Args Args;
   constexpr int J = GroupLimits<K>::jobs;
-  static size_t lds_single = 0, lds_grouped = 0;
+  static LdsLimit lds_single, lds_grouped;
   const int n = (int)b.gx.size();
   for (int j0 = 0; j0 < n; j0 += J) {
     const int cnt = n - j0 < J ? n - j0 : J;
@@ -166,7 +179,7 @@ int submit(const typename K::Args& a, int gx, int gy, size_t lds, hipStream_t s)
   const bool prof = profiling();
   if (prof) profile_take_note(&note_f, &note_b);
   if (g.depth == 0) {
-    static size_t lds_single = 0;
+    static LdsLimit lds_single;
     if (int e = ensure_lds<K>((const void*)k_single<K>, lds, &lds_single)) return e;
     void* ph = prof ? profile_open(kernel_name<K>(), s) : nullptr;
     hipLaunchKernelGGL(k_single<K>, dim3(gx, gy), dim3(K::NT), lds, s, a);

@@ -7,6 +7,7 @@
 // scaling pass.  RMI never materialises the [B,C,9,65025] fp64 neighbourhood
 // stack: Gram matrices are accumulated straight from the pooled maps.
 #include "common.h"
+#include "group.h"
 #include "../../include/semseg_hip.h"
 #include <float.h>
 
@@ -522,13 +523,9 @@ int ssa_ce_fwd(const float* logits, int ld, const int64_t* labels, long P, int C
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return (int)e;
   {   // the [NT][C] fp32 tile exceeds the default 64 KB of dynamic LDS from 65 classes (Mapillary) on
-    static size_t allowed = 64 * 1024;
-    const size_t need = (size_t)NT * C * sizeof(float);
-    if (need > allowed) {
-      e = hipFuncSetAttribute((const void*)pixel_loss_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-      if (e != hipSuccess) return (int)e;
-      allowed = need;
-    }
+    static ssa::LdsLimit lds_limit;         // per device (group.h)
+    if (int rc = ssa::raise_lds_limit((const void*)pixel_loss_kernel<0>, (size_t)NT * C * sizeof(float), 64 * 1024, &lds_limit))
+      return rc;
   }
   hipLaunchKernelGGL(pixel_loss_kernel<0>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
                      s, logits, ld, labels, P, C, ignore_index, acc, dlogits);
@@ -551,13 +548,9 @@ int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int 
     return SSA_OK;
   }
   {   // the [NT][C] fp32 tile exceeds the default 64 KB of dynamic LDS from 65 classes (Mapillary) on
-    static size_t allowed = 64 * 1024;
-    const size_t need = (size_t)NT * C * sizeof(float);
-    if (need > allowed) {
-      e = hipFuncSetAttribute((const void*)pixel_loss_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-      if (e != hipSuccess) return (int)e;
-      allowed = need;
-    }
+    static ssa::LdsLimit lds_limit;         // per device (group.h)
+    if (int rc = ssa::raise_lds_limit((const void*)pixel_loss_kernel<1>, (size_t)NT * C * sizeof(float), 64 * 1024, &lds_limit))
+      return rc;
   }
   hipLaunchKernelGGL(pixel_loss_kernel<1>, dim3(grid_for(P, 2048)), dim3(NT), NT * C * sizeof(float),
                      s, logits, ld, labels, P, C, 0, acc, dlogits);
@@ -607,13 +600,9 @@ int ssa_rmi_gram(const float* pooled_pr, const float* pooled_la, int BC, int Hp,
   const size_t lds = (size_t)2 * (GROWS + 2) * gram_stride(Wp) * sizeof(double);
   // wide crops (pooled width beyond ~620: crops wider than ~2,480 pixels at pool stride 4) need more than the default
   // 64 KB of dynamic LDS for the fp64 tiles: raise the kernel's limit, up to the CU's 160 KB (pooled width ~1,700)
-  static size_t lds_set = 0;
+  static ssa::LdsLimit lds_limit;           // per device (group.h)
   if (lds > 160 * 1024) return SSA_EUNSUPPORTED;
-  if (lds > 60000 && lds > lds_set) {
-    e = hipFuncSetAttribute((const void*)rmi_gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    lds_set = lds;
-  }
+  if (int rc = ssa::raise_lds_limit((const void*)rmi_gram_kernel, lds, 60000, &lds_limit)) return rc;
   hipLaunchKernelGGL(rmi_gram_kernel, dim3((Hp - 2 + GROWS - 1) / GROWS, BC), dim3(NT), lds, s,
                      pooled_pr, pooled_la, Hp, Wp, gram);
   SSA_LAUNCH_CHECK();

@@ -136,9 +136,12 @@ __global__ __launch_bounds__(kThreads) void amp_check_kernel(const SgdBatch tb, 
 }
 
 __global__ void amp_update_kernel(float* __restrict__ state, int growth_interval, float growth, float backoff,
-                                  float min_scale, float max_scale) {
+                                  float min_scale, float max_scale, float* __restrict__ counters) {
   if (threadIdx.x || blockIdx.x) return;
   float scale = state[0], good = state[2];
+  if (counters) {                     // {skipped steps in total, skipped steps in a row}: what a host-side log reads
+    if (state[1] != 0.f) { counters[0] += 1.f; counters[1] += 1.f; } else { counters[1] = 0.f; }
+  }
   if (state[1] != 0.f) {
     scale = fmaxf(scale * backoff, min_scale);
     good = 0.f;
@@ -222,13 +225,18 @@ extern "C" int ssa_amp_check_grads(const void* const* grads, const int64_t* nume
   return SSA_OK;
 }
 
-extern "C" int ssa_amp_update(float* amp_state, int growth_interval, float growth, float backoff, float min_scale,
-                              float max_scale, void* stream) {
+extern "C" int ssa_amp_update_counted(float* amp_state, float* counters, int growth_interval, float growth, float backoff,
+                                      float min_scale, float max_scale, void* stream) {
   if (!amp_state || growth_interval < 1 || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) ||
       !(min_scale > 0.f) || !(max_scale >= min_scale))
     return SSA_EINVAL;
   hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amp_state, growth_interval, growth,
-                     backoff, min_scale, max_scale);
+                     backoff, min_scale, max_scale, counters);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
+}
+
+extern "C" int ssa_amp_update(float* amp_state, int growth_interval, float growth, float backoff, float min_scale,
+                              float max_scale, void* stream) {
+  return ssa_amp_update_counted(amp_state, nullptr, growth_interval, growth, backoff, min_scale, max_scale, stream);
 }

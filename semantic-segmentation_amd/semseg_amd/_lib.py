@@ -168,6 +168,7 @@ _SIGS = {
     "ssa_sgd_momentum_step": ([_P, _P, _P, _P, c_int, c_float, _P, c_float, c_float, c_int, _P, _P], c_int),
     "ssa_amp_check_grads": ([_P, _P, c_int, _P, _P], c_int),
     "ssa_amp_update": ([_P, c_int, c_float, c_float, c_float, c_float, _P], c_int),
+    "ssa_amp_update_counted": ([_P, _P, c_int, c_float, c_float, c_float, c_float, _P], c_int),
     "ssa_ewise_f32": ([c_int, _P, _P, _P, c_long, _P], c_int),
     "ssa_ewise_bwd_f32": ([c_int, _P, _P, _P, _P, _P, c_long, _P], c_int),
     "ssa_axpy_f32": ([_P, c_float, _P, c_long, c_int, _P], c_int),

@@ -227,10 +227,8 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
-    layout = 1 if mode in (10, 11) else 0       # fragment order of csrc/conv_tile_q.hip (ssa_pack_filter mode 2 / 3 + 8)
+    layout = 0                  # one fragment order (reserved field of ssa_pack_job)
     api_mode = mode
-    if layout:
-        mode -= 8
     if mode >= 4:               # parity class (py, px) of a stride-2 data gradient: (1+py)*(1+px) taps
         rows, kdim = Cin, (1 + ((mode - 4) >> 1)) * (1 + ((mode - 4) & 1)) * cout_pad
     elif mode & 1 == 0:
@@ -239,10 +237,6 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
         rows, kdim = Cin, KH * KW * cout_pad
     if mode < 2 or mode >= 4:
         Kpad = _roundup(kdim, 32)
-    elif layout:                # 48-row n-tiles, 14 k-steps of 32 per 48-channel chunk (9 * 48 = 432 real)
-        cpad = cout_pad if mode & 1 else cin_pad
-        assert (KH, KW) == (3, 3) and cpad % 48 == 0, (KH, KW, cpad)
-        rows, Kpad = _roundup(rows, 48), cpad // 48 * 448
     else:                       # MFMA-fragment order (conv_tile.hip): rows padded to 32, K exact
         rows, Kpad = _roundup(rows, 32), kdim
     w = weight.detach()
@@ -772,7 +766,7 @@ def _fit_tile_strips(jobs, strip):
     launch carries up to 32 layers of one instantiation (csrc/group.h MAXJOBS) and its workgroups are persistent, so a launch
     of 552 or 640 workgroups runs as a full round on the chip's 512 slots (two 64 KB workgroups per CU) plus a tail
     round of the same length -- 96-105 us where 480 workgroups take 76 (profiles/r04_notes.md).  For every launch
-    pick the strip length in [strip, 2*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
+    pick the strip length in [strip, 6*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
     out = {}
     if not _WGRAD_FIT or strip <= 0:
         return out
@@ -1074,9 +1068,12 @@ def _bn_out(m, shape, device):
     if m.out is None:
         return torch.empty(shape, dtype=ACT_DTYPE, device=device), shape[3]
     z = m.out
-    assert tuple(z.shape) == tuple(shape) and z.dtype == ACT_DTYPE and z.stride(3) == 1 and z.stride(2) % 8 == 0 and \
-        z.stride(1) == shape[2] * z.stride(2) and z.stride(0) == shape[1] * z.stride(1) and z.data_ptr() % 16 == 0, \
-        "output slot does not fit the result"
+    fits = tuple(z.shape) == tuple(shape) and z.dtype == ACT_DTYPE and z.stride(3) == 1 and z.stride(2) % 8 == 0 and \
+        z.stride(1) == shape[2] * z.stride(2) and z.stride(0) == shape[1] * z.stride(1) and z.data_ptr() % 16 == 0
+    if not fits:
+        # a slot that does not fit the result (another model reusing the placement hint with other shapes): a fresh dense
+        # tensor -- ops.cat then finds the operands NOT adjacent (adjacent_slices) and concatenates by copy
+        return torch.empty(shape, dtype=ACT_DTYPE, device=device), shape[3]
     return z, z.stride(2)
 
 
@@ -1097,7 +1094,13 @@ def adjacent_slices(a, b):
 
 class CatViewFn(torch.autograd.Function):
     """torch.cat((a, b), dim=3) for two tensors that already are neighbouring channel slices of one buffer: the dense
-    view of that buffer, no copy; backward = the two slices of the gradient."""
+    view of that buffer, no copy; backward = the two slices of the gradient.
+
+    READ-ONLY contract: the result ALIASES the storage of both operands (and of the BatchNorm outputs the kernels wrote
+    into the slots through raw pointers); autograd does not know -- the version counters are not shared.  The result
+    and the slots must therefore never be written in place (no in-place ReLU / dropout on them): that would corrupt
+    tensors saved for backward without raising.  Its only consumer is the 1x1 conv of SpatialOCR_Module
+    (network/ocr_utils.py:149-158), which reads it; ops.HipBackend.cat falls back to a copying concat for anything else."""
 
     @staticmethod
     def forward(ctx, a, b):

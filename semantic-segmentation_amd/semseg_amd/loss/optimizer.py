@@ -49,6 +49,7 @@ class FusedSGD(optim.Optimizer):
                                       nesterov=nesterov))
         self._lr_dev = {}          # group index -> (device scalar, value it holds)
         self.loss_scaler = None    # semseg_amd.amp.LossScaler (fp16 training): un-scale, overflow test, skipped steps
+        self._pending_scaler_state = None   # a checkpoint's scaler state loaded before a scaler was attached
 
     def _lr_scalar(self, gi, group, device, capturing):
         ent = self._lr_dev.get(gi)
@@ -80,8 +81,11 @@ class FusedSGD(optim.Optimizer):
             # the overflow test covers EVERY gradient before any parameter moves (apex skips the whole step)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                      for group in self.param_groups for p in group["params"] if p.grad is not None]
+            if any(g.device != amp.state.device for g in grads):
+                raise RuntimeError("FusedSGD with a loss scaler drives ONE device per process: the overflow record lives "
+                                   "on %s, a gradient on another device" % amp.state.device)
             if grads:
-                with _launch_scope(grads[0].device) as (stream, _):
+                with _launch_scope(amp.state.device) as (stream, _):
                     amp.check(grads, stream)
         for gi, group in enumerate(self.param_groups):
             momentum = float(group["momentum"])
@@ -137,8 +141,11 @@ class FusedSGD(optim.Optimizer):
         state_dict = dict(state_dict)
         ls = state_dict.pop("loss_scaler", None)
         super().load_state_dict(state_dict)
-        if ls is not None and self.loss_scaler is not None:
-            self.loss_scaler.load_state_dict(ls)
+        if ls is not None:
+            if self.loss_scaler is not None:
+                self.loss_scaler.load_state_dict(ls)
+            else:                       # restored before amp.initialize: semseg_amd.amp.attach_scaler applies it
+                self._pending_scaler_state = dict(ls)
 
 
 def _mark_updated(tensors):

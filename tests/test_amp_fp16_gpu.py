@@ -103,7 +103,11 @@ def test_scale_bounds_and_state_dict_round_trip():
         opt.step()
     assert opt.loss_scaler.loss_scale() == 1.0
     sd = opt.state_dict()
-    assert sd["loss_scaler"] == {"loss_scale": 1.0, "unskipped": 0}
+    assert sd["loss_scaler"] == {"loss_scale": 1.0, "unskipped": 0, "skipped_steps": 5, "skipped_in_a_row": 5}
+    assert opt.loss_scaler.skipped_steps() == (5, 5)
+    said = []
+    opt.loss_scaler.warn_after = 4
+    assert "skipped" in opt.loss_scaler.health(said.append) and said      # five overflows in a row at the lower bound
     q = torch.zeros(100, device=DEV, requires_grad=True)
     opt2 = FusedSGD([q], lr=0.1, momentum=0.9)
     opt2.loss_scaler = LossScaler(torch.device(DEV))
@@ -112,6 +116,17 @@ def test_scale_bounds_and_state_dict_round_trip():
     sd["loss_scaler"] = {"loss_scale": 256.0, "unskipped": 7}
     opt2.load_state_dict(sd)
     assert opt2.loss_scaler.state.cpu().tolist()[:3] == [256.0, 0.0, 7.0]
+    assert opt2.loss_scaler.health() is None
+    # a checkpoint restored BEFORE the scaler exists (amp.initialize comes later): kept, applied on attach (advisor, r5)
+    r = torch.zeros(100, device=DEV, requires_grad=True)
+    opt3 = FusedSGD([r], lr=0.1, momentum=0.9)
+    r.grad = torch.ones_like(r)
+    opt3.step()
+    opt3.load_state_dict(sd)
+    assert opt3.loss_scaler is None and opt3._pending_scaler_state["loss_scale"] == 256.0
+    from semseg_amd import amp as samp
+    sc = samp.attach_scaler(opt3, torch.device(DEV))
+    assert sc.state.cpu().tolist()[:3] == [256.0, 0.0, 7.0] and opt3._pending_scaler_state is None
 
 
 def test_scaled_step_replays_as_a_graph():

@@ -263,9 +263,37 @@ def test_eval_nscale(setup):
     for k in sorted(ref):
         print("nscale %-10s rel err hip %.4f emu %.4f" % (k, eh_all[k], ee_all[k]))
         assert torch.isfinite(hip[k]).all() and hip[k].shape == ref[k].shape
+    from util import ACT_DTYPE
     for k in sorted(ref):
         bound = 1.5 * worst[kind(k)] + 5e-3
         assert eh_all[k] <= bound, (k, eh_all[k], ee_all[k], bound)
+        if ACT_DTYPE == torch.float16:
+            # fp16 storage (the reference's own format) sits an order of magnitude closer to the oracle: at ~1e-2 the
+            # amplified noise no longer decides an output's error, so EVERY output is held to its own emulation
+            # error (the per-output bound of round 3, asked back by the round-5 review) and to an absolute level
+            assert eh_all[k] <= 1.5 * ee_all[k] + 1e-2, (k, eh_all[k], ee_all[k])
+            assert eh_all[k] <= 0.06, (k, eh_all[k])
     mh, me = sum(eh_all.values()) / len(eh_all), sum(ee_all.values()) / len(ee_all)
     print("nscale mean over the outputs: hip %.4f emu %.4f" % (mh, me))
     assert mh <= 1.25 * me + 5e-3, (mh, me)
+
+
+def test_smoke_entry():
+    """`__graft_entry__.smoke()` -- what the driver runs before the bench -- is part of the suite (advisor, round 5):
+    one 2 x 3 x 128 x 256 training step on the HIP path against the oracle (loss 5e-3, classifier-gradient cosine 0.99)."""
+    import importlib
+    import os
+    import sys
+    from util import ACT_DTYPE
+    if ACT_DTYPE == torch.float16:
+        pytest.skip("smoke() is the default (bf16) build's entry; fp16 training goes through the loss scaler "
+                    "(tests/test_amp_fp16_gpu.py)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from semseg_amd.config import cfg
+    saved = (cfg.LOSS.SUPERVISED_MSCALE_WT, cfg.MODEL.N_SCALES)
+    try:
+        importlib.import_module("__graft_entry__").smoke()
+    finally:
+        cfg.LOSS.SUPERVISED_MSCALE_WT, cfg.MODEL.N_SCALES = saved

@@ -55,3 +55,11 @@ def test_eval_teacher_forced_on_the_fp16_build():
     pixel and fp32 summation order picked the row of V.  With calibrated buffers (calibrate_eval_bn) the harness asserts
     the operand ranges and the op holds the one-rounding bound."""
     _run(["tests/test_parity_eval_gpu.py", "-k", "three_scales_small or single_scale_1024x2048"], "fp16_eval_parity.log", 900)
+
+
+@pytest.mark.gpu
+def test_eval_mapillary_teacher_forced_on_the_fp16_build():
+    """BASELINE configs[4] in the format it names (fp16): the recipe's four-scale chain {0.25, 0.5, 1.0, 2.0} at
+    896 x 1152 and the three-scale case at 1152 x 1536 (2.0x pass 2304 x 3072), 65 classes, teacher-forced op by op at
+    one-rounding tolerance on libsemseg_hip_f16.so (scripts/eval_mapillary.yml:10-18, network/ocrnet.py:185-262)."""
+    _run(["tests/test_parity_eval_gpu.py", "-k", "mapillary_65_classes"], "fp16_eval_mapillary.log", 1500)

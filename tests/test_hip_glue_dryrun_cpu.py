@@ -177,7 +177,7 @@ def test_loss_scaler_glue(dry, monkeypatch):
 
     def spy(self, name):
         fn = real_getattr(self, name)
-        if name in ("ssa_amp_check_grads", "ssa_sgd_momentum_step", "ssa_amp_update"):
+        if name in ("ssa_amp_check_grads", "ssa_sgd_momentum_step", "ssa_amp_update_counted"):
             def wrapped(*a):
                 order.append(name)
                 return fn(*a)
@@ -197,7 +197,7 @@ def test_loss_scaler_glue(dry, monkeypatch):
         opt.step()
     finally:
         hip_backend.enable_fp16_training(False)
-    assert order[0] == "ssa_amp_check_grads" and order[-1] == "ssa_amp_update"
+    assert order[0] == "ssa_amp_check_grads" and order[-1] == "ssa_amp_update_counted"
     first_sgd = order.index("ssa_sgd_momentum_step")
     assert all(n == "ssa_amp_check_grads" for n in order[:first_sgd])           # every check before the first update
     assert all(n == "ssa_sgd_momentum_step" for n in order[first_sgd:-1])

@@ -134,3 +134,27 @@ def test_deepv3_oracle_matches_reference():
         pred = DeepV3PlusNet(sd2, 19, training=False).forward(gold["images"])["pred"]
     ref = gold["eval_pred"]
     assert float((pred[:, :, ::8, ::8] - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_mscale_eval_four_scales_65_classes_matches_reference():
+    """BASELINE configs[4]'s recipe chain (scripts/eval_mapillary.yml:13-18: n_scales 0.25,0.5,1.0,2.0, 65 classes):
+    `nscale_forward` (network/ocrnet.py:185-262) performs two consecutive `s < 1.0` fusions; the oracle against the
+    real reference's outputs (tests/golden/make_golden_nscale4.py), every key of the output dict (the fixture also holds the
+    three-scale chain on the same 65-class weights; the 19-class three-scale chain is pinned above)."""
+    from oracle.model import Net, seeded_state_dict
+    g = _load("nscale4_golden.pt")
+    assert g["num_classes"] == 65 and g["scales4"] == [0.25, 0.5, 1.0, 2.0]
+    sd = seeded_state_dict(g["shapes"], seed=g["seed"])
+    for k, v in g["calib_buffers"].items():
+        sd[k].copy_(v)
+    net = Net(sd, 65, training=False)
+
+    def sample(v):
+        st = 16 if v.shape[1] > 1 else 8
+        return v[:, :, ::st, ::st]
+
+    with torch.no_grad():
+        o = net.nscale_forward(g["images"], g["scales4"])
+    assert sorted(o) == sorted(g["eval_nscale4"]), (sorted(o), sorted(g["eval_nscale4"]))
+    for k, v in g["eval_nscale4"].items():
+        check_close("nscale4 " + k, sample(o[k]), v, 1e-4, 1e-4)

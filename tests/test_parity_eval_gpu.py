@@ -231,3 +231,17 @@ def test_eval_mapillary_65_classes_three_scales():
     tb, out = _teacher_eval("HRNet_Mscale", 65, [0.5, 1.0, 2.0], 1152, 1536)
     for k in ("pred_0.5x", "pred_2.0x", "attn_1.0x"):
         assert k in out, sorted(out)
+
+
+def test_eval_mapillary_65_classes_four_scales():
+    """BASELINE configs[4] as the reference's recipe chains it (scripts/eval_mapillary.yml:13-18:
+    n_scales 0.25,0.5,1.0,2.0): `nscale_forward` (network/ocrnet.py:185-262) runs 2.0 -> 1.0 -> 0.5 -> 0.25 and fuses
+    TWICE through the `s < 1.0` branch (attention-weighted logits resampled UP to the running prediction).  896 x 1152:
+    the 0.25x pass is 224 x 288 (its trunk ends at 7 x 9 pixels), the 2.0x pass 1792 x 2304; 65 classes.  The oracle's
+    four-scale chain is pinned to the real reference by tests/golden/nscale4_golden.pt
+    (tests/test_oracle_golden.py::test_mscale_eval_four_scales_65_classes_matches_reference); this test runs on both
+    storage builds (tests/test_fp16_storage_gpu.py runs it on the fp16 build, the format BASELINE names)."""
+    tb, out = _teacher_eval("HRNet_Mscale", 65, [0.25, 0.5, 1.0, 2.0], 896, 1152)
+    for k in ("pred_0.25x", "pred_0.5x", "pred_1.0x", "pred_2.0x", "attn_0.25x", "attn_0.5x", "attn_1.0x"):
+        assert k in out, sorted(out)
+    assert "attn_2.0x" not in out

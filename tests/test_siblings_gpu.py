@@ -93,7 +93,8 @@ def test_sibling_eval_op_by_op(name):
     assert ah >= ae - 0.05, (ah, ae)
 
 
-@pytest.mark.parametrize("name,crit,wt", [("mscale.HRNet", "rmi", 0.05), ("mscale2.DeepV3R50", "ce", 0.0)])
+@pytest.mark.parametrize("name,crit,wt", [("mscale.HRNet", "rmi", 0.05), ("mscale2.DeepV3R50", "ce", 0.0),
+                                          ("ocrnet.HRNet", "rmi", 0.0)])     # the plain OCR network's TRAINING step
 def test_sibling_train_step(name, crit, wt):
     from semseg_amd import ops
     from oracle_backend import OracleBackend
