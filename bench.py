@@ -75,7 +75,7 @@ def _lib_sha():
     return _lib.built_sha()
 
 
-CONV_FAMILIES = ("ConvTile", "ConvHaloGemm", "ConvIgemm", "ConvWgradTile", "ConvWgradHead", "ConvWgradTr")
+CONV_FAMILIES = ("ConvTile", "ConvHaloGemm", "ConvGemmWide", "ConvIgemm", "ConvWgradTile", "ConvWgradHead", "ConvWgradTr")
 
 
 def source_sha():
@@ -96,7 +96,9 @@ def family(kernel):
     if f in ("ConvTileAny", "ConvTilePAny", "ConvTilePK", "ConvTileP"):
         return "ConvTile"
     # the head convs: conv_halo_gemm.hip (3x3: ConvHaloGemm3, 1x1: ConvHaloGemm1), conv_wgrad_head.hip (3x3: ...Head3)
-    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead"}.get(f, f)
+    # conv_gemm_wide.hip: the large 1x1 convs on the 256 x 256 tile
+    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
+            "ConvGemmWide1": "ConvGemmWide"}.get(f, f)
 
 
 def synth_batch(B, H, W, rank, device):

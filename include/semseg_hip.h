@@ -158,6 +158,18 @@ int ssa_conv2d_halo_supported(const ssa_conv_desc* d);
 int ssa_conv2d_halo(const ssa_conv_desc* d, const void* x, const void* w_frag,
                     const float* bias, void* y, double* stats, void* stream);
 
+/* Wide-tile GEMM for the large 1x1 stride-1 convs of the OCR / attention heads and their data gradients (aux_head
+ * 720->720, SpatialOCR 1024->512, f_up 256->512; network/ocrnet.py:61-76, network/ocr_utils.py:68-93,142-156):
+ * 256 pixels x 256 output channels per workgroup, 128 x 64 per wave (4 x 2 MFMA 32x32x16 tiles), both operands by
+ * global_load_lds in 32-channel stages through a ring of four LDS buffers (csrc/conv_gemm_wide.hip).  Same operands
+ * as ssa_conv2d_halo (w_frag: ssa_pack_filter mode 2 / 3 with cin_pad = d->Cin, a multiple of 16); 16-bit output
+ * only; stats as for ssa_conv2d_tile.  ssa_conv2d_halo forwards the problems for which
+ * ssa_conv2d_gemm_wide_supported() returns 1 (1x1, more than 256 output channels, >= 16384 pixels; SSA_GEMM_WIDE=0
+ * keeps them on the 256 x 128 kernel); the entry point itself takes any 1x1 stride-1 problem of >= 256 pixels.   */
+int ssa_conv2d_gemm_wide_supported(const ssa_conv_desc* d);
+int ssa_conv2d_gemm_wide(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias,
+                         void* y, double* stats, void* stream);
+
 /* Tile configuration ssa_conv2d_igemm would use for this problem
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);

@@ -210,6 +210,12 @@ __device__ __forceinline__ void bn_apply_rows(const RowSet<ROWS>& rs, const uint
       *reinterpret_cast<uint4*>(zb + (long)rs.off[u] * ldz) = pk;
       if (mrow) mrow[(long)rs.off[u] * (C >> 3)] = (unsigned char)positive_bits(pk);
     }
+#ifndef SSA_EMU
+    // one row at a time: left alone the scheduler unpacks all ROWS rows side by side (16 more registers per row) and the
+    // training apply lands on 129 registers -- one over the 128 that let FOUR workgroups share a CU, i.e. a trunk
+    // level's ~930 workgroups all be resident at once instead of 768 + a second round (profiles/r06_notes.md)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
@@ -252,7 +258,7 @@ template <int ROWS>
 __device__ __forceinline__ void bn_apply_train_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
     bf16_t* __restrict__ z, int ldz, long P, int C, const double* __restrict__ sums, int nrep,
-    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+    double count, double inv_count, double unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ running_mean, float* __restrict__ running_var,
     long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ coef,
     float* __restrict__ pass_stats, int relu, const float* __restrict__ post, long pix_per_img,
@@ -273,10 +279,18 @@ __device__ __forceinline__ void bn_apply_train_body(
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     replica_sums(sums, nrep, C, c, &s1, &s2);
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    // This prologue sits on the critical path of EVERY workgroup (the launch is one round of ~900 workgroups: its
+    // duration is a workgroup's lifetime), so it holds no fp64 division or square root -- software sequences of a few
+    // hundred dependent instructions each: the same pass with the coefficients given ran 6.5 us against 12.8 with them
+    // (tools/bnbench.py, profiles/r06_notes.md).  1 / count and count / (count - 1) come from the host;
+    // 1 / sqrt(var + eps) is v_rsq_f32 plus one Newton step (the result is stored as fp32 anyway: <= 1 ulp of it).
+    const double mean = s1 * inv_count;
+    double var = s2 * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float ve = (float)(var + (double)eps);
+    float rs = ssa_rsqrt(ve);
+    rs = rs * (1.5f - 0.5f * ve * rs * rs);
+    const double invstd = (double)rs;
     const double g = gamma ? (double)gamma[c] : 1.0;
     const double b = beta ? (double)beta[c] : 0.0;
     const float sc = (float)(g * invstd), sf = (float)(b - mean * g * invstd);
@@ -288,7 +302,7 @@ __device__ __forceinline__ void bn_apply_train_body(
       coef[2 * C + c] = (float)mean;
       coef[3 * C + c] = (float)invstd;
       if (running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        const double unbiased = var * unbias;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
       }
@@ -409,46 +423,54 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
   block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, bx, nrep);
 }
 
-template <int ROWS>
+// MODE: where the ReLU mask comes from -- 0: the forward's sign bytes (or there is no ReLU), 1: recomputed from x
+// (mask scale / shift), 2: read off z.  Compile-time, so that each form holds only its own operands in registers.
+template <int ROWS, int MODE>
 __device__ __forceinline__ void bn_bwd_apply_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
     bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    const double* __restrict__ sums, int nrep, double count, int relu,
+    const double* __restrict__ sums, int nrep, double inv_count, int relu,
     const float* __restrict__ post, long pix_per_img, long pix_per_block,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
     const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg,
     const unsigned char* __restrict__ mask, const int bx) {
-  SSA_DYN_LDS(float, sh);                 // [7C]: mean, invstd, gamma*invstd, sum_g/N, sum_gxhat/N, mask scale, mask shift
+  // dx = a (g - c1 - xhat c2),  xhat = (x - mean) invstd,  a = gamma invstd,  c1 = sum_g / N,  c2 = sum_g_xhat / N
+  //    = A g + (Bx x + D)   with   A = a,  Bx = -a c2 invstd,  D = a (c2 invstd mean - c1):
+  // three per-channel constants in registers instead of five (this pass ran at 173 registers = TWO workgroups per CU;
+  // a trunk level is ~930 workgroups, i.e. two rounds -- with <= 128 registers all of it is resident at once)
+  SSA_DYN_LDS(float, sh);                 // [5C]: A, Bx, D, mask scale, mask shift
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
   const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
-  const bool use_bits = relu && !mscale && mask != nullptr;
-  const bool use_z = relu && !mscale && !use_bits;
+  constexpr bool ZMASK = MODE == 2;
+  const bool use_bits = MODE == 0 && relu && mask != nullptr;
+  const bool from_x = MODE == 1 && relu;
   const long pb = bx * pix_per_block;
   const long pe = min(P, pb + pix_per_block);
   // ---- the first chunk's loads, then the coefficient prologue while they are in flight
   RowSet<ROWS> rs;
   rs.init(pb, pe, pr, RP, active);
-  uint4 gv[ROWS], xr[ROWS], zr[ROWS];
-  unsigned mk[ROWS];
+  uint4 gv[ROWS], xr[ROWS], zr[ZMASK ? ROWS : 1];
+  unsigned mk[MODE == 0 ? ROWS : 1];
   rs.load(dz + pb * lddz + cg * 8, lddz, gv);
   rs.load(x + pb * ldx + cg * 8, ldx, xr);
-  if (use_z) rs.load(z + pb * ldz + cg * 8, ldz, zr);
-  if (use_bits) load_sign_bytes<ROWS>(rs, mask + pb * VC + cg, VC, mk);
+  if constexpr (ZMASK) rs.load(z + pb * ldz + cg * 8, ldz, zr);
+  if constexpr (MODE == 0) { if (use_bits) load_sign_bytes<ROWS>(rs, mask + pb * VC + cg, VC, mk); }
   for (int c = t; c < C; c += NT) {
     double s1 = 0.0, s2 = 0.0;
     replica_sums(sums, nrep, C, c, &s1, &s2);
-    const float is_ = invstd[c];
-    sh[c] = mean[c];
-    sh[C + c] = is_;
-    sh[2 * C + c] = (gamma ? gamma[c] : 1.f) * is_;
-    sh[3 * C + c] = (float)(s1 / count);
-    sh[4 * C + c] = (float)(s2 / count);
-    sh[5 * C + c] = mscale ? mscale[c] : 0.f;
-    sh[6 * C + c] = mscale ? mshift[c] : 0.f;
+    const float is_ = invstd[c], mu_ = mean[c];
+    const float a_ = (gamma ? gamma[c] : 1.f) * is_;
+    const float c1_ = (float)(s1 * inv_count);    // (no fp64 division on every workgroup's critical path: see the apply)
+    const float c2_ = (float)(s2 * inv_count);
+    sh[c] = a_;
+    sh[C + c] = -a_ * c2_ * is_;
+    sh[2 * C + c] = a_ * (c2_ * is_ * mu_ - c1_);
+    sh[3 * C + c] = mscale ? mscale[c] : 0.f;
+    sh[4 * C + c] = mscale ? mshift[c] : 0.f;
     if (bx == 0) {
       // accumulate_pg: the gradient buffer is shared by every pass over this layer (cleared once
       // per step); passes grouped into one launch add concurrently, hence the atomics
@@ -463,13 +485,18 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   }
   __syncthreads();
   if (!active) return;
-  float mu[8], is[8], a[8], c1[8], c2[8], ma[8], mb[8];
+  float A[8], Bx[8], D[8], ma[8], mb[8];
   {
     auto ld8 = [&](int row, float (&o)[8]) {
       const float4 v0 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8), v1 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8 + 4);
       o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
     };
-    ld8(0, mu); ld8(1, is); ld8(2, a); ld8(3, c1); ld8(4, c2); ld8(5, ma); ld8(6, mb);
+    ld8(0, A); ld8(1, Bx); ld8(2, D);
+    if constexpr (MODE == 1) { ld8(3, ma); ld8(4, mb); }
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ma[j] = 0.f; mb[j] = 0.f; }
+    }
   }
   for (long p0 = pb;;) {
 #pragma unroll
@@ -478,24 +505,25 @@ __device__ __forceinline__ void bn_bwd_apply_body(
       unpack8(gv[u], g);
       unpack8(xr[u], xv);
       const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
-      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp, use_bits, use_bits ? mk[u] : 0u);
+      bn_bwd_mask(g, xv, zr[ZMASK ? u : 0], ZMASK && relu, relu, from_x, ma, mb, pp, use_bits,
+                  (MODE == 0 && use_bits) ? mk[MODE == 0 ? u : 0] : 0u);
       const bool ok = (rs.ok >> u) & 1u;
       if (dres && ok) *reinterpret_cast<uint4*>(dres + (p0 + rs.off[u]) * lddres + cg * 8) = pack8(g);
       float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh = (xv[j] - mu[j]) * is[j];
-        o[j] = a[j] * (g[j] - c1[j] - xh * c2[j]);
-      }
+      for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + (Bx[j] * xv[j] + D[j]);
       if (ok) *reinterpret_cast<uint4*>(dx + (p0 + rs.off[u]) * lddx + cg * 8) = pack8(o);
+#ifndef SSA_EMU
+      __builtin_amdgcn_sched_barrier(0);        // one row at a time (register pressure: see bn_apply_rows)
+#endif
     }
     p0 += (long)RP * ROWS;
     if (p0 >= pe) break;
     rs.init(p0, pe, pr, RP, true);
     rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
     rs.load(x + p0 * ldx + cg * 8, ldx, xr);
-    if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
-    if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk);
+    if constexpr (ZMASK) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
+    if constexpr (MODE == 0) { if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk); }
   }
 }
 
@@ -538,13 +566,14 @@ struct BnApplyK {
 };
 template <int ROWS>
 struct BnApplyTrainK {
+  static constexpr int WPE = ROWS <= 4 ? 4 : 2;      // <= 128 registers: four workgroups per CU (a trunk level resident at once)
   struct Args { const bf16_t* x; const bf16_t* res; bf16_t* z; const double* sums; const float* gamma;
                 const float* beta; float* running_mean; float* running_var; long* nbt; float* coef;
-                float* pass_stats; const float* post; unsigned char* mask; double count; long P, pix_per_img, ppb;
-                int ldx, ldr, ldz, C, nrep, relu; float momentum, eps; };
+                float* pass_stats; const float* post; unsigned char* mask; double count, inv_count, unbias;
+                long P, pix_per_img, ppb; int ldx, ldr, ldz, C, nrep, relu; float momentum, eps; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_apply_train_body<ROWS>(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.gamma,
+    bn_apply_train_body<ROWS>(a.x, a.ldx, a.res, a.ldr, a.z, a.ldz, a.P, a.C, a.sums, a.nrep, a.count, a.inv_count, a.unbias, a.gamma,
                               a.beta, a.running_mean, a.running_var, a.nbt, a.momentum, a.eps, a.coef,
                               a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, a.mask, bx);
   }
@@ -560,20 +589,27 @@ struct BnBwdReduceK {
                              a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, a.mask, bx);
   }
 };
-template <int ROWS>
-struct BnBwdApplyK {
+template <int ROWS, int MODE>
+struct BnBwdApplyKM {
+  static constexpr int WPE = ROWS <= 4 ? 4 : 2;  // <= 128 registers: four workgroups per CU (see bn_bwd_apply_body)
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; bf16_t* dx; bf16_t* dres;
                 const float* gamma; const float* mean; const float* invstd; const double* sums;
                 const float* post; float* dgamma; float* dbeta; const float* mscale; const float* mshift;
-                const unsigned char* mask; double count; long P, pix_per_img, ppb; int ldx, lddz, ldz, lddx, lddres, C, nrep, relu;
+                const unsigned char* mask; double inv_count; long P, pix_per_img, ppb; int ldx, lddz, ldz, lddx, lddres, C, nrep, relu;
                 float param_grad_scale; int accumulate_pg; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_bwd_apply_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
-                            a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.count, a.relu, a.post, a.pix_per_img,
+    bn_bwd_apply_body<ROWS, MODE>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
+                            a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.inv_count, a.relu, a.post, a.pix_per_img,
                             a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg, a.mask, bx);
   }
 };
+// (BnBwdApplyK is the name the profiles know: the sign-byte / no-ReLU form -- bn2 of a block; XK recomputes the mask
+// from x -- bn1; ZK reads z)
+template <int ROWS> struct BnBwdApplyK : BnBwdApplyKM<ROWS, 0> {};
+template <int ROWS> struct BnBwdApplyXK : BnBwdApplyKM<ROWS, 1> {};
+template <int ROWS> struct BnBwdApplyZK : BnBwdApplyKM<ROWS, 2> {};
+
 
 __global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,7 +737,8 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
   const Grid g = plan_grid(P, C, apply_rows());
   return SSA_BN_SUBMIT(BnApplyTrainK, g, ({(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta,
                                            running_mean, running_var, num_batches_tracked, coef, pass_stats, post,
-                                           (unsigned char*)sign_mask, count,
+                                           (unsigned char*)sign_mask, count, 1.0 / count,
+                                           count > 1.0 ? count / (count - 1.0) : 1.0,
                                            P, pix_per_img, g.ppb, ldx, ldr, ldz, C, nrep, relu, momentum, eps}),
                        2 * C * sizeof(float), (hipStream_t)stream);
 }
@@ -746,11 +783,16 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
   const Grid g = plan_grid(P, C, bwd_rows());
-  return SSA_BN_SUBMIT(BnBwdApplyK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres,
-                                         gamma, mean, invstd, sums, post, dgamma, dbeta, mask_scale, mask_shift,
-                                         (const unsigned char*)sign_mask, count, P,
-                                         pix_per_img, g.ppb, ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale,
-                                         accumulate_param_grads}), 7 * C * sizeof(float), (hipStream_t)stream);
+  // one instantiation per source of the ReLU mask (bn_bwd_apply_body's MODE)
+#define SSA_BN_BWD_APPLY(K)                                                                                              \
+  SSA_BN_SUBMIT(K, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres, gamma, mean, invstd, \
+                        sums, post, dgamma, dbeta, mask_scale, mask_shift, (const unsigned char*)sign_mask, 1.0 / count, P,    \
+                        pix_per_img, g.ppb, ldx, lddz, ldz, lddx, lddres, C, nrep, relu, param_grad_scale,                     \
+                        accumulate_param_grads}), 5 * C * sizeof(float), (hipStream_t)stream)
+  if (relu && mask_scale) return SSA_BN_BWD_APPLY(BnBwdApplyXK);
+  if (relu && !sign_mask) return SSA_BN_BWD_APPLY(BnBwdApplyZK);
+  return SSA_BN_BWD_APPLY(BnBwdApplyK);
+#undef SSA_BN_BWD_APPLY
 }
 
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {

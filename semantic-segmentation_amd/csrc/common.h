@@ -200,6 +200,15 @@ template <typename T> __device__ __forceinline__ void st_from_f32(T* p, float v)
 template <> __device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_from_f32<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// 1 / sqrt(v): v_rsq_f32 (1 ulp) -- callers that want fp32-exact results follow it with one Newton step
+__device__ __forceinline__ float ssa_rsqrt(float v) {
+#ifdef SSA_EMU
+  return 1.0f / sqrtf(v);
+#else
+  return __builtin_amdgcn_rsqf(v);
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

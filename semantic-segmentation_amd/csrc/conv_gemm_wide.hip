@@ -1,0 +1,305 @@
+// Wide-tile GEMM for the large 1x1 convolutions of the OCR / attention heads and their data gradients
+// (gfx950 / MI355X): aux_head 720->720, SpatialOCR 1024->512, f_up 256->512, f_pixel 512->256, and the transposed
+// forms (network/ocrnet.py:61-76, network/ocr_utils.py:68-93,142-156).
+//
+//   y[p][n] = sum_c x[p][c] * w[n][c]            p = flattened (b, y, x) pixel, no spatial structure
+//
+// conv_halo_gemm.hip's 1x1 kernel gives a workgroup 256 pixels x 128 channels, 64 x 64 per wave: every MFMA wants one
+// ds_read_b128 and a 16-channel k-step moves 12 KiB through the L1 -> LDS path (64 B/clk/CU) per 32 MFMAs -- 75 % of
+// that path, which is what bounds it (0.12-0.17 of the MFMA peak, profiles/r05_pmc.txt).  Here
+//   * workgroup tile 256 pixels x 256 channels, 8 wave64s as 2 (pixels) x 4 (channels), 128 x 64 per wave = 4 x 2
+//     MFMA 32x32x16 tiles (128 accumulator registers): a k-step reads 6 fragments for 8 MFMAs and moves 16 KiB per 64
+//     MFMAs -- half the L1 -> LDS bytes and 3/4 of the LDS reads per MFMA;
+//   * both operands arrive by LDS DMA (global_load_lds_dwordx4: no registers, no ds_write) in CK-channel stages into a
+//     ring of RING buffers.  <CK = 64, RING = 2> (the shipped form): a stage fetches whole 128-byte lines of every pixel
+//     (64 B per pixel and stage -- CK = 32 -- reads every line of x twice, half a line at a time: 256 pixels x 128 B is
+//     the whole L1), 32 MFMAs per wave between barriers, the next stage's DMAs issued at the top of the stage, the
+//     stage ends in  s_waitcnt vmcnt(0) ; s_barrier.  <CK = 32, RING = 4> keeps three stages in flight and ends a stage
+//     in  s_waitcnt vmcnt(K) ; s_barrier  with K = the DMAs issued after the stage after next (memory operations retire
+//     in order) -- conv_halo_gemm.hip's 3x3 protocol with one "tap" -- and reads its first fragments across the barrier;
+//   * the pixel tile lies in LDS pixel-major, 2 CK bytes per pixel and stage, the 16-byte piece q of pixel p in slot
+//     q ^ ((p >> 1) & 7) (CK = 64) / q ^ ((p >> 2) & 3) (CK = 32): the 16 lanes a ds_read_b128 services together read
+//     one q of 16 pixels with distinct p mod 16, i.e. 16 distinct 16-byte slots of the 256-byte bank row (a DMA fills
+//     64 CONSECUTIVE slots; which piece a lane fetches is free, so the swizzle sits in the source address);
+//   * the filter is conv_halo_gemm.hip's: MFMA-fragment order [n-block][k-step][lane][8] (ssa_pack_filter mode 2 / 3).
+// Cin need only be a multiple of 16: the last 32-channel stage of Cin = 720 fetches zero pieces for channels >= Cin
+// (and a clamped, finite filter block: 0 * w = 0).
+#include "common.h"
+#include "group.h"
+#include "../../include/semseg_hip.h"
+
+#ifndef SSA_WIDE_CK          // experiment builds (tools/expbuild.sh) compile the other stage form: -DSSA_WIDE_CK=32 -DSSA_WIDE_RING=4
+#define SSA_WIDE_CK 64
+#define SSA_WIDE_RING 2
+#endif
+
+namespace {
+
+constexpr int kStatReplicasW = 8;   // must equal conv_tile.hip's kStatReplicas
+
+__device__ uint4 g_zero_piece_w;    // 16 zero bytes: what a piece outside the tile / past Cin loads
+
+struct WideArgs {
+  const bf16_t* x; const uint4* wfrag; const float* bias; void* y; double* stats;
+  long P;                        // pixels (B * H * W)
+  int ldx, Cin, ldy, out_f32, Cout, nb_total, ptiles;
+};
+
+template <int CK, int RING>
+struct ConvGemmWide1 {
+  typedef WideArgs Args;
+  static constexpr int NT = 512;
+  static constexpr int BM = 256, NB = 8, CST = CK / 16;
+  static constexpr int PPX = CK / 8;                     // 16-byte pieces per pixel and stage (4 or 8)
+  static constexpr int PSH = CK == 64 ? 7 : 6;           // log2 of the pixel stride in LDS
+  static constexpr int A_BYTES = BM * CK * 2;            // 256 pixels x 2 CK bytes
+  static constexpr int B_BYTES = NB * CST * 1024;        // NB x CST fragment blocks
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int NA = A_BYTES / 1024 / 8;          // A DMAs per wave and stage
+  static constexpr int NF = NB * CST / 8;                // filter DMAs per wave and stage
+  static constexpr int D = RING - 1;                     // stages in flight
+  static constexpr bool AHEAD = RING >= 4;               // counted waits + fragment read-ahead across the barrier
+  static constexpr size_t PIPE_BYTES = (size_t)RING * STAGE_BYTES;
+  static constexpr int LDC = NB * 32 + 8;                // epilogue staging: [256][264] elements + [2][2][256] floats
+  static constexpr size_t EPI_BYTES = (size_t)BM * LDC * 2 + 2 * 2 * 256 * sizeof(float);
+  static constexpr size_t LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+  static_assert(CK == 32 || CK == 64, "stage width");
+  static_assert(RING == 2 || RING >= 4, "double buffer, or a ring deep enough to read ahead into the next stage");
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit in LDS");
+
+  // slot of piece q of tile pixel p
+  static __device__ __forceinline__ int swz(int p, int q) { return CK == 64 ? (q ^ ((p >> 1) & 7)) : (q ^ ((p >> 2) & 3)); }
+
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const uint4* __restrict__ wfrag = a.wfrag;
+  const int ldx = a.ldx, Cin = a.Cin, nb_total = a.nb_total;
+  const long P = a.P;
+  SSA_DYN_LDS(unsigned char, smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;      // 2 x 4 waves
+  const long p0 = (long)bx * BM;
+  const int nb0 = by * NB;
+  const int nchunk = (Cin + CK - 1) / CK;
+  const int ksteps = Cin / 16;
+  const int last = nchunk - 1;
+
+  // this lane's NA pieces of a stage's pixel tile: wave instruction wi = i * 8 + wave fills slots 64 wi .. 64 wi + 63 =
+  // 64 / PPX pixels; lane l -> pixel wi * (64 / PPX) + l / PPX, slot l % PPX, i.e. the piece the swizzle puts there
+  const bf16_t* a_ptr[NA];
+  unsigned ok_mask = 0, ok_last_mask = 0;       // bit i: piece i lies inside the image (and, last stage, below Cin)
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int wi = i * 8 + wave;
+    const int pl = wi * (64 / PPX) + lane / PPX;
+    const int q = swz(pl, lane % PPX);
+    const bool ok = p0 + pl < P;
+    ok_mask |= (ok ? 1u : 0u) << i;
+    ok_last_mask |= ((ok && last * CK + q * 8 < Cin) ? 1u : 0u) << i;
+    a_ptr[i] = a.x + (p0 + (ok ? pl : 0)) * ldx + q * 8;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero_piece_w);
+  auto issue = [&](int c, int slot) {
+    unsigned char* As = smem + slot * STAGE_BYTES;
+    unsigned char* Bs = As + A_BYTES;
+    const unsigned m = c == last ? ok_last_mask : ok_mask;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      ssa_glds16(((m >> i) & 1u) ? a_ptr[i] + c * CK : zero, As + (i * 8 + wave) * 1024);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int fi = f * 8 + wave;
+      const int nb = fi / CST, j = fi - nb * CST;
+      const int nbg = min(nb0 + nb, nb_total - 1);
+      const int ks = min(c * CST + j, ksteps - 1);
+      ssa_glds16(wfrag + ((long)nbg * ksteps + ks) * 64 + lane, Bs + fi * 1024);
+    }
+  };
+
+  // A fragment of this lane: pixel (wm * 4 + mi) * 32 + (lane & 31) of the tile, k half lane >> 5
+  int a_adr[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int p = (wm * 4 + mi) * 32 + (lane & 31);
+    a_adr[mi] = (p << PSH) | (swz(p, lane >> 5) << 4);                       // piece (lane >> 5) of c-step 0
+  }
+  const int b_adr = A_BYTES + (wn * 2 * CST) * 1024 + lane * 16;
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  bf16x8_t af[2][4], bfr[2][2];
+  auto rd = [&](const unsigned char* St, const int j, const int sl) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)       // piece 2 j + half: slot ^ (2 j) = address ^ (j << 5)
+      af[sl][mi] = *reinterpret_cast<const bf16x8_t*>(St + (a_adr[mi] ^ (j << 5)));
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+      bfr[sl][ni] = *reinterpret_cast<const bf16x8_t*>(St + b_adr + (ni * CST + j) * 1024);
+  };
+  auto mfmas = [&](const int sl) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = ssa_mfma32(af[sl][mi], bfr[sl][ni], acc[mi][ni]);
+  };
+
+  int slot = 0;
+  if constexpr (AHEAD) {
+#pragma unroll
+    for (int q = 0; q < D; ++q) issue(min(q, last), q);
+    ssa_wait_vm_barrier<0, 0>();
+    rd(smem, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+    for (int s = 0; s < nchunk; ++s) {
+      int sd = slot + D; if (sd >= RING) sd -= RING;
+      int sn = slot + 1; if (sn >= RING) sn -= RING;
+      issue(min(s + D, last), sd);
+      const unsigned char* Sc = smem + slot * STAGE_BYTES;
+      const unsigned char* Sn = smem + sn * STAGE_BYTES;
+#pragma unroll
+      for (int j = 0; j < CST; ++j) {
+        if (j + 1 < CST) rd(Sc, j + 1, (j + 1) & 1);
+        else rd(Sn, 0, 0);
+        mfmas(j & 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      static_assert(CST % 2 == 0, "slot 0 of the fragment ring starts every stage");
+      ssa_wait_vm_barrier<(D - 2) * (NA + NF) < 0 ? 0 : (D - 2) * (NA + NF), 6>();
+      slot = sn;
+    }
+    ssa_wait_vm_barrier<0, 0>();                // the clamped prefetches of the last stages land before LDS is reused
+  } else {
+    issue(0, 0);
+    ssa_wait_vm_barrier<0, 0>();
+    for (int s = 0; s < nchunk; ++s) {
+      if (s + 1 < nchunk) issue(s + 1, slot ^ 1);       // (every wave passed the barrier behind the reads of that buffer)
+      const unsigned char* Sc = smem + slot * STAGE_BYTES;
+      rd(Sc, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int j = 0; j < CST; ++j) {
+        if (j + 1 < CST) rd(Sc, j + 1, (j + 1) & 1);
+        mfmas(j & 1);
+        if (j + 1 < CST) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+      }
+      ssa_wait_vm_barrier<0, 0>();              // the next stage has landed; every wave is through with this one
+      slot ^= 1;
+    }
+  }
+
+  // ---- epilogue: bias, rounding to 16 bits, BatchNorm partial sums of the ROUNDED values, 16-byte row stores
+  const float* __restrict__ bias = a.bias;
+  double* __restrict__ stats = a.stats;
+  const int ldy = a.ldy, Cout = a.Cout;
+  bf16_t* Cs = reinterpret_cast<bf16_t*>(smem);
+  float* red = reinterpret_cast<float*>(smem + (size_t)BM * LDC * 2);       // [2 wm][2][256]
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = wn * 64 + ni * 32 + (lane & 31);
+    const int n = nb0 * 32 + col;
+    const float bv = (bias != nullptr && n < Cout) ? bias[n] : 0.f;
+    float sacc = 0.f, qacc = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * 4 + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const bf16_t o = f2bf(acc[mi][ni][r] + bv);
+        Cs[row * LDC + col] = o;
+        if (stats != nullptr) {
+          const float f = (p0 + row < P) ? bf2f(o) : 0.f;
+          sacc += f;
+          qacc += f * f;
+        }
+      }
+    if (stats != nullptr) {
+      sacc += __shfl_xor(sacc, 32, 64);
+      qacc += __shfl_xor(qacc, 32, 64);
+      if (lane < 32) {
+        red[(wm * 2 + 0) * 256 + col] = sacc;
+        red[(wm * 2 + 1) * 256 + col] = qacc;
+      }
+    }
+  }
+  __syncthreads();
+  if (stats != nullptr) {
+    double* st = stats + (long)(bx % kStatReplicasW) * 2 * Cout;
+    const int which = tid >> 8, col = tid & 255;
+    const int n = nb0 * 32 + col;
+    if (n < Cout) atomicAdd(&st[which * Cout + n], (double)(red[(0 * 2 + which) * 256 + col] + red[(1 * 2 + which) * 256 + col]));
+  }
+  bf16_t* yb = reinterpret_cast<bf16_t*>(a.y);
+  constexpr int CPR = NB * 4;                    // 16-byte pieces per tile row
+  for (int idx = tid; idx < BM * CPR; idx += NT) {
+    const int row = idx / CPR, cp = idx - row * CPR;
+    const int n = nb0 * 32 + cp * 8;
+    if (p0 + row >= P || n >= Cout) continue;
+    bf16_t* dst = yb + (p0 + row) * ldy + n;
+    const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (n + 8 <= Cout) {
+      *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      for (int j = 0; n + j < Cout; ++j) dst[j] = src[j];
+    }
+  }
+  }
+};
+
+bool wide_shape_ok(const ssa_conv_desc* d) {
+  if (!d || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->dil != 1 || d->transposed || d->pad != 0) return false;
+  if (d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->out_f32) return false;       // the fp32 logit convs have <= 65 output channels: not this kernel's problems
+  if (d->Cin % 16 || d->Cin < 64 || d->ldx % 8 || d->Cout % 8 || d->ldy % 8) return false;
+  return (long)d->B * d->H * d->W >= 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 = the wide kernel takes this problem AND is the better choice for it (at least two 256-channel tiles of output:
+// with one, a 256^2 + 128^2 training level is 320 workgroups = 1.25 rounds on 256 CUs; the 256 x 128 tile gives 640)
+int ssa_conv2d_gemm_wide_supported(const ssa_conv_desc* d) {
+  if (!wide_shape_ok(d)) return 0;
+  return d->Cout > 256 && (long)d->B * d->H * d->W >= 16384 ? 1 : 0;
+}
+
+int ssa_conv2d_gemm_wide(const ssa_conv_desc* dp, const void* x, const void* w_frag, const float* bias,
+                         void* y, double* stats, void* stream) {
+  if (!dp || !x || !w_frag || !y) return SSA_EINVAL;
+  if (!wide_shape_ok(dp)) return SSA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
+    return SSA_EINVAL;
+  const ssa_conv_desc& d = *dp;
+  WideArgs a;
+  a.x = (const bf16_t*)x; a.wfrag = (const uint4*)w_frag; a.bias = bias; a.y = y; a.stats = stats;
+  a.P = (long)d.B * d.H * d.W;
+  a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.out_f32 = 0; a.Cout = d.Cout;
+  a.nb_total = (d.Cout + 31) / 32;
+  a.ptiles = (int)((a.P + 255) / 256);
+  // Cin a multiple of 64: whole 128-byte lines per stage, double buffer.  Otherwise (aux_head's 720 channels: 11.25
+  // stages of 64 would spend 6 % of the MFMAs on zeros) the 32-channel ring (measured 116.6 against 124.0 us at 256^2)
+  if (d.Cin % SSA_WIDE_CK == 0) {
+    typedef ConvGemmWide1<SSA_WIDE_CK, SSA_WIDE_RING> K;
+    return ssa::submit<K>(a, a.ptiles, (a.nb_total + K::NB - 1) / K::NB, K::LDS_BYTES, (hipStream_t)stream);
+  }
+  typedef ConvGemmWide1<32, 4> K;
+  return ssa::submit<K>(a, a.ptiles, (a.nb_total + K::NB - 1) / K::NB, K::LDS_BYTES, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -31,6 +31,7 @@
 #include "common.h"
 #include "group.h"
 #include "../../include/semseg_hip.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -505,6 +506,9 @@ int ssa_conv2d_halo(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   if (stats && dp->out_f32) return SSA_EINVAL;
   const ssa_conv_desc& d = *dp;
   hipStream_t s = (hipStream_t)stream;
+  // the large 1x1 problems go to the 256 x 256 tile (conv_gemm_wide.hip); SSA_GEMM_WIDE=0: all stay here
+  static const bool wide_on = !(getenv("SSA_GEMM_WIDE") && atoi(getenv("SSA_GEMM_WIDE")) == 0);
+  if (wide_on && d.KH == 1 && ssa_conv2d_gemm_wide_supported(dp)) return ssa_conv2d_gemm_wide(dp, x, w_frag, bias, y, stats, stream);
   const int ck = pick_ck(d.Cin);
   if (d.KH == 3) {
     if (ck == 64) return launch_halo3<64, 4>(d, x, w_frag, bias, y, stats, s);

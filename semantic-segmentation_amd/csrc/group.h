@@ -63,14 +63,27 @@ __global__ __launch_bounds__(K::NT, WavesPerEu<K>::value) void k_single(const ty
   K::run(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
+// A workgroup finds its problem in TWO scalar-memory round trips: the prefix sums sit at constant kernel-argument
+// offsets, so the unrolled count below compiles to a few wide s_load's issued together and two scalar instructions per
+// entry (the host fills the entries from the last problem's on with INT_MAX: no test against n); the second round trip
+// fetches end[j - 1], gx[j] and the problem's arguments together.  The rolled loop it replaces was
+// s_load end[j] -> s_waitcnt -> compare  per problem, then dependent loads of end[j - 1], gx[j] and the arguments:
+// 4 + j round trips before a workgroup issued its first data load -- on the critical path of every workgroup of the
+// one-chunk-per-workgroup kernels (BatchNorm, sums, resampling), where the LAST problems of the table end the launch
+// (round 6: a 2-workgroup BatchNorm launch took 7 us).
 template <class K>
 __global__ __launch_bounds__(K::NT, WavesPerEu<K>::value) void k_grouped(const GroupTable<K> t) {
+  constexpr int J = GroupLimits<K>::jobs;
+  const int bx = (int)blockIdx.x;
   int j = 0;
-#pragma unroll 1
-  while (j + 1 < t.n && (int)blockIdx.x >= t.end[j]) ++j;
-  const int v = (int)blockIdx.x - (j ? t.end[j - 1] : 0);
+#pragma unroll
+  for (int i = 0; i + 1 < J; ++i) j += bx >= t.end[i] ? 1 : 0;
+  const int prev = t.end[j > 0 ? j - 1 : 0];
   const int gx = t.gx[j];
-  K::run(t.a[j], v % gx, v / gx, gx);
+  const int v = bx - (j > 0 ? prev : 0);
+  int vx = v, vy = 0;
+  if (v >= gx) { vy = v / gx; vx = v - vy * gx; }   // grid.y == 1 (or the first row): no integer division
+  K::run(t.a[j], vx, vy, gx);
 }
 
 struct Bucket {
@@ -152,6 +165,9 @@ int flush_bucket(Bucket& b, hipStream_t s) {
         t.gx[i] = b.gx[j0 + i];
         memcpy(&t.a[i], b.args.data() + (size_t)(j0 + i) * sizeof(Args), sizeof(Args));
       }
+      // the kernel's search counts the entries <= blockIdx.x without looking at n: no entry from the last problem's on
+      // may compare true (blockIdx.x < total always holds; end[j - 1] is only read for j <= cnt - 1)
+      for (int i = cnt - 1; i < J; ++i) t.end[i] = 0x7fffffff;
       if (int e = ensure_lds<K>((const void*)k_grouped<K>, b.lds, &lds_grouped)) return e;
       void* ph = profiling() ? profile_open(kernel_name<K>(), s) : nullptr;
       hipLaunchKernelGGL(k_grouped<K>, dim3(total), dim3(K::NT), b.lds, s, t);

@@ -14,3 +14,10 @@ def graph_training(net, optim, warmup=2):
 def GraphedTrainStep(net, optim, warmup=2):
     from .graphed import GraphedTrainStep as _G
     return _G(net, optim, warmup)
+
+
+def graph_eval(net, max_graphs=4, clone_outputs=True):
+    """Proxy of `net` whose evaluation-mode calls under torch.no_grad() replay one captured forward per input signature
+    (semseg_amd/graphed.py GraphedEval): what the reference's validate() loop calls once per image."""
+    from .graphed import graph_eval as _g
+    return _g(net, max_graphs, clone_outputs)

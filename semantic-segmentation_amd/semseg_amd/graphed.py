@@ -16,8 +16,13 @@ reference's loop holds so that the UNMODIFIED loop runs the captured step:
                                  # optimizer's device scalar (FusedSGD.sync_lr)
 
 Everything the step needs is capture safe by construction (no host synchronisation, torch's caching allocator,
-kernels on the current stream; at N > 1 the SyncBN and gradient exchanges are direct RCCL nodes).  Evaluation
-(`net.eval()` / `torch.no_grad()`) goes straight to the module.
+kernels on the current stream; at N > 1 the SyncBN and gradient exchanges are direct RCCL nodes).
+
+Evaluation (`net.eval()` under `torch.no_grad()`: what utils/trnval_utils.py:134-141 calls once per image, flip and scale)
+is the same host-bound story -- ~830 ctypes launches per pass -- and goes through `GraphedEval`: one captured forward per
+input signature, the least recently used signature evicted beyond `max_graphs` (validation images of a dataset like
+Mapillary come in many sizes; a captured forward owns its activation pool).  `graph_eval(net)` gives an evaluation-only
+run the same proxy; `graph_training` includes it.  SSA_GRAPHED_EVAL=0: evaluation goes straight to the module.
 
 Guards: at most `max_graphs` input signatures are captured (a run with ragged shapes would otherwise multiply the
 activation pools); further signatures, and every step after a capture that raised (logged once), run the SAME
@@ -25,6 +30,8 @@ sequence eagerly.  With N > 1 every rank must see the same shapes in the same it
 capture issue collectives).  Reloading the optimizer's state (`optim.load_state_dict`) drops the captured graphs:
 they hold the addresses of the old momentum buffers.
 """
+import collections
+import os
 import sys
 
 import torch
@@ -142,6 +149,92 @@ class GraphedTrainStep:
         return loss_out.clone()
 
 
+def _map_tensors(obj, fn):
+    """fn over every tensor of a (possibly nested) dict / list / tuple / tensor result; everything else as it is."""
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return type(obj)((k, _map_tensors(v, fn)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
+class GraphedEval:
+    """Captured `with torch.no_grad(): net(inputs)` of an evaluation-mode network, one hipGraph per input signature.
+
+    The reference's validation loop (utils/trnval_utils.py:115-160) calls `net(inputs)` once per image, flip and scale
+    and reads `output_dict['pred']` (plus the `pred_*` / `attn_*` assets of the last call).  A call here copies the batch
+    into the signature's static inputs, re-packs the filters of parameters that changed since the last call (training
+    between two validations; one batched launch, outside the graph), replays, and returns CLONES of the static outputs
+    (`clone_outputs=False` hands out the static buffers themselves: valid until the next call with that signature).
+    At most `max_graphs` signatures stay captured, least recently used evicted first."""
+
+    def __init__(self, net, warmup=1, max_graphs=4, clone_outputs=True):
+        self.net, self.warmup, self.max_graphs, self.clone_outputs = net, warmup, max(1, int(max_graphs)), clone_outputs
+        self._graphs = collections.OrderedDict()       # signature -> (graph, static inputs, static outputs)
+        self.eager_only = False
+        self.replays = self.captures = self.evictions = 0
+
+    def invalidate(self):
+        self._graphs.clear()
+
+    @staticmethod
+    def _signature(inputs):
+        return tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(inputs.items()) if torch.is_tensor(v))
+
+    def _forward(self, inputs):
+        with torch.no_grad():
+            return self.net(inputs)
+
+    def _capture(self, inputs):
+        static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):            # allocator, packed-filter cache (the capture must not pack)
+                self._forward(static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._forward(static)
+        return graph, static, out
+
+    def __call__(self, inputs):
+        from . import hip_backend
+        sig = self._signature(inputs)
+        ent = self._graphs.get(sig)
+        if ent is None:
+            if self.eager_only:
+                return self._forward(inputs)
+            while len(self._graphs) >= self.max_graphs:      # free the evicted forward's pool BEFORE capturing the next
+                self._graphs.popitem(last=False)
+                self.evictions += 1
+            try:
+                ent = self._capture(inputs)
+            except Exception as e:          # noqa: BLE001 -- whatever refused the capture: evaluation runs eagerly
+                self.eager_only = True
+                print("semseg_amd.graphed: hipGraph capture of the evaluation forward failed (%s: %s); evaluation goes "
+                      "on with eager launches" % (type(e).__name__, str(e)[:300]), file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                return self._forward(inputs)
+            self._graphs[sig] = ent
+            self.captures += 1
+        else:
+            self._graphs.move_to_end(sig)
+            graph, static, _ = ent
+            for k, v in inputs.items():
+                if torch.is_tensor(v):
+                    static[k].copy_(v, non_blocking=True)
+            # parameters trained since this forward was captured: their packed 16-bit forms are what the graph reads
+            hip_backend.refresh_packed_filters()
+        graph, static, out = ent
+        graph.replay()
+        self.replays += 1
+        return _map_tensors(out, lambda t: t.clone()) if self.clone_outputs else _map_tensors(out, lambda t: t)
+
+
 class _GraphedNet(nn.Module):
     """What the reference's loop calls as `net(inputs)`: in training mode the whole captured step.
 
@@ -151,10 +244,11 @@ class _GraphedNet(nn.Module):
     (`DistributedDataParallel(_GraphedNet(net)).state_dict()` has `module.X` keys and loads them back, which is what
     the reference's `restore_net` -> `forgiving_state_restore`, train.py:396, does with --snapshot / --resume)."""
 
-    def __init__(self, net, stepper):
+    def __init__(self, net, stepper, eval_stepper=None):
         super().__init__()
         object.__setattr__(self, "_net", net)          # not a registered submodule
-        object.__setattr__(self, "_stepper", stepper)
+        object.__setattr__(self, "_stepper", stepper)  # GraphedTrainStep, or None (graph_eval: training runs eagerly)
+        object.__setattr__(self, "_eval_stepper", eval_stepper)
         self._modules = net._modules
         self._parameters = net._parameters
         self._buffers = net._buffers
@@ -171,9 +265,13 @@ class _GraphedNet(nn.Module):
         return self._net
 
     def forward(self, inputs):
-        if self._net.training and torch.is_grad_enabled():
+        if self._net.training and torch.is_grad_enabled() and self._stepper is not None:
             loss = self._stepper(inputs)
             return loss.requires_grad_(True)   # a leaf: the loop's own .backward() has nothing to do
+        ev = self._eval_stepper
+        if ev is not None and not self._net.training and not torch.is_grad_enabled() and isinstance(inputs, dict) and \
+                any(torch.is_tensor(v) and v.is_cuda for v in inputs.values()):
+            return ev(inputs)                  # validation: one replayed forward per image (GraphedEval)
         return self._net(inputs)
 
     def train(self, mode=True):
@@ -223,8 +321,21 @@ class _GraphedOptim:
         setattr(self.__dict__["_optim"], name, value)
 
 
-def graph_training(net, optim, warmup=2, max_graphs=4):
+def _eval_stepper(net, max_eval_graphs, clone_outputs=True):
+    if os.environ.get("SSA_GRAPHED_EVAL", "1") == "0" or max_eval_graphs <= 0:
+        return None
+    return GraphedEval(net, max_graphs=max_eval_graphs, clone_outputs=clone_outputs)
+
+
+def graph_training(net, optim, warmup=2, max_graphs=4, max_eval_graphs=4):
     """(net, optim) -> proxies under which the reference's unmodified train() loop runs one hipGraph replay per
-    iteration (see the module docstring)."""
+    iteration and its validate() loop one replayed forward per image (see the module docstring)."""
     stepper = GraphedTrainStep(net, optim, warmup, max_graphs)
-    return _GraphedNet(net, stepper), _GraphedOptim(optim, stepper)
+    return _GraphedNet(net, stepper, _eval_stepper(net, max_eval_graphs)), _GraphedOptim(optim, stepper)
+
+
+def graph_eval(net, max_graphs=4, clone_outputs=True):
+    """net -> proxy whose evaluation-mode calls under torch.no_grad() replay a captured forward per input signature
+    (GraphedEval); training-mode calls go to the module unchanged.  For evaluation-only runs (train.py --eval val/folder,
+    utils/trnval_utils.py:134-141): `net = semseg_amd.graph_eval(net)`."""
+    return _GraphedNet(net, None, _eval_stepper(net, max_graphs, clone_outputs))

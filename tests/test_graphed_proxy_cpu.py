@@ -64,3 +64,54 @@ def test_optimizer_reload_invalidates_the_graphs_and_the_cap_holds():
     assert goptim.param_groups is optim.param_groups
     goptim.zero_grad()
     goptim.step()
+
+
+def test_evaluation_proxy_routes_and_evicts_least_recently_used(monkeypatch):
+    """graph_eval / the evaluation half of graph_training without a GPU: CPU inputs and grad-enabled calls go straight to
+    the module; the signature cache is LRU (capture stubbed: the bookkeeping around it is what runs here); a capture
+    that raises switches evaluation to eager launches for good; SSA_GRAPHED_EVAL=0 installs no evaluation stepper."""
+    net = _net().eval()
+    g = graphed.graph_eval(net, max_graphs=2)
+    ev = g._eval_stepper
+    assert isinstance(ev, graphed.GraphedEval) and g._stepper is None
+    x = torch.randn(1, 3, 8, 8)
+    with torch.no_grad():
+        assert torch.equal(g(x), net(x))                      # not a dict of device tensors: the module itself
+    assert ev.captures == 0
+    # the stepper's cache, with the capture and the replay stubbed
+    class _G:
+        def __init__(self):
+            self.n = 0
+
+        def replay(self):
+            self.n += 1
+    made = []
+
+    def fake_capture(inputs):
+        gr = _G()
+        made.append(gr)
+        return gr, {k: v.clone() for k, v in inputs.items()}, {"pred": torch.zeros(1)}
+    ev._capture = fake_capture
+    from semseg_amd import hip_backend
+    monkeypatch.setattr(hip_backend, "refresh_packed_filters", lambda: None)
+    a, b, c = ({"images": torch.zeros(1, 3, s, s)} for s in (8, 9, 10))
+    for inp in (a, b, a, c, b):
+        out = ev(inp)
+        assert set(out) == {"pred"}
+    # a, b captured; a replayed (now most recent); c evicts b; b comes back and evicts a
+    assert (ev.captures, ev.evictions, ev.replays) == (4, 2, 5)
+    assert [k[0][1] for k in ev._graphs] == [(1, 3, 10, 10), (1, 3, 9, 9)]
+    # a capture that raises: eager from then on
+    ev2 = graphed.GraphedEval(net, max_graphs=1)
+    ev2._capture = lambda inputs: (_ for _ in ()).throw(RuntimeError("no device"))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    net_calls = []
+    ev2._forward = lambda inputs: net_calls.append(1) or {"pred": torch.ones(1)}
+    ev2({"images": torch.zeros(1, 3, 8, 8)})
+    ev2({"images": torch.zeros(1, 3, 8, 8)})
+    assert ev2.eager_only and net_calls == [1, 1] and ev2.captures == 0
+    # the switch
+    monkeypatch.setenv("SSA_GRAPHED_EVAL", "0")
+    assert graphed.graph_eval(net)._eval_stepper is None
+    optim = torch.optim.SGD(net.parameters(), lr=0.1)
+    assert graphed.graph_training(net, optim)[0]._eval_stepper is None

@@ -192,6 +192,55 @@ def test_conv_fwd_bwd(case):
         check_close("conv_bgrad %s" % (case,), bd.grad, br.grad, 1e-2, 4e-3)
 
 
+WIDE_CASES = [
+    # B, H, W, Cin, Cout, bias, stats, transposed-pack (the data-gradient form: ssa_pack_filter mode 3)
+    (1, 16, 32, 96, 264, False, True, False),      # two pixel tiles x two channel tiles, the second 8 channels wide
+    (1, 9, 31, 80, 520, True, True, False),        # ragged pixel tile (279 pixels), Cin = 2.5 stages, three channel tiles
+    (2, 16, 16, 64, 256, True, False, False),      # one channel tile, exactly two stages (the ring's clamped prefetches)
+    (1, 20, 16, 272, 328, False, True, True),      # data-gradient packing, 8.5 stages (ring wraps twice), n-block tail
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_gemm_wide_1x1(case):
+    """csrc/conv_gemm_wide.hip through its own entry point (ssa_conv2d_halo forwards only the large head problems to
+    it): every tile / stage / ring edge at sizes the CPU emulation runs in seconds -- ragged pixel tile, Cin that is no
+    multiple of the 32-channel stage, channel-tile and n-block tails, bias, the BatchNorm partial sums of the ROUNDED
+    outputs, both filter packings."""
+    import ctypes
+    from oracle import ops as O
+    from semseg_amd._lib import check
+    hb = _hb()
+    B, H, W, Cin, Cout, bias, stats, tr = case
+    x = _rand(B, Cin, H, W, seed=3)
+    w = _rand(Cout, Cin, 1, 1, seed=4, scale=1.0 / math.sqrt(Cin))
+    b = _rand(Cout, seed=5) if bias else None
+    ref = O.conv2d(x, w, b, 1, 0, 1)
+    xd = _to_dev_nhwc(x)
+    hb.clear_pack_cache()
+    if tr:      # the weight of the conv whose DATA gradient this is: [Cin_fwd = Cout here][Cout_fwd = Cin here]
+        wt = w[:, :, 0, 0].t().contiguous().view(Cin, Cout, 1, 1).to(xd.device)
+        wp, _ = hb._packed_filter(wt, 3, 0, Cin)
+    else:
+        wp, _ = hb._packed_filter(w.to(xd.device), 2, Cin, 0)
+    d = hb._tile_desc(B, H, W, Cin, Cin, Cout, (1, 1), 1, 0, 1, H, W, False)
+    L = hb.lib()
+    assert L.ssa_conv2d_gemm_wide_supported(ctypes.byref(d)) == 0      # (too small for the dispatcher: direct call)
+    y = torch.empty(B, H, W, Cout, dtype=ACT_DTYPE, device=xd.device)
+    nrep = hb.stat_replicas()
+    st = torch.zeros(nrep, 2, Cout, dtype=torch.float64, device=xd.device) if stats else None
+    bd = b.to(xd.device) if b is not None else None
+    check(L.ssa_conv2d_gemm_wide(ctypes.byref(d), hb._p(xd), hb._p(wp), hb._p(bd), hb._p(y), hb._p(st), hb._s()), "wide")
+    if xd.is_cuda:
+        torch.cuda.synchronize()
+    check_close("gemm_wide %s" % (case,), nchw(y.float()), ref)
+    if stats:
+        yr = y.float().view(-1, Cout).double()
+        got = st.sum(0).cpu()
+        check_close("gemm_wide sums %s" % (case,), got[0], yr.sum(0).cpu(), 1e-4, 1e-4)
+        check_close("gemm_wide squares %s" % (case,), got[1], (yr * yr).sum(0).cpu(), 1e-4, 1e-4)
+
+
 def test_stride2_dgrad_by_parity_matches_zero_inserted():
     """ssa_conv2d_dgrad_s2 (four dense parity classes) against the zero-inserted transposed form it
     replaces: same operands, same bf16 rounding of the result; the two differ only in the order of the

@@ -47,6 +47,11 @@ class Prob:
                                       P(self.stats), self.nrep, float(self.P), P(self.gamma), P(self.beta), None, None, None,
                                       0.1, 1e-5, P(self.coef), None, 1, None, self.P, P(self.mask) if (res and self.use_mask) else None, hb._s()), "apply")
 
+    def apply_eval(self, res):
+        """the evaluation form: scale / shift given (no statistics prologue, no LDS, no barrier)"""
+        hb.check(L.ssa_bn_apply(P(self.x), self.C, P(self.res) if res else None, self.C, P(self.z), self.C, self.P, self.C,
+                                P(self.coef[0]), P(self.coef[1]), 1, None, self.P, hb._s()), "apply_eval")
+
     def reduce(self, from_x):
         msc, msh = (self.coef[0], self.coef[1]) if from_x else (None, None)
         hb.check(L.ssa_bn_bwd_reduce(P(self.x), self.C, P(self.dz), self.C, None if from_x else P(self.z), self.C, self.P, self.C,
@@ -98,6 +103,8 @@ def main():
     rows = {k: os.environ.get(k, "-") for k in ("SSA_BN_ROWS_APPLY", "SSA_BN_ROWS_BWD", "SSA_BN_ROWS_REDUCE")}
     print("level of 8 problems, %.2f M elements; rows %s" % (elems / 1e6, rows))
     for name, fn, bpe in (("apply (bn1: no residual)", lambda p: p.apply(False), 4), ("apply (bn2: + residual)", lambda p: p.apply(True), 6),
+                          ("apply, coefficients given (bn1)", lambda p: p.apply_eval(False), 4),
+                          ("apply, coefficients given (bn2)", lambda p: p.apply_eval(True), 6),
                           ("bwd reduce (mask from z)", lambda p: p.reduce(False), 6), ("bwd reduce (mask from x)", lambda p: p.reduce(True), 4),
                           ("bwd apply (bn2: z mask, dres)", lambda p: p.bapply(False, True), 10),
                           ("bwd apply (bn1: x mask)", lambda p: p.bapply(True, False), 6)):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Secondary measurement (not the headline metric): inference throughput of the three eval
-configurations of BASELINE.json on one MI355X, synthetic input, random weights, hipGraph replay:
+configurations of BASELINE.json on one MI355X, synthetic input, random weights -- through `semseg_amd.graph_eval` (the
+captured forward a drop-in user's validate() loop replays per image) with the eager call of the bare module beside it:
   configs[1]  HRNet-OCR single scale, 1024x2048                     (ocrnet.HRNet)
   configs[2]  HRNet-OCR-MScale hierarchical attention {0.5,1.0,2.0}  (ocrnet.HRNet_Mscale, N_SCALES)
   configs[4]  Mapillary: 65 classes, {0.5,1.0,2.0} on a 1536x2048 image (the 2.0x pass is 3072x4096), one GPU --
@@ -17,9 +18,12 @@ import torch  # noqa: E402
 
 
 def run(name, arch, n_scales, H, W, iters, classes=19, use_graph=True):
+    """One row: the forward the reference's validate() loop calls (`net(inputs)` under no_grad) through
+    `semseg_amd.graph_eval` -- what a drop-in user gets -- and the same call on the bare module (eager launches)."""
     from semseg_amd.config import cfg
     from semseg_amd.loss import CrossEntropyLoss2d
     from semseg_amd.network import get_model
+    from semseg_amd.graphed import graph_eval
     cfg.MODEL.N_SCALES = n_scales
     cfg.MODEL.BNFUNC = None
     torch.manual_seed(0)
@@ -27,48 +31,32 @@ def run(name, arch, n_scales, H, W, iters, classes=19, use_graph=True):
     net = get_model(arch, classes, CrossEntropyLoss2d(ignore_index=255)).cuda().eval()
     images = torch.randn(1, 3, H, W, device="cuda")
     inputs = {"images": images}
+    gnet = graph_eval(net, max_graphs=2, clone_outputs=True)
     out_buf = {}
 
-    def step():
+    def timed(model, n):
         with torch.no_grad():
-            o = net(inputs)
-        out_buf["pred"] = o["pred"]
+            for _ in range(2):
+                out_buf["pred"] = model(inputs)["pred"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out_buf["pred"] = model(inputs)["pred"]
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    graph = None
-    try:
-        if not use_graph:
-            raise RuntimeError("eager requested")
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            step()
-        torch.cuda.synchronize()
-    except Exception as e:
-        print("graph capture failed, eager:", repr(e)[:120], file=sys.stderr)
-        graph = None
-    f = graph.replay if graph is not None else step
-    for _ in range(2):
-        f()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        f()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    eager = timed(net, max(2, iters // 3))
+    dt = timed(gnet if use_graph else net, iters)
+    ev = gnet._eval_stepper
     pred = out_buf["pred"]
     from semseg_amd import _lib
     res = {"config": name, "arch": arch, "storage": _lib.ACT, "scales": n_scales or [1.0], "input": [H, W], "classes": classes,
-           "ms_per_image": dt * 1e3,
-           "images_per_s": 1.0 / dt, "hipgraph": graph is not None, "pred_shape": list(pred.shape),
+           "ms_per_image": dt * 1e3, "eager_ms_per_image": eager * 1e3,
+           "images_per_s": 1.0 / dt, "hipgraph": bool(use_graph and ev is not None and not ev.eager_only and ev.replays > 0),
+           "api": "semseg_amd.graph_eval (clone_outputs=True)", "pred_shape": list(pred.shape),
            "finite": bool(torch.isfinite(pred).all()), "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     print(json.dumps(res))
-    del net, graph
+    del net, gnet
     torch.cuda.empty_cache()
 
 

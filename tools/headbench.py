@@ -53,11 +53,17 @@ class WProb:
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
     shapes = [(720, 512, 256, 256, 3), (720, 512, 128, 128, 3), (512, 256, 128, 128, 3), (256, 256, 128, 128, 3),
-              (720, 720, 256, 256, 1), (512, 256, 256, 256, 1), (1024, 512, 256, 256, 1), (512, 512, 256, 256, 1)]
+              (720, 720, 256, 256, 1), (512, 256, 256, 256, 1), (1024, 512, 256, 256, 1), (512, 512, 256, 256, 1),
+              (512, 1024, 256, 256, 1), (256, 512, 256, 256, 1), (720, 720, 128, 128, 1), (1024, 512, 128, 128, 1)]
+    if "--only-1x1" in sys.argv:
+        shapes = [s for s in shapes if s[4] == 1]
     probs = [WProb(*s) for s in shapes]
     for p in probs:
-        t = timeit(p.wgrad, reps)
-        line = "%s  wgrad %8.1f us %6.0f TF/s (splits %3d)" % (p.name, t, p.flops / t / 1e6, p.ns)
+        if "--fwd-only" in sys.argv:
+            line = p.name
+        else:
+            t = timeit(p.wgrad, reps)
+            line = "%s  wgrad %8.1f us %6.0f TF/s (splits %3d)" % (p.name, t, p.flops / t / 1e6, p.ns)
         if p.halo:
             try:
                 t = timeit(p.fwd, reps)
@@ -65,6 +71,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line += "   fwd failed: %s" % e
         print(line, flush=True)
+
+    if "--fwd-only" in sys.argv:
+        return
 
     def all3():
         with hb.group():
