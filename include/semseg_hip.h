@@ -258,6 +258,11 @@ int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit
 int ssa_conv2d_wgrad_tile(const ssa_conv_desc* d, const void* x, const void* dy,
                           int lddy, int cout_pad, int nsplit, float* partial,
                           void* stream);
+/* Launch geometry of ssa_conv2d_wgrad_tile for a Cin = cout_pad layer, for the host's strip fitting
+ * (hip_backend._fit_tile_strips): parts = workgroups per strip of 128-pixel tiles, slots = workgroups of that
+ * instantiation resident on the chip at once, kind = which instantiation (launches of one kind share a grouped launch:
+ * 0 = the 8-wave all-taps form of the 96-channel blocks, csrc/conv_wgrad_tile.hip ConvWgradTileA). */
+int ssa_conv2d_wgrad_tile_geometry(int Cin, int cout_pad, int* parts, int* slots, int* kind);
 /* Weight gradient of the large-channel 3x3 / 1x1 stride-1 head convs (Cin >= 128,
  * >= 16 K pixels): 8-wave workgroups persistent over 128-pixel tiles hold a
  * 128(co) x 128(ci) x 3(kw) [3x3] or 128 x 256 [1x1] block of dW in MFMA

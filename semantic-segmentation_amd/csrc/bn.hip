@@ -366,7 +366,12 @@ __device__ __forceinline__ void load_sign_bytes(const RowSet<ROWS>& rs, const un
   for (int u = 0; u < ROWS; ++u) mk[u] = base[(long)rs.off[u] * VC];
 }
 
-template <int ROWS>
+// MODE as in bn_bwd_apply_body below (0: sign bytes / no ReLU, 1: mask recomputed from x, 2: mask read off z).  The loop
+// accumulates sum g and sum g x per thread and centres ONCE at the end -- sum g xhat = invstd (sum g x - mean sum g), per
+// thread, over its <= ROWS x chunks pixels, before the block reduction -- so mean / invstd are not live in it: with the
+// mask source compile-time and the rows kept apart the 8-row form fits 128 registers (it ran at 246 = two workgroups per
+// CU: a head-sized launch of 1,280-3,072 workgroups took three to six rounds).
+template <int ROWS, int MODE>
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
     const bf16_t* __restrict__ z, int ldz, long P, int C, const float* __restrict__ mean,
@@ -374,35 +379,30 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
     double* __restrict__ sums, int nrep, long pix_per_block, const float* __restrict__ mscale,
     const float* __restrict__ mshift, const unsigned char* __restrict__ mask, const int bx) {
   SSA_DYN_LDS(float, sh);
+  constexpr bool ZMASK = MODE == 2;
   const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
   const int t = threadIdx.x;
   const bool active = t < NA;
   const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
-  const bool use_bits = relu && !mscale && mask != nullptr;
-  const bool use_z = relu && !mscale && !use_bits;
-  float sg[8], sgx[8], mu[8], is[8], ma[8], mb[8];
+  const bool use_bits = MODE == 0 && relu && mask != nullptr;
+  const bool from_x = MODE == 1 && relu;
+  float sg[8], sgx[8], ma[8], mb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; ma[j] = 0.f; mb[j] = 0.f; }
   const long pb = bx * pix_per_block;
   const long pe = min(P, pb + pix_per_block);
-  bool have_coef = false;
   for (long p0 = pb; p0 < pe; p0 += (long)RP * ROWS) {
     RowSet<ROWS> rs;
     rs.init(p0, pe, pr, RP, active);
-    uint4 gv[ROWS], xr[ROWS], zr[ROWS];
-    unsigned mk[ROWS];
+    uint4 gv[ROWS], xr[ROWS], zr[ZMASK ? ROWS : 1];
+    unsigned mk[MODE == 0 ? ROWS : 1];
     rs.load(dz + p0 * lddz + cg * 8, lddz, gv);
     rs.load(x + p0 * ldx + cg * 8, ldx, xr);
-    if (use_z) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
-    if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk);
-    if (!have_coef) {
+    if constexpr (ZMASK) rs.load(z + p0 * ldz + cg * 8, ldz, zr);
+    if constexpr (MODE == 0) { if (use_bits) load_sign_bytes<ROWS>(rs, mask + p0 * VC + cg, VC, mk); }
+    if constexpr (MODE == 1) {      // (behind the data loads; L1 hits from the second chunk on)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
-      if (mscale) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
-      }
-      have_coef = true;
+      for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
     }
 #pragma unroll
     for (int u = 0; u < ROWS; ++u) {
@@ -410,16 +410,22 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
       unpack8(gv[u], g);
       unpack8(xr[u], xv);
       const float* pp = post ? post + (unsigned)((unsigned)(p0 + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
-      bn_bwd_mask(g, xv, zr[u], use_z, relu, mscale != nullptr, ma, mb, pp, use_bits, use_bits ? mk[u] : 0u);
-      const float keep = ((rs.ok >> u) & 1u) ? 1.f : 0.f;      // masked rows re-read the chunk's first pixel
+      bn_bwd_mask(g, xv, zr[ZMASK ? u : 0], ZMASK && relu, relu, from_x, ma, mb, pp, use_bits,
+                  (MODE == 0 && use_bits) ? mk[MODE == 0 ? u : 0] : 0u);
+      const bool keep = (rs.ok >> u) & 1u;                      // masked rows re-read the chunk's first pixel
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gk = g[j] * keep;
+        const float gk = keep ? g[j] : 0.f;
         sg[j] += gk;
-        sgx[j] += gk * (xv[j] - mu[j]) * is[j];
+        sgx[j] += gk * xv[j];
       }
+#ifndef SSA_EMU
+      __builtin_amdgcn_sched_barrier(0);        // one row at a time (register pressure: see bn_apply_rows)
+#endif
     }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sgx[j] = (sgx[j] - mean[cg * 8 + j] * sg[j]) * invstd[cg * 8 + j];
   block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, bx, nrep);
 }
 
@@ -578,17 +584,22 @@ struct BnApplyTrainK {
                               a.pass_stats, a.relu, a.post, a.pix_per_img, a.ppb, a.mask, bx);
   }
 };
-template <int ROWS>
-struct BnBwdReduceK {
+template <int ROWS, int MODE>
+struct BnBwdReduceKM {
+  static constexpr int WPE = ROWS <= 4 ? 4 : 2;      // 4 rows: <= 128 registers (see bn_bwd_reduce_body)
   struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
                 const float* post; double* sums; const float* mscale; const float* mshift; const unsigned char* mask;
                 long P, pix_per_img, ppb; int ldx, lddz, ldz, C, relu, nrep; };
   static constexpr int NT = ::NT;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int) {
-    bn_bwd_reduce_body<ROWS>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
+    bn_bwd_reduce_body<ROWS, MODE>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.P, a.C, a.mean, a.invstd, a.relu, a.post,
                              a.pix_per_img, a.sums, a.nrep, a.ppb, a.mscale, a.mshift, a.mask, bx);
   }
 };
+template <int ROWS> struct BnBwdReduceK : BnBwdReduceKM<ROWS, 0> {};
+template <int ROWS> struct BnBwdReduceXK : BnBwdReduceKM<ROWS, 1> {};
+template <int ROWS> struct BnBwdReduceZK : BnBwdReduceKM<ROWS, 2> {};
+
 template <int ROWS, int MODE>
 struct BnBwdApplyKM {
   static constexpr int WPE = ROWS <= 4 ? 4 : 2;  // <= 128 registers: four workgroups per CU (see bn_bwd_apply_body)
@@ -766,10 +777,14 @@ int ssa_bn_bwd_reduce(const void* x, int ldx, const void* dz, int lddz, const vo
     if (e != hipSuccess) return (int)e;
   }
   const Grid g = plan_reduce_grid(P, C);
-  return SSA_BN_SUBMIT(BnBwdReduceK, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums,
-                                          mask_scale, mask_shift, (const unsigned char*)sign_mask, P, pix_per_img, g.ppb, ldx,
-                                          lddz, ldz, C, relu, nrep}),
-                       16 * (NT + 1) * sizeof(float), s);
+#define SSA_BN_BWD_REDUCE(K)                                                                                                  \
+  SSA_BN_SUBMIT(K, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, post, sums, mask_scale, mask_shift, \
+                        (const unsigned char*)sign_mask, P, pix_per_img, g.ppb, ldx, lddz, ldz, C, relu, nrep}),               \
+                16 * (NT + 1) * sizeof(float), s)
+  if (relu && mask_scale) return SSA_BN_BWD_REDUCE(BnBwdReduceXK);
+  if (relu && !sign_mask) return SSA_BN_BWD_REDUCE(BnBwdReduceZK);
+  return SSA_BN_BWD_REDUCE(BnBwdReduceK);
+#undef SSA_BN_BWD_REDUCE
 }
 
 int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,

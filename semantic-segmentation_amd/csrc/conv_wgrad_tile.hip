@@ -49,6 +49,8 @@ __device__ __forceinline__ bf16x8_t tr_read8(const unsigned char* p, int stride_
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+__device__ uint4 g_zero_piece_t;    // 16 zero bytes: what a piece outside the image loads (ConvWgradTileA's DMAs)
+
 struct WgradTileArgs {
   const bf16_t* x; const bf16_t* dy; float* partial;
   int ldx, Cin, lddy, cout_pad, B, H, W, tiles_x, tiles_y, tiles_per_wg, n_parts;
@@ -271,6 +273,187 @@ struct ConvWgradTile {
   }
 };
 
+// ---- All nine taps per staged tile, LDS-DMA double buffer (round 6) ----------------------------------------------------
+// ConvWgradTile above holds 9 accumulator tiles per wave AND the next tile's x / dy pieces in registers (it stages
+// through them) AND their addresses: 467 registers per lane, i.e. ONE 4-wave workgroup per CU (the host sized its
+// launches for two), whose single wave per SIMD alternates between staging, two barriers and 48-72 MFMAs per tile --
+// MFMA pipe busy 0.12 (profiles/r05_pmc.txt); and a 96-channel block's tile is staged three times, once per kernel row.
+// Here, for the 96-channel blocks (Cin = Cout = 96 / 192 / 384: three quarters of the trunk's weight-gradient FLOPs),
+//   * a workgroup (4 waves, one per SIMD) owns HALF of the 27 (tap, 32-channel) n-blocks -- 14 or 13 -- x 3 m-blocks of
+//     its (96 co x 96 ci) block: wave w holds n-blocks w, w + 4, w + 8, w + 12 of its half x 3 m-blocks = 12
+//     accumulator tiles, 192 registers -- the matrix instructions of one function accumulate EITHER in the accumulator
+//     half of the register file OR in the vector half (256 registers = 16 tiles each), so 21 tiles per wave, a whole
+//     block on four waves, spill (tried: 817 spilled registers).  The staged tile feeds 336 MFMAs instead of 216 -- 96 per
+//     wave between barriers instead of 48-72 -- and is fetched twice per block instead of three times;
+//   * x halo image and dy tile arrive by LDS DMA (global_load_lds_dwordx4; pieces outside the image fetch a zero block)
+//     into the other half of a double buffer while the current tile's MFMAs run -- no staging registers, no ds_write, no
+//     address tables -- and a tile costs ONE barrier (s_waitcnt vmcnt(0) ; s_barrier: the next tile has landed,
+//     everybody is through with the buffer the DMAs after it overwrite);
+//   * the fragments of k-step ks + 1 are read (second register set) while the MFMAs of k-step ks run, as above;
+//   * every wave runs the same straight-line body over 4 n-block slots; a slot past the half's count multiplies the
+//     image's first pixels into an accumulator that is never stored (2 of 16 slots in one half, 3 in the other).
+// Same pixel-major LDS image (192-byte pixel stride = 64 x odd: ds_read_b64_tr_b16 conflict free), same partials.
+template <int DUMMY>
+struct ConvWgradTileA {
+  typedef WgradTileArgs Args;
+  static constexpr int NT = 256, NW = 4;
+  static constexpr int MAXJOBS = 32;
+  static constexpr int CX = 96, MB = 3, NBW = 27, NBL = 4, TAP_PARTS = 2, NB_FIRST = 14;
+  static constexpr int TW = 32, TH = 4, HW_ = TW + 2, HH_ = TH + 2;
+  static constexpr int SX = 192, SD = 192, XP = 12, DP = 12;       // pixel strides (bytes), 16-byte pieces per pixel
+  static constexpr int XN = HH_ * HW_ * XP, DN = TH * TW * DP;     // pieces: 2448, 1536
+  static constexpr int XW = (XN + 63) / 64, DW = DN / 64;          // wave instructions: 39, 24
+  static constexpr int XI = (XW + NW - 1) / NW, DI = DW / NW;      // per wave: 10 (the last wave 9), 6
+  static constexpr int X_BYTES = XW * 1024, D_BYTES = DW * 1024, STAGE_BYTES = X_BYTES + D_BYTES;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)STAGE_BYTES;
+  static_assert(DN % 64 == 0 && DW % NW == 0 && LDS_BYTES <= 160 * 1024, "geometry");
+
+  static __device__ __forceinline__ void run(const Args& a, const int bx, const int by, const int /*gx*/) {
+  const bf16_t* __restrict__ x = a.x;
+  const bf16_t* __restrict__ dy = a.dy;
+  float* __restrict__ partial = a.partial;
+  const int ldx = a.ldx, Cin = a.Cin, lddy = a.lddy, cout_pad = a.cout_pad, B = a.B, H = a.H, W = a.W;
+  const int tiles_x = a.tiles_x, tiles_y = a.tiles_y, tiles_per_wg = a.tiles_per_wg, n_parts = a.n_parts;
+  SSA_DYN_LDS(unsigned char, smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // by = (co block, ci block, half of the n-blocks): n_parts = 2 x the ci blocks
+  const int n_part = by % n_parts, co_part = by / n_parts;
+  const int half = n_part % TAP_PARTS, ci_part = n_part / TAP_PARTS;
+  const int co0 = co_part * 96, ci_base = ci_part * 96;
+  const int nb_begin = half * NB_FIRST, nb_count = half == 0 ? NB_FIRST : NBW - NB_FIRST;
+  const int Kflat = 9 * Cin;
+
+  // per-lane constants of the B (x) fragments of this wave's n-blocks: n-block nb = (tap nb / 3, channels 32 (nb % 3))
+  const int li = lane & 15, lj = li >> 2, lq = li & 3, lg = (lane >> 4) & 1, lh = lane >> 5;
+  int b_off[NBL], kcol0[NBL];
+#pragma unroll
+  for (int l = 0; l < NBL; ++l) {
+    const bool ok = wave + NW * l < nb_count;
+    const int nb = nb_begin + wave + NW * l;
+    const int tap = ok ? nb / 3 : 0, c32 = ok ? (nb - tap * 3) * 32 : 0;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    b_off[l] = (kh * HW_ + kw) * SX + (c32 + 16 * lg + 4 * lq) * 2;
+    kcol0[l] = ok ? tap * Cin + ci_base + c32 : -1;
+  }
+  const int a_col = (16 * lg + 4 * lq) * 2;     // byte offset of this lane's 4 channels inside an m-block
+
+  f32x16_t acc[MB][NBL];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][l][r] = 0.f;
+
+  // this lane's pieces of a tile, tile-invariant part: x piece i = slot 64 (wave + 8 i) + lane -> (halo pixel, piece);
+  // packed (hy << 16) | (hx << 8) | piece, -1: no such piece (its DMA fetches the zero block)
+  int xd[XI], dd[DI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int slot = (wave + NW * i) * 64 + lane;
+    const int pix = slot / XP, pc = slot - pix * XP;
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    xd[i] = (wave + NW * i < XW && slot < XN) ? ((hy << 16) | (hx << 8) | pc) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < DI; ++i) {
+    const int slot = (wave + NW * i) * 64 + lane;
+    const int pix = slot / DP, pc = slot - pix * DP;
+    const int ty = pix / TW, tx = pix - ty * TW;
+    dd[i] = (co0 + pc * 8 < cout_pad) ? ((ty << 16) | (tx << 8) | pc) : -1;
+  }
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(&g_zero_piece_t);
+  const int total_tiles = B * tiles_x * tiles_y;
+  const int t_begin = bx * tiles_per_wg;
+  const int t_end = min(total_tiles, t_begin + tiles_per_wg);
+
+  auto issue = [&](int t, int buf) {
+    int r_ = t;
+    const int tx_i = r_ % tiles_x; r_ /= tiles_x;
+    const int ty_i = r_ % tiles_y;
+    const int b = r_ / tiles_y;
+    const int x0 = tx_i * TW, y0 = ty_i * TH;
+    unsigned char* Xs = smem + buf * STAGE_BYTES;
+    unsigned char* Ds = Xs + X_BYTES;
+    const bf16_t* xb = x + (long)b * H * W * ldx + ci_base;
+    const bf16_t* db = dy + (long)b * H * W * lddy + co0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int wi = wave + NW * i;
+      if (wi < XW) {                            // (wave-uniform: the last wave has one instruction fewer)
+        const int iy = y0 - 1 + (xd[i] >> 16), ix = x0 - 1 + ((xd[i] >> 8) & 255);
+        const bool ok = xd[i] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const bf16_t* src = ok ? xb + ((long)iy * W + ix) * ldx + (xd[i] & 255) * 8 : zero;
+        ssa_glds16_untracked(src, Xs + wi * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int wi = wave + NW * i;
+      const int oy = y0 + (dd[i] >> 16), ox = x0 + ((dd[i] >> 8) & 255);
+      const bool ok = dd[i] >= 0 && oy < H && ox < W;
+      const bf16_t* src = ok ? db + ((long)oy * W + ox) * lddy + (dd[i] & 255) * 8 : zero;
+      ssa_glds16_untracked(src, Ds + wi * 1024);
+    }
+  };
+
+  // The fragments of k-step ks + 1 are read into the other half of a register ring while the MFMAs of k-step ks run.
+  auto compute = [&](const unsigned char* Xs, const unsigned char* Ds) {
+    constexpr int NL = NBL;
+    bf16x8_t af[2][MB], bfr[2][NL];
+    auto rd = [&](int ks, int slot) {
+      const int ty = ks >> 1, tx0 = (ks & 1) * 16;
+      const int kp = tx0 + 8 * lh + lj;         // this lane's first pixel column inside the row
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) af[slot][mb] = tr_read8(Ds + (ty * TW + kp) * SD + mb * 64 + a_col, SD);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) bfr[slot][l] = tr_read8(Xs + (ty * HW_ + kp) * SX + b_off[l], SX);
+    };
+    rd(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MB + NL), 0);      // the prologue reads are a group of their own
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb][l] = ssa_mfma32(af[ks & 1][mb], bfr[ks & 1][l], acc[mb][l]);
+      if (ks + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MB + NL), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MB * NL, 0);
+    }
+  };
+
+  int buf = 0;
+  if (t_begin < t_end) issue(t_begin, 0);
+  for (int t = t_begin; t < t_end; ++t) {
+    ssa_wait_vm_barrier<0, 0>();                // tile t has landed; every wave is through with the other buffer
+    if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+    const unsigned char* Xs = smem + buf * STAGE_BYTES;
+    const unsigned char* Ds = Xs + X_BYTES;
+    compute(Xs, Ds);
+    buf ^= 1;
+  }
+
+  // ---- this workgroup's block of partial[g][co][k] (zeros if it had no tile)
+  float* out = partial + (long)bx * cout_pad * Kflat;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int l = 0; l < NBL; ++l) {
+      if (kcol0[l] < 0) continue;
+      const int kcol = kcol0[l] + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < cout_pad) out[(long)co * Kflat + kcol] = acc[mb][l][r];
+      }
+    }
+  }
+};
+
 struct Plan { int cx, mb, nbw, n_parts, co_parts; };
 
 bool c96_on() {
@@ -278,8 +461,18 @@ bool c96_on() {
   return on;
 }
 
+// SSA_WGRAD_ALL=0: the 96-channel blocks stay on the 4-wave, one-kernel-row-per-workgroup form
+bool all_taps_on() {
+  static const bool on = !(getenv("SSA_WGRAD_ALL") && atoi(getenv("SSA_WGRAD_ALL")) == 0);
+  return on;
+}
+
 bool make_plan(int Cin, int cout_pad, Plan* p) {
   if (Cin != cout_pad) return false;
+  if (all_taps_on() && (Cin == 96 || Cin == 192 || Cin == 384)) {      // ConvWgradTileA: cx = 0 marks it
+    *p = Plan{0, 3, 27, 2 * (Cin / 96), Cin / 96};       // n_parts = 2 halves of the n-blocks x ci blocks
+    return true;
+  }
   switch (Cin) {
     case 48: *p = {48, 2, 14, 1, 1}; return true;
     case 64: *p = {64, 2, 18, 1, 1}; return true;
@@ -339,6 +532,18 @@ int ssa_conv2d_wgrad_tile_plan(const ssa_conv_desc* d, int cout_pad, int* nsplit
   return SSA_OK;
 }
 
+// What the host's launch planning needs to know about a layer's launch: workgroups per strip (`parts`) and how many
+// workgroups of this instantiation the chip holds at once (`slots`: 64 KB of LDS and <= 256 registers x 4 waves = two per
+// CU on paper -- the 4-wave form in fact holds 467 registers and gets ONE; the 8-wave all-taps form: one per CU).
+int ssa_conv2d_wgrad_tile_geometry(int Cin, int cout_pad, int* parts, int* slots, int* kind) {
+  Plan p;
+  if (!parts || !slots || !kind || !make_plan(Cin, cout_pad, &p)) return SSA_EUNSUPPORTED;
+  *parts = p.n_parts * p.co_parts;
+  *slots = 256;
+  *kind = p.cx == 0 ? 0 : (p.cx == 96 ? 96 : p.cx);      // launches group by instantiation
+  return SSA_OK;
+}
+
 int ssa_conv2d_wgrad_tile(const ssa_conv_desc* dp, const void* x, const void* dy, int lddy, int cout_pad,
                           int nsplit, float* partial, void* stream) {
   Plan p;
@@ -349,6 +554,14 @@ int ssa_conv2d_wgrad_tile(const ssa_conv_desc* dp, const void* x, const void* dy
   const long tiles = (long)d.B * ((d.W + 31) / 32) * ((d.H + 3) / 4);
   const int tpw = (int)((tiles + nsplit - 1) / nsplit);
   hipStream_t s = (hipStream_t)stream;
+  if (p.cx == 0) {
+    typedef ConvWgradTileA<0> K;
+    WgradTileArgs a;
+    a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.partial = partial;
+    a.ldx = d.ldx; a.Cin = d.Cin; a.lddy = lddy; a.cout_pad = cout_pad; a.B = d.B; a.H = d.H; a.W = d.W;
+    a.tiles_x = (d.W + 31) / 32; a.tiles_y = (d.H + 3) / 4; a.tiles_per_wg = tpw; a.n_parts = p.n_parts;
+    return ssa::submit<K>(a, nsplit, p.n_parts * p.co_parts, K::LDS_BYTES, s);
+  }
   switch (d.Cin) {
     case 48: return launch<48, 2, 14>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);
     case 64: return launch<64, 2, 18>(d, p, x, dy, lddy, cout_pad, nsplit, tpw, partial, s);

@@ -97,6 +97,7 @@ _SIGS = {
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_tile_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_tile": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
+    "ssa_conv2d_wgrad_tile_geometry": ([c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)], c_int),
     "ssa_conv2d_wgrad_head_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad_head": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_conv2d_wgrad_reduce": ([_P] + [c_int] * 7 + [_P, c_int, _P], c_int),

@@ -754,10 +754,10 @@ def _wgrad_job(x, ldx, geom_in, dy, lddy, cout_pad, geom_out, k, stride, pad, di
 
 
 _WGRAD_FIT = os.environ.get("SSA_WGRAD_FIT", "1") != "0"
-# workgroup slots a weight-gradient launch is fitted to: two 64 KB workgroups per CU = the whole chip.  (One per CU --
-# leaving every CU 96 KB of LDS and half its registers for the main branch's kernels -- measured the same step time:
-# profiles/r05_notes.md call B; the branches do not overlap however they are sized)
-_WGRAD_SLOTS = 512
+# workgroup slots a weight-gradient launch is fitted to, when the library does not say (ssa_conv2d_wgrad_tile_geometry):
+# rounds 2-5 fitted to 512 -- two 64 KB workgroups per CU -- but the 4-wave tile kernel holds 467 registers per lane and
+# gets ONE workgroup per CU (kernel-resource-usage report, round 6): a "full round" of 512 was two rounds of 256.
+_WGRAD_SLOTS = int(os.environ.get("SSA_WGRAD_SLOTS", "256"))
 _WGRAD_GROUP = 32       # layers (problems) per grouped weight-gradient launch: csrc/group.h MAXJOBS of ConvWgradTile
 
 
@@ -766,30 +766,35 @@ def _fit_tile_strips(jobs, strip):
     launch carries up to 32 layers of one instantiation (csrc/group.h MAXJOBS) and its workgroups are persistent, so a launch
     of 552 or 640 workgroups runs as a full round on the chip's 512 slots (two 64 KB workgroups per CU) plus a tail
     round of the same length -- 96-105 us where 480 workgroups take 76 (profiles/r04_notes.md).  For every launch
-    pick the strip length in [strip, 6*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
+    pick the strip length in [strip, 8*strip] that minimises rounds x (strip + fixed cost); job -> strip."""
     out = {}
     if not _WGRAD_FIT or strip <= 0:
         return out
     groups = {}
+    L = lib()
     for j in jobs:
         B, H, W, Cin = j.geom_in
         if j.k != (3, 3) or j.stride != 1 or j.dil != 1 or j.pad != 1 or Cin != j.cout_pad or Cin not in (48, 64, 96, 192, 384):
             continue
-        parts = {48: 1, 64: 1, 96: 3, 192: 12, 384: 48}[Cin]
+        # workgroups per strip, resident workgroups, instantiation: from the library (csrc/conv_wgrad_tile.hip make_plan)
+        parts, slots, kind = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        if L.ssa_conv2d_wgrad_tile_geometry(Cin, j.cout_pad, ctypes.byref(parts), ctypes.byref(slots), ctypes.byref(kind)) != 0:
+            continue
         tiles = B * ((W + 31) // 32) * ((H + 3) // 4)
-        groups.setdefault(min(Cin, 96), []).append((j, tiles, parts))
+        groups.setdefault(kind.value, []).append((j, tiles, parts.value, min(slots.value, _WGRAD_SLOTS)))
     for lst in groups.values():
         for i in range(0, len(lst), _WGRAD_GROUP):
             chunk = lst[i:i + _WGRAD_GROUP]
+            slots = chunk[0][3]
             best = None
             # (twice the layers per launch want strips up to twice as long for the same workgroup count: that is the
             # point -- a layer's fp32 partials, one block per workgroup, halve, and so does what WgradReduceK reads)
-            for s_ in range(strip, 6 * strip + 1):
-                wgs = sum(-(-t // s_) * p for _, t, p in chunk)
-                cost = -(-wgs // _WGRAD_SLOTS) * (s_ + 2.0)
+            for s_ in range(strip, 8 * strip + 1):
+                wgs = sum(-(-t // s_) * p for _, t, p, _ in chunk)
+                cost = -(-wgs // slots) * (s_ + 2.0)
                 if best is None or cost < best[0] - 1e-9:
                     best = (cost, s_)
-            for j, _, _ in chunk:
+            for j, _, _, _ in chunk:
                 out[id(j)] = best[1]
     return out
 

@@ -89,15 +89,18 @@ def test_teacher_forced_ops_at_1024():
     assert n_fwd > 100 and bwd_cmp > 1500
     if CROP >= 1024:
         fams = {n.split("<")[0] for n in names}
-        for f in ("ConvHaloGemm3", "ConvHaloGemm1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile", "ConvIgemm",
-                  "ConvWgradTr"):
+        for f in ("ConvHaloGemm3", "ConvHaloGemm1", "ConvGemmWide1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile",
+                  "ConvWgradTileA", "ConvIgemm", "ConvWgradTr", "BnApplyTrainK", "BnBwdReduceK", "BnBwdReduceXK", "BnBwdApplyK",
+                  "BnBwdApplyXK"):
             assert f in fams, "dispatch class %s is not on the traced path" % f
         # the trunk levels' 3x3 convs: the resident (48 channels) and the streamed instantiation behind one kernel,
         # conv_tile_p.hip: plain forward <0>, data gradient with the residual gradient <1> / the BatchNorm-backward
         # sums <2> in the epilogue
         for inst in ("ConvTilePK<0>", "ConvTilePK<1>", "ConvTilePK<2>"):
             assert inst in names, "%s is not on the path" % inst
-        assert any(n.startswith("ConvWgradTile<96,") for n in names)
+        # the trunk's 3x3 weight gradients: 48 channels on the 4-wave tile kernel, the 96-channel blocks (96 / 192 / 384
+        # channels) on the all-taps form (round 6), the large 1x1 head convs on the 256 x 256 GEMM
+        assert any(n.startswith("ConvWgradTile<48,") for n in names) and "ConvWgradTileA<0>" in names
     assert not tb.rec.failures(), tb.rec.summary(30)
 
 
