@@ -509,6 +509,11 @@ def halo_supported(d):
     return bool(lib().ssa_conv2d_halo_supported(ctypes.byref(d)))
 
 
+def wide_supported(d):
+    """The 256 x 256 GEMM (csrc/conv_gemm_wide.hip) takes this 1x1 problem and is the better choice for it."""
+    return bool(lib().ssa_conv2d_gemm_wide_supported(ctypes.byref(d)))
+
+
 _STAT_REPLICAS = None
 
 
@@ -541,7 +546,7 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     return y
 
 
-def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0):
+def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=None, mode=0, wide=False):
     """Halo-staged conv launch: conv_tile.hip (small-channel 3x3 convs; aux = fused epilogue tile of
     the data gradient, see ssa_conv2d_tile_aux) or conv_halo_gemm.hip (large-channel 3x3 / 1x1)."""
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=torch.float32 if d.out_f32 else ACT_DTYPE,
@@ -550,7 +555,9 @@ def _tile_conv(d, x, wfrag, bias, stats, halo=False, aux=None, ldaux=0, coef=Non
     _note(2.0 * P * d.Cout * d.Cin * d.KH * d.KW,
           _conv_bytes(P, d.Cin, P, d.Cout, (d.KH, d.KW), 4 if d.out_f32 else 2) + (2.0 * P * d.Cout if mode else 0.0))
     L = lib()
-    if not halo and bias is None and tile_p_supported(d):
+    if wide:
+        check(L.ssa_conv2d_gemm_wide(ctypes.byref(d), _p(x), _p(wfrag), _p(bias), _p(y), _p(stats), _s()), "ssa_conv2d_gemm_wide")
+    elif not halo and bias is None and tile_p_supported(d):
         check(L.ssa_conv2d_tile_p(ctypes.byref(d), _p(x), _p(wfrag), None, _p(y), _p(stats),
                                   _p(aux), ldaux, _p(coef), mode, _s()), "ssa_conv2d_tile_p")
     elif mode:
@@ -629,13 +636,14 @@ def _conv_fwd(x, ldx, weight, b, stride, pad, dil, out_f32, want_stats):
     td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, out_f32)
     al = x.data_ptr() % 16 == 0
     use_tile = al and tile_supported(td)
-    use_halo = (not use_tile) and al and halo_supported(td)
+    use_wide = (not use_tile) and al and wide_supported(td)          # (the library's policy: csrc/conv_gemm_wide.hip)
+    use_halo = (not use_tile) and (not use_wide) and al and halo_supported(td)
     stats = None
-    if want_stats and not out_f32 and not (_NO_IGEMM_STATS and not (use_tile or use_halo)):
+    if want_stats and not out_f32 and not (_NO_IGEMM_STATS and not (use_tile or use_halo or use_wide)):
         stats = _ARENA.take(stat_replicas() * 2 * Cout, x.device)
-    if use_tile or use_halo:
+    if use_tile or use_halo or use_wide:
         wp, _ = _packed_filter(weight, 2, Cin, 0)
-        y = _tile_conv(td, x, wp, b, stats, halo=use_halo)
+        y = _tile_conv(td, x, wp, b, stats, halo=use_halo, wide=use_wide)
     else:
         wp, Kpad = _packed_filter(weight, 0, Cin, 0)
         y = _igemm(x, ldx, (B, H, W, Cin), wp, Kpad, b, (Ho, Wo), Cout, (KH, KW), stride, pad, dil, False,
@@ -663,12 +671,13 @@ def _conv_dgrad(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw, 
     td = _dgrad_desc(x_shape, weight, dyb, lddy, cout_pad, stride, pad, dil, out_hw)
     al = dyb.data_ptr() % 16 == 0
     use_tile = al and tile_supported(td)
-    use_halo = (not use_tile) and al and halo_supported(td)
+    use_wide = (not use_tile) and al and not mode and wide_supported(td)
+    use_halo = (not use_tile) and (not use_wide) and al and halo_supported(td)
     if mode:
         assert use_tile
-    if use_tile or use_halo:
+    if use_tile or use_halo or use_wide:
         wpt, _ = _packed_filter(weight, 3, 0, cout_pad)
-        return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode)
+        return _tile_conv(td, dyb, wpt, None, stats, halo=use_halo, aux=aux, ldaux=ldaux, coef=coef, mode=mode, wide=use_wide)
     if _DGRAD_S2 and stride == 2 and (KH, KW) == (3, 3) and pad == 1 and dil == 1 and Cin % 8 == 0 and al and \
             lddy % 8 == 0 and (Ho, Wo) == ((H - 1) // 2 + 1, (W - 1) // 2 + 1):
         return _dgrad_s2(x_shape, weight, dyb, lddy, cout_pad, out_hw)

@@ -200,7 +200,11 @@ def test_train_step(setup):
     rel_e = {k: float((se[k] - sr[k]).abs().max() / (sr[k].abs().max() + 1e-12)) for k in sr}
     top = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
     print("running stats worst rel %.4g (emu %.4g); the five worst: %s" % (top[0][1], max(rel_e.values()), [(k, round(v, 4), round(rel_e[k], 4)) for k, v in top]))
-    over = [(k, v, rel_e[k]) for k, v in rel.items() if v > max(3e-2, 2.0 * rel_e[k])]
+    # (round 6: the bound on the largest entry sat INSIDE the range the comment above states -- 3 % against 1.7-3.8 % --,
+    # and the first kernel change that moved a rounding anywhere upstream tripped it: f_up's variance 3.03 % with 1 ulp
+    # different BatchNorm scales, identical with the new conv kernels switched on or off.  4.5 % clears the stated range;
+    # a wrong statistic -- a miscounted pixel, a missed pass -- is off by 10 % or more.)
+    over = [(k, v, rel_e[k]) for k, v in rel.items() if v > max(4.5e-2, 2.0 * rel_e[k])]
     assert not over, over[:5]
 
 
