@@ -97,7 +97,7 @@ def family(kernel):
         return "ConvTile"
     # the head convs: conv_halo_gemm.hip (3x3: ConvHaloGemm3, 1x1: ConvHaloGemm1), conv_wgrad_head.hip (3x3: ...Head3)
     # conv_gemm_wide.hip: the large 1x1 convs on the 256 x 256 tile
-    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
+    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloReg3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
             "ConvGemmWide1": "ConvGemmWide", "ConvWgradTileA": "ConvWgradTile",
             # the BatchNorm backward passes, whichever way the ReLU mask arrives (csrc/bn.hip MODE)
             "BnBwdApplyXK": "BnBwdApplyK", "BnBwdApplyZK": "BnBwdApplyK", "BnBwdReduceXK": "BnBwdReduceK",
@@ -471,7 +471,7 @@ def main():
         k3 = {"us": 0.0, "flops": 0.0, "kernels": {}}
         for r in recs:
             base = r["kernel"].split("<")[0]
-            if family(r["kernel"]) == "ConvTile" or base in ("ConvHaloGemm3", "ConvWgradHead3", "ConvWgradTile", "ConvWgradTileA"):
+            if family(r["kernel"]) == "ConvTile" or base in ("ConvHaloGemm3", "ConvHaloReg3", "ConvWgradHead3", "ConvWgradTile", "ConvWgradTileA"):
                 t_us = max(r["total_us"] - empty_us * r["launches"], 0.05 * r["launches"])
                 k3["us"] += t_us
                 k3["flops"] += r["flops"]

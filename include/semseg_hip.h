@@ -170,6 +170,18 @@ int ssa_conv2d_gemm_wide_supported(const ssa_conv_desc* d);
 int ssa_conv2d_gemm_wide(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias,
                          void* y, double* stats, void* stream);
 
+/* Second geometry for the 3x3 stride-1 "same" convs of the OCR / attention heads and their data gradients
+ * (conv3x3_ocr 720->512, attn 512->256 / 256->256; network/ocrnet.py:54-58, network/utils.py:348-357): 128 pixels x
+ * 256 channels per 4-wave workgroup, 128 x 64 per wave (4 x 2 MFMA 32x32x16 tiles); the filter fragments go straight
+ * from global memory into the MFMA operand registers through a ring six k-steps deep (they never touch LDS), the input
+ * halo tile by LDS DMA, double buffered per 48 / 64-channel chunk: one workgroup barrier per chunk
+ * (csrc/conv_halo_reg.hip).  Same operands as ssa_conv2d_halo; 16-bit output only; stats as for ssa_conv2d_tile.
+ * ssa_conv2d_halo forwards the 3x3 problems this entry point supports (SSA_HALO3_REG=0 keeps them on the 256 x 128
+ * LDS-ring kernel).                                                                                              */
+int ssa_conv2d_halo_reg_supported(const ssa_conv_desc* d);
+int ssa_conv2d_halo_reg(const ssa_conv_desc* d, const void* x, const void* w_frag, const float* bias,
+                        void* y, double* stats, void* stream);
+
 /* Tile configuration ssa_conv2d_igemm would use for this problem
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);

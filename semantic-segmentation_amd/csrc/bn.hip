@@ -667,12 +667,19 @@ int norm_rows(int r) { return r <= 2 ? 2 : (r <= 4 ? 4 : 8); }
 // `rows` pixel rows per thread (2, 4 or 8: the instantiation) in one chunk per workgroup; at most max_blocks
 // workgroups, beyond which a workgroup walks several chunks (the reducing kernels end in 2C fp64 atomics per
 // workgroup, so they get a lower cap).
-Grid plan_grid(long P, int C, int rows, long max_blocks = 16384) {
+Grid plan_grid(long P, int C, int rows, long max_blocks = 16384, int chunks = 1) {
   const int VC = C >> 3;
   const int RP = active_threads(VC) / VC;
   const long chunk = (long)RP * rows;
   long ppb = chunk;
   long blocks = (P + ppb - 1) / ppb;
+  // `chunks` > 1 (the passes with a per-workgroup coefficient prologue on wide layers): a workgroup walks that many
+  // chunks as long as the launch still fills every workgroup slot of the chip (4 per CU)
+  if (chunks > 1 && blocks > 1024) {
+    long want = (blocks + chunks - 1) / chunks;
+    if (want < 1024) want = 1024;
+    if (want < max_blocks) max_blocks = want;
+  }
   if (blocks > max_blocks) {
     ppb = (P + max_blocks - 1) / max_blocks;
     ppb = (ppb + chunk - 1) / chunk * chunk;
@@ -682,6 +689,14 @@ Grid plan_grid(long P, int C, int rows, long max_blocks = 16384) {
   return {(int)blocks, ppb, rows};
 }
 // Rows per thread of the three pass families (SSA_BN_ROWS_*: 2 / 4 / 8; sweep in profiles/r04_notes.md)
+// The training apply and the backward apply derive their per-channel coefficients from the [nrep][2][C] fp64 sums in
+// EVERY workgroup (128 B per channel: 92 KB at the aux head's 720 channels -- against the 11.5 KB of data of that layer's
+// 8-pixel chunk: a 10,240-workgroup launch read 0.94 GB of sums for 0.24 GB of activations, 102 us).  From 256 channels
+// on a workgroup therefore walks several chunks per prologue (SSA_BN_WIDE_CHUNKS, 0 = one chunk as before).
+int prologue_chunks(int C) {
+  static const int n = env_int("SSA_BN_WIDE_CHUNKS", 6);
+  return (C >= 256 && n > 1) ? n : 1;
+}
 int apply_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_APPLY", 4)); return r; }
 int bwd_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_BWD", 4)); return r; }
 int reduce_rows() { static const int r = norm_rows(env_int("SSA_BN_ROWS_REDUCE", 8)); return r; }
@@ -745,7 +760,7 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
   if (!x || !z || !sums || !coef || !ok_c(C) || !ok_p(P) || ldx % 8 || ldz % 8 || (residual && ldr % 8) ||
       count <= 0 || nrep < 1 || (running_mean && !running_var))
     return SSA_EINVAL;
-  const Grid g = plan_grid(P, C, apply_rows());
+  const Grid g = plan_grid(P, C, apply_rows(), 16384, prologue_chunks(C));
   return SSA_BN_SUBMIT(BnApplyTrainK, g, ({(const bf16_t*)x, (const bf16_t*)residual, (bf16_t*)z, sums, gamma, beta,
                                            running_mean, running_var, num_batches_tracked, coef, pass_stats, post,
                                            (unsigned char*)sign_mask, count, 1.0 / count,
@@ -797,7 +812,7 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
       (mask_scale && !mask_shift))
     return SSA_EINVAL;
   if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
-  const Grid g = plan_grid(P, C, bwd_rows());
+  const Grid g = plan_grid(P, C, bwd_rows(), 16384, prologue_chunks(C));
   // one instantiation per source of the ReLU mask (bn_bwd_apply_body's MODE)
 #define SSA_BN_BWD_APPLY(K)                                                                                              \
   SSA_BN_SUBMIT(K, g, ({(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres, gamma, mean, invstd, \

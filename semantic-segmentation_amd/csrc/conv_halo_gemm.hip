@@ -509,6 +509,9 @@ int ssa_conv2d_halo(const ssa_conv_desc* dp, const void* x, const void* w_frag, 
   // the large 1x1 problems go to the 256 x 256 tile (conv_gemm_wide.hip); SSA_GEMM_WIDE=0: all stay here
   static const bool wide_on = !(getenv("SSA_GEMM_WIDE") && atoi(getenv("SSA_GEMM_WIDE")) == 0);
   if (wide_on && d.KH == 1 && ssa_conv2d_gemm_wide_supported(dp)) return ssa_conv2d_gemm_wide(dp, x, w_frag, bias, y, stats, stream);
+  // the 3x3 problems go to the register-fed geometry (conv_halo_reg.hip); SSA_HALO3_REG=0: all stay here
+  static const bool reg_on = !(getenv("SSA_HALO3_REG") && atoi(getenv("SSA_HALO3_REG")) == 0);
+  if (reg_on && d.KH == 3 && ssa_conv2d_halo_reg_supported(dp)) return ssa_conv2d_halo_reg(dp, x, w_frag, bias, y, stats, stream);
   const int ck = pick_ck(d.Cin);
   if (d.KH == 3) {
     if (ck == 64) return launch_halo3<64, 4>(d, x, w_frag, bias, y, stats, s);

@@ -92,6 +92,8 @@ _SIGS = {
     "ssa_conv2d_halo": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_conv2d_gemm_wide_supported": ([POINTER(ConvDesc)], c_int),
     "ssa_conv2d_gemm_wide": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
+    "ssa_conv2d_halo_reg_supported": ([POINTER(ConvDesc)], c_int),
+    "ssa_conv2d_halo_reg": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P], c_int),
     "ssa_pack_filter": ([_P, _P] + [c_int] * 8 + [_P], c_int),
     "ssa_conv2d_wgrad_plan": ([POINTER(ConvDesc), c_int, POINTER(c_int), POINTER(c_size_t)], c_int),
     "ssa_conv2d_wgrad": ([POINTER(ConvDesc), _P, _P, c_int, c_int, c_int, _P, _P], c_int),

@@ -241,6 +241,55 @@ def test_gemm_wide_1x1(case):
         check_close("gemm_wide squares %s" % (case,), got[1], (yr * yr).sum(0).cpu(), 1e-4, 1e-4)
 
 
+HALO_REG_CASES = [
+    # B, H, W, Cin, Cout, bias, stats, transposed-pack (the data-gradient form: ssa_pack_filter mode 3)
+    (1, 8, 64, 128, 264, True, True, False),       # 2 x 2 pixel tiles, two 64-channel chunks, two channel tiles (2nd: 8 wide)
+    (1, 7, 37, 96, 72, False, True, False),        # ragged tile rows / columns, two 48-channel chunks, n-block tail
+    (2, 4, 32, 192, 256, True, False, False),      # batch 2, three 64-channel chunks (odd count), one full channel tile
+    (1, 9, 33, 144, 320, False, True, True),       # data-gradient packing, three 48-channel chunks, image edge columns
+]
+
+
+@pytest.mark.parametrize("case", HALO_REG_CASES)
+def test_halo_reg_3x3(case):
+    """csrc/conv_halo_reg.hip through its own entry point (ssa_conv2d_halo forwards the head's 3x3 problems to it): the
+    register-fed filter ring, the masked halo DMA (image borders, ragged tiles, the unused pieces of a 48-channel chunk),
+    both chunk widths with even / odd chunk counts, channel-tile and n-block tails, bias, the BatchNorm partial sums of the
+    ROUNDED outputs, both filter packings -- at sizes the CPU emulation runs in seconds."""
+    import ctypes
+    from oracle import ops as O
+    from semseg_amd._lib import check
+    hb = _hb()
+    B, H, W, Cin, Cout, bias, stats, tr = case
+    x = _rand(B, Cin, H, W, seed=3)
+    w = _rand(Cout, Cin, 3, 3, seed=4, scale=1.0 / math.sqrt(9 * Cin))
+    b = _rand(Cout, seed=5) if bias else None
+    ref = O.conv2d(x, w, b, 1, 1, 1)
+    xd = _to_dev_nhwc(x)
+    hb.clear_pack_cache()
+    if tr:      # the weight of the conv whose DATA gradient this is: flipped taps, [Cin_fwd = Cout here][Cout_fwd = Cin here]
+        wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous().to(xd.device)
+        wp, _ = hb._packed_filter(wt, 3, 0, Cin)
+    else:
+        wp, _ = hb._packed_filter(w.to(xd.device), 2, Cin, 0)
+    d = hb._tile_desc(B, H, W, Cin, Cin, Cout, (3, 3), 1, 1, 1, H, W, False)
+    L = hb.lib()
+    assert L.ssa_conv2d_halo_reg_supported(ctypes.byref(d)) == 1
+    y = torch.empty(B, H, W, Cout, dtype=ACT_DTYPE, device=xd.device)
+    nrep = hb.stat_replicas()
+    st = torch.zeros(nrep, 2, Cout, dtype=torch.float64, device=xd.device) if stats else None
+    bd = b.to(xd.device) if b is not None else None
+    check(L.ssa_conv2d_halo_reg(ctypes.byref(d), hb._p(xd), hb._p(wp), hb._p(bd), hb._p(y), hb._p(st), hb._s()), "halo_reg")
+    if xd.is_cuda:
+        torch.cuda.synchronize()
+    check_close("halo_reg %s" % (case,), nchw(y.float()), ref)
+    if stats:
+        yr = y.float().view(-1, Cout).double()
+        got = st.sum(0).cpu()
+        check_close("halo_reg sums %s" % (case,), got[0], yr.sum(0).cpu(), 1e-4, 1e-4)
+        check_close("halo_reg squares %s" % (case,), got[1], (yr * yr).sum(0).cpu(), 1e-4, 1e-4)
+
+
 def test_stride2_dgrad_by_parity_matches_zero_inserted():
     """ssa_conv2d_dgrad_s2 (four dense parity classes) against the zero-inserted transposed form it
     replaces: same operands, same bf16 rounding of the result; the two differ only in the order of the

@@ -89,7 +89,8 @@ def test_teacher_forced_ops_at_1024():
     assert n_fwd > 100 and bwd_cmp > 1500
     if CROP >= 1024:
         fams = {n.split("<")[0] for n in names}
-        for f in ("ConvHaloGemm3", "ConvHaloGemm1", "ConvGemmWide1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile",
+        halo3 = "ConvHaloGemm3" if os.environ.get("SSA_HALO3_REG") == "0" else "ConvHaloReg3"      # (csrc/conv_halo_gemm.hip's switch)
+        for f in (halo3, "ConvHaloGemm1", "ConvGemmWide1", "ConvWgradHead3", "ConvWgradHead", "ConvTile", "ConvWgradTile",
                   "ConvWgradTileA", "ConvIgemm", "ConvWgradTr", "BnApplyTrainK", "BnBwdReduceK", "BnBwdReduceXK", "BnBwdApplyK",
                   "BnBwdApplyXK"):
             assert f in fams, "dispatch class %s is not on the traced path" % f

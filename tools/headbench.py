@@ -57,6 +57,9 @@ def main():
               (512, 1024, 256, 256, 1), (256, 512, 256, 256, 1), (720, 720, 128, 128, 1), (1024, 512, 128, 128, 1)]
     if "--only-1x1" in sys.argv:
         shapes = [s for s in shapes if s[4] == 1]
+    if "--only-3x3" in sys.argv:      # + the data-gradient shapes of the same convs and the 1.0x attention-head sizes
+        shapes = [s for s in shapes if s[4] == 3] + [(512, 720, 256, 256, 3), (512, 720, 128, 128, 3), (512, 256, 256, 256, 3),
+                                                     (256, 256, 256, 256, 3), (256, 512, 128, 128, 3)]
     probs = [WProb(*s) for s in shapes]
     for p in probs:
         if "--fwd-only" in sys.argv:

@@ -37,7 +37,7 @@ def family(i):
     f = re.sub(r"<.*", "", i)
     if f in ("ConvTileAny", "ConvTilePAny", "ConvTilePK", "ConvTileP"):
         return "ConvTile"
-    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
+    return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloReg3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
             "ConvGemmWide1": "ConvGemmWide", "ConvWgradTileA": "ConvWgradTile", "BnBwdApplyXK": "BnBwdApplyK",
             "BnBwdApplyZK": "BnBwdApplyK", "BnBwdReduceXK": "BnBwdReduceK", "BnBwdReduceZK": "BnBwdReduceK"}.get(f, f)
 
