@@ -100,7 +100,7 @@ def family(kernel):
     return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloReg3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
             "ConvGemmWide1": "ConvGemmWide", "ConvWgradTileA": "ConvWgradTile",
             # the BatchNorm backward passes, whichever way the ReLU mask arrives (csrc/bn.hip MODE)
-            "BnBwdApplyXK": "BnBwdApplyK", "BnBwdApplyZK": "BnBwdApplyK", "BnBwdReduceXK": "BnBwdReduceK",
+            "BnBwdApplyXK": "BnBwdApplyK", "BnBwdFusedXK": "BnBwdFusedK", "BnBwdFusedZK": "BnBwdFusedK", "BnBwdApplyZK": "BnBwdApplyK", "BnBwdReduceXK": "BnBwdReduceK",
             "BnBwdReduceZK": "BnBwdReduceK"}.get(f, f)
 
 

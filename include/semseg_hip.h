@@ -370,6 +370,25 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz,
                      long pix_per_img, float* dgamma, float* dbeta,
                      float param_grad_scale, const float* mask_scale,
                      const float* mask_shift, int accumulate_param_grads, const void* sign_mask, void* stream);
+/* Backward reduce + apply as ONE launch for the BatchNorm layers whose sums no conv epilogue has formed (bn2 of a
+ * BasicBlock, network/hrnetv2.py:53-64): phase 1 forms sum g / sum g xhat as ssa_bn_bwd_reduce does, a grid-wide
+ * rendezvous (one atomic ticket per workgroup) follows, phase 2 applies them to the chunk the workgroup still holds in
+ * registers -- (x, dz, mask) are read once instead of twice.  Same arguments as ssa_bn_bwd_apply (sums: zeroed
+ * [nrep][2][C], accumulated here) plus `ticket`, one zeroed 32-bit word per call.  Every workgroup of the launch must be
+ * able to be resident at once: ssa_bn_bwd_fused_blocks(P, C) = workgroups the problem takes (0: unsupported -- more
+ * than one chunk per workgroup, emulation build), ssa_bn_bwd_fused_capacity() = workgroups the device holds; the caller
+ * keeps a bracket's total within it and takes the two-launch form otherwise, and whenever a SyncBN exchange has to happen
+ * between the halves.  A workgroup that waits ~1 s gives up and counts itself: ssa_bn_bwd_fused_timeouts (0 = never). */
+int ssa_bn_bwd_fused_blocks(long P, int C);
+int ssa_bn_bwd_fused_capacity(void);
+int ssa_bn_bwd_fused_timeouts(unsigned* out);
+int ssa_bn_bwd_fused(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
+                     void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
+                     const float* mean, const float* invstd, double* sums, int nrep,
+                     double count, int relu, const float* post, long pix_per_img, float* dgamma,
+                     float* dbeta, float param_grad_scale, const float* mask_scale,
+                     const float* mask_shift, int accumulate_param_grads, const void* sign_mask, void* ticket,
+                     void* stream);
 /* dgamma[c] = sums[C+c], dbeta[c] = sums[c] (fp64 -> fp32)                     */
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);

@@ -533,6 +533,175 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   }
 }
 
+// ---- backward reduce + apply as ONE launch (round 6) ---------------------------------------------------------
+// The two-launch form reads (x, dz, mask) twice: once to form sum g and sum g xhat, once more to apply them.  A trunk
+// level is ~930 workgroups of one chunk each, all resident at once (<= 128 registers, 4 workgroups per CU): here every
+// workgroup keeps its chunk IN REGISTERS across a grid-wide rendezvous -- phase 1 is the reduce (per-workgroup partial
+// sums -> fp64 atomics), then one atomic ticket per workgroup and a spin on the ticket counter, then phase 2 derives the
+// coefficients from the completed sums and writes dx (and the residual gradient).  The sums are read with agent-scope
+// atomic loads: they were accumulated by atomics at the coherence point, and another XCD's L2 owes a plain load nothing
+// before the kernel boundary.
+// The rendezvous needs every workgroup of the PROBLEM resident (or able to become resident while others spin): the
+// host only routes a bracket here whose workgroups all fit on the chip at once (ssa_bn_bwd_fused_blocks), kernels of
+// other streams that hold CUs (the weight-gradient stream) finish on their own and free them.  A workgroup that has
+// spun ~1 s gives up, counts itself in g_bn_fused_timeouts (ssa_bn_bwd_fused_timeouts) and applies what sums there are:
+// a wrong gradient the tests and bench.py detect, never a hung GPU.
+#ifndef SSA_BN_SPIN_SLEEP      // 64-clock units between two polls of the ticket counter (experiment builds)
+#define SSA_BN_SPIN_SLEEP 8
+#endif
+__device__ unsigned g_bn_fused_timeouts;
+
+__device__ __forceinline__ double coherent_load(const double* p) {
+#ifdef SSA_EMU
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+template <int ROWS, int MODE>
+__device__ __forceinline__ void bn_bwd_fused_body(
+    const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dz, int lddz,
+    const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ dx, int lddx,
+    bf16_t* __restrict__ dres, int lddres, long P, int C, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    double* __restrict__ sums, int nrep, double inv_count, int relu,
+    const float* __restrict__ post, long pix_per_img, long pix_per_block,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float param_grad_scale,
+    const float* __restrict__ mscale, const float* __restrict__ mshift, const int accumulate_pg,
+    const unsigned char* __restrict__ mask, unsigned* __restrict__ ticket, const int bx, const int nblocks) {
+  SSA_DYN_LDS(float, sh);                 // phase 1: [16][NT + 1] transposed partials; phase 2: [5C] coefficients
+  const int VC = C >> 3, NA = active_threads(VC), RP = NA / VC;
+  const int t = threadIdx.x;
+  const bool active = t < NA;
+  const int cg = active ? t % VC : 0, pr = active ? t / VC : 0;
+  constexpr bool ZMASK = MODE == 2;
+  const bool use_bits = MODE == 0 && relu && mask != nullptr;
+  const bool from_x = MODE == 1 && relu;
+  const long pb = bx * pix_per_block;
+  const long pe = min(P, pb + pix_per_block);   // ONE chunk: pix_per_block == RP * ROWS (the launcher's contract)
+  RowSet<ROWS> rs;
+  rs.init(pb, pe, pr, RP, active);
+  uint4 gv[ROWS], xr[ROWS], zr[ZMASK ? ROWS : 1];
+  unsigned mk[MODE == 0 ? ROWS : 1];
+  rs.load(dz + pb * lddz + cg * 8, lddz, gv);
+  rs.load(x + pb * ldx + cg * 8, ldx, xr);
+  if constexpr (ZMASK) rs.load(z + pb * ldz + cg * 8, ldz, zr);
+  if constexpr (MODE == 0) { if (use_bits) load_sign_bytes<ROWS>(rs, mask + pb * VC + cg, VC, mk); }
+  // ---- phase 1: this workgroup's share of sum g and sum g xhat
+  {
+    float sg[8], sgx[8], ma[8], mb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sgx[j] = 0.f; ma[j] = 0.f; mb[j] = 0.f; }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ma[j] = mscale[cg * 8 + j]; mb[j] = mshift[cg * 8 + j]; }
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+      float g[8], xv[8];
+      unpack8(gv[u], g);
+      unpack8(xr[u], xv);
+      const float* pp = post ? post + (unsigned)((unsigned)(pb + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
+      bn_bwd_mask(g, xv, zr[ZMASK ? u : 0], ZMASK && relu, relu, from_x, ma, mb, pp, use_bits,
+                  (MODE == 0 && use_bits) ? mk[MODE == 0 ? u : 0] : 0u);
+      const bool keep = (rs.ok >> u) & 1u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gk = keep ? g[j] : 0.f;
+        sg[j] += gk;
+        sgx[j] += gk * xv[j];
+      }
+#ifndef SSA_EMU
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sgx[j] = (sgx[j] - mean[cg * 8 + j] * sg[j]) * invstd[cg * 8 + j];
+    block_reduce_2x8(sg, sgx, cg, C, active, sums, sh, bx, nrep);
+  }
+  // ---- rendezvous: every workgroup's atomics are performed before its ticket is; the last ticket releases everybody
+  // (no __threadfence(): an agent-scope release fence writes the XCD's whole L2 back, an acquire load invalidates it --
+  // ~100 us per launch with 930 workgroups doing both, call P.  Nothing here needs either: the sums only ever see atomics,
+  // which are performed at the coherence point, and the barrier below waits vmcnt(0) -- every atomic of this workgroup has
+  // been acknowledged before thread 0 takes the ticket; the polls and the phase-2 loads of the sums are relaxed
+  // agent-scope atomics, which bypass the caches; everything else phase 2 reads was written by earlier kernels)
+  __syncthreads();
+  if (t == 0) {
+    unsigned seen = atomicAdd(ticket, 1u) + 1u;
+    unsigned spins = 0;
+    while (seen < (unsigned)nblocks) {
+#ifndef SSA_EMU
+      __builtin_amdgcn_s_sleep(SSA_BN_SPIN_SLEEP);
+      seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+      seen = *ticket;
+#endif
+      if (++spins > (1u << 22)) { atomicAdd(&g_bn_fused_timeouts, 1u); break; }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: coefficients from the completed sums, then dx from the chunk still in registers
+  for (int c = t; c < C; c += NT) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < nrep; ++r) {
+      s1 += coherent_load(sums + (long)r * 2 * C + c);
+      s2 += coherent_load(sums + (long)r * 2 * C + C + c);
+    }
+    const float is_ = invstd[c], mu_ = mean[c];
+    const float a_ = (gamma ? gamma[c] : 1.f) * is_;
+    const float c1_ = (float)(s1 * inv_count);
+    const float c2_ = (float)(s2 * inv_count);
+    sh[c] = a_;
+    sh[C + c] = -a_ * c2_ * is_;
+    sh[2 * C + c] = a_ * (c2_ * is_ * mu_ - c1_);
+    sh[3 * C + c] = mscale ? mscale[c] : 0.f;
+    sh[4 * C + c] = mscale ? mshift[c] : 0.f;
+    if (bx == 0) {
+      if (accumulate_pg) {
+        if (dbeta) unsafeAtomicAdd(&dbeta[c], (float)(s1 * param_grad_scale));
+        if (dgamma) unsafeAtomicAdd(&dgamma[c], (float)(s2 * param_grad_scale));
+      } else {
+        if (dbeta) dbeta[c] = (float)(s1 * param_grad_scale);
+        if (dgamma) dgamma[c] = (float)(s2 * param_grad_scale);
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float A[8], Bx[8], D[8], ma[8], mb[8];
+  {
+    auto ld8 = [&](int row, float (&o)[8]) {
+      const float4 v0 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8), v1 = *reinterpret_cast<const float4*>(sh + row * C + cg * 8 + 4);
+      o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+    };
+    ld8(0, A); ld8(1, Bx); ld8(2, D);
+    if constexpr (MODE == 1) { ld8(3, ma); ld8(4, mb); }
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ma[j] = 0.f; mb[j] = 0.f; }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < ROWS; ++u) {
+    float g[8], xv[8];
+    unpack8(gv[u], g);
+    unpack8(xr[u], xv);
+    const float* pp = post ? post + (unsigned)((unsigned)(pb + rs.off[u]) / (unsigned)pix_per_img) * C + cg * 8 : nullptr;
+    bn_bwd_mask(g, xv, zr[ZMASK ? u : 0], ZMASK && relu, relu, from_x, ma, mb, pp, use_bits,
+                (MODE == 0 && use_bits) ? mk[MODE == 0 ? u : 0] : 0u);
+    const bool ok = (rs.ok >> u) & 1u;
+    if (dres && ok) *reinterpret_cast<uint4*>(dres + (pb + rs.off[u]) * lddres + cg * 8) = pack8(g);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + (Bx[j] * xv[j] + D[j]);
+    if (ok) *reinterpret_cast<uint4*>(dx + (pb + rs.off[u]) * lddx + cg * 8) = pack8(o);
+#ifndef SSA_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
+
 __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -620,6 +789,26 @@ struct BnBwdApplyKM {
 template <int ROWS> struct BnBwdApplyK : BnBwdApplyKM<ROWS, 0> {};
 template <int ROWS> struct BnBwdApplyXK : BnBwdApplyKM<ROWS, 1> {};
 template <int ROWS> struct BnBwdApplyZK : BnBwdApplyKM<ROWS, 2> {};
+
+template <int ROWS, int MODE>
+struct BnBwdFusedKM {
+  static constexpr int WPE = 4;                  // <= 128 registers: four workgroups per CU -- what the residency count assumes
+  struct Args { const bf16_t* x; const bf16_t* dz; const bf16_t* z; bf16_t* dx; bf16_t* dres;
+                const float* gamma; const float* mean; const float* invstd; double* sums;
+                const float* post; float* dgamma; float* dbeta; const float* mscale; const float* mshift;
+                const unsigned char* mask; unsigned* ticket; double inv_count; long P, pix_per_img, ppb;
+                int ldx, lddz, ldz, lddx, lddres, C, nrep, relu; float param_grad_scale; int accumulate_pg; };
+  static constexpr int NT = ::NT;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    bn_bwd_fused_body<ROWS, MODE>(a.x, a.ldx, a.dz, a.lddz, a.z, a.ldz, a.dx, a.lddx, a.dres, a.lddres, a.P, a.C,
+                                  a.gamma, a.mean, a.invstd, a.sums, a.nrep, a.inv_count, a.relu, a.post, a.pix_per_img,
+                                  a.ppb, a.dgamma, a.dbeta, a.param_grad_scale, a.mscale, a.mshift, a.accumulate_pg,
+                                  a.mask, a.ticket, bx, gx);
+  }
+};
+struct BnBwdFusedK : BnBwdFusedKM<4, 0> {};
+struct BnBwdFusedXK : BnBwdFusedKM<4, 1> {};
+struct BnBwdFusedZK : BnBwdFusedKM<4, 2> {};
 
 
 __global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
@@ -823,6 +1012,74 @@ int ssa_bn_bwd_apply(const void* x, int ldx, const void* dz, int lddz, const voi
   if (relu && !sign_mask) return SSA_BN_BWD_APPLY(BnBwdApplyZK);
   return SSA_BN_BWD_APPLY(BnBwdApplyK);
 #undef SSA_BN_BWD_APPLY
+}
+
+// One-launch backward (bn_bwd_fused_body).  ssa_bn_bwd_fused_blocks: the workgroups the problem takes (one 4-row chunk
+// each) -- the caller sums them over the bracket and uses this entry point only while the total stays within
+// ssa_bn_bwd_fused_capacity() (every workgroup of the launch resident at once); 0: not supported (emulation build,
+// odd shapes).  `ticket`: one zeroed 32-bit word per call.
+int ssa_bn_bwd_fused_blocks(long P, int C) {
+#ifdef SSA_EMU
+  return 0;                                      // workgroups run one after another on the host: no rendezvous
+#else
+  if (!ok_c(C) || !ok_p(P)) return 0;
+  const Grid g = plan_grid(P, C, 4);
+  const int VC = C >> 3;
+  if (g.ppb != (long)(active_threads(VC) / VC) * 4) return 0;      // more than one chunk per workgroup
+  return g.blocks;
+#endif
+}
+
+int ssa_bn_bwd_fused_capacity(void) {
+#ifdef SSA_EMU
+  return 0;
+#else
+  static int cap = -1;
+  if (cap < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 0;
+    cap = 4 * cus;                               // WPE = 4, 40 KB of LDS at most: four workgroups per CU
+  }
+  return cap;
+#endif
+}
+
+int ssa_bn_bwd_fused_timeouts(unsigned* out) {
+  if (!out) return SSA_EINVAL;
+#ifdef SSA_EMU
+  *out = g_bn_fused_timeouts;
+  return SSA_OK;
+#else
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bn_fused_timeouts), sizeof(unsigned));
+  return e == hipSuccess ? SSA_OK : (int)e;
+#endif
+}
+
+int ssa_bn_bwd_fused(const void* x, int ldx, const void* dz, int lddz, const void* z, int ldz,
+                     void* dx, int lddx, void* dres, int lddres, long P, int C, const float* gamma,
+                     const float* mean, const float* invstd, double* sums, int nrep,
+                     double count, int relu, const float* post, long pix_per_img, float* dgamma,
+                     float* dbeta, float param_grad_scale, const float* mask_scale,
+                     const float* mask_shift, int accumulate_param_grads, const void* sign_mask, void* ticket,
+                     void* stream) {
+  if (!x || !dz || !dx || !sums || !mean || !invstd || !ticket || !ok_c(C) || !ok_p(P) ||
+      (relu && !z && !mask_scale && !sign_mask) || nrep < 1 || (mask_scale && !mask_shift))
+    return SSA_EINVAL;
+  if (ldx % 8 || lddz % 8 || lddx % 8 || (z && ldz % 8) || (dres && lddres % 8)) return SSA_EINVAL;
+  if (ssa_bn_bwd_fused_blocks(P, C) <= 0) return SSA_EUNSUPPORTED;
+  const Grid g = plan_grid(P, C, 4);
+  const size_t lds_red = 16 * (NT + 1) * sizeof(float), lds_coef = 5 * (size_t)C * sizeof(float);
+  const size_t lds = lds_red > lds_coef ? lds_red : lds_coef;
+#define SSA_BN_BWD_FUSED(K)                                                                                               \
+  ssa::submit<K>(K::Args{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, (bf16_t*)dres, gamma, mean, invstd, \
+                         sums, post, dgamma, dbeta, mask_scale, mask_shift, (const unsigned char*)sign_mask,                  \
+                         (unsigned*)ticket, 1.0 / count, P, pix_per_img, g.ppb, ldx, lddz, ldz, lddx, lddres, C, nrep, relu,   \
+                         param_grad_scale, accumulate_param_grads}, g.blocks, 1, lds, (hipStream_t)stream)
+  if (relu && mask_scale) return SSA_BN_BWD_FUSED(BnBwdFusedXK);
+  if (relu && !sign_mask) return SSA_BN_BWD_FUSED(BnBwdFusedZK);
+  return SSA_BN_BWD_FUSED(BnBwdFusedK);
+#undef SSA_BN_BWD_FUSED
 }
 
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, void* stream) {

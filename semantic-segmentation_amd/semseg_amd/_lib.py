@@ -122,6 +122,11 @@ _SIGS = {
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
                           _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
+    "ssa_bn_bwd_fused_blocks": ([c_long, c_int], c_int),
+    "ssa_bn_bwd_fused_capacity": ([], c_int),
+    "ssa_bn_bwd_fused_timeouts": ([_P], c_int),
+    "ssa_bn_bwd_fused": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
+                          _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P, _P, _P], c_int),
     "ssa_sum_act": ([_P, _P, _P, _P, _P, c_long, c_int, _P], c_int),
     "ssa_relu_bwd": ([_P, _P, _P, c_long, _P], c_int),
     "ssa_nchw_f32_to_nhwc_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),

@@ -1195,6 +1195,34 @@ def _bn_train_fwd(xs, ldxs, metas, gammas, betas, ress, posts, masks=None):
     return zs, coefs, counts, worlds
 
 
+# OFF by default: measured (round 6, calls P / P2, tools/bnbench.py) 49 us for a 7.4 M-element level against 8.3 + 14.0 us
+# for the two launches -- the rendezvous of ~930 workgroups across 8 XCDs (one returning atomic per workgroup on one
+# address + the polls, all served at the memory-side coherence point) costs more than the second read of (x, dz, mask)
+# it saves, which comes from the 256 MB MALL anyway.  SSA_BN_FUSED_BWD=1 switches it on; the kernel and its test stay.
+_BN_FUSED_BWD = os.environ.get("SSA_BN_FUSED_BWD", "0") == "1"
+
+
+def _bn_bwd_fused_ids(todo):
+    """ids of the jobs of `todo` that take the one-launch backward: training-mode, no SyncBN exchange, one chunk per
+    workgroup, and all of them together within the chip's resident-workgroup capacity (the rendezvous inside the kernel
+    waits for every workgroup of a problem)."""
+    if not _BN_FUSED_BWD or not todo:
+        return set()
+    L = lib()
+    cap = L.ssa_bn_bwd_fused_capacity()
+    total, ids = 0, set()
+    for j in todo:
+        B, H, W, C = j["x"].shape
+        nb = L.ssa_bn_bwd_fused_blocks(B * H * W, C) if (j["training"] and not j["world"]) else 0
+        if nb <= 0:
+            continue
+        if total + nb > cap:
+            return set()            # (a bracket that does not fit stays on the two-launch form as a whole)
+        total += nb
+        ids.add(id(j))
+    return ids
+
+
 def _bn_bwd(jobs):
     """Backward of N BatchNorm(+ReLU/residual/mask) problems.  job: dict with x, ldx, dz, lddz, z,
     coef, g (gamma fp32 or None), gamma_param, beta_param, relu, pst, training, world, count,
@@ -1209,6 +1237,11 @@ def _bn_bwd(jobs):
         if j.get("sums") is None:
             j["sums"] = _ARENA.take(j["nrep"] * 2 * C, j["x"].device)
             todo.append(j)
+    # the jobs whose sums nobody has formed yet go through ONE launch (reduce, grid-wide rendezvous, apply: the chunk
+    # stays in registers, csrc/bn.hip bn_bwd_fused_body) when every workgroup of the bracket fits on the chip at once
+    # and no SyncBN exchange has to happen between the two halves
+    fused = _bn_bwd_fused_ids(todo)
+    todo = [j for j in todo if id(j) not in fused]
     if todo:
         with group():
             for j in todo:
@@ -1262,6 +1295,15 @@ def _bn_bwd(jobs):
             dx = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev)
             dres = torch.empty((B, H, W, C), dtype=ACT_DTYPE, device=dev) if j["has_res"] else None
             _note(0.0, 2.0 * P * C * (3 + (1 if dres is not None else 0)))
+            if id(j) in fused:
+                ticket = _ARENA.take(1, dev)
+                check(L.ssa_bn_bwd_fused(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, _p(dx), C, _p(dres), C, P, C,
+                                         _p(g), _p(coef[2]), _p(coef[3]), _p(use_sums), j["nrep"], j["count"], int(j["relu"]),
+                                         _p(j["pst"]), H * W, _p(pg_g) if fuse_pg else None, _p(pg_b) if fuse_pg else None,
+                                         pscale, _p(msc), _p(msh), accumulate if fuse_pg else 0, _p(j.get("mask")),
+                                         _p(ticket), _s()), "ssa_bn_bwd_fused")
+                out.append((dx, dres, ret_g, ret_b))
+                continue
             check(L.ssa_bn_bwd_apply(_p(x), j["ldx"], _p(j["dz"]), j["lddz"], _p(j["z"]), C, _p(dx), C, _p(dres), C, P, C,
                                      _p(g), _p(coef[2]), _p(coef[3]), _p(use_sums), j["nrep"], j["count"], int(j["relu"]),
                                      _p(j["pst"]), H * W, _p(pg_g) if fuse_pg else None, _p(pg_b) if fuse_pg else None,

@@ -571,6 +571,62 @@ def test_bn_train(C, relu, res, post):
         check_close("bn_dres", nchw(rd.grad.float()), rr.grad)
 
 
+@pytest.mark.parametrize("C,res,level", [(48, True, False), (96, False, False), (48, True, True)])
+def test_bn_bwd_fused_equals_two_launches(C, res, level):
+    """The one-launch BatchNorm backward (reduce, grid-wide rendezvous, apply: csrc/bn.hip bn_bwd_fused_body) against
+    the two-launch form on the same inputs: the sums are formed by the same per-workgroup partials in another order of
+    fp64 atomics, so everything agrees to fp32 rounding of the coefficients (1e-5 relative; the 16-bit outputs then differ
+    in at most the last bit); no workgroup may have timed out of the rendezvous.  `level`: several problems in one grouped
+    launch, each with its own ticket."""
+    import ctypes
+    hb = _hb()
+    if DEV != "cuda":
+        pytest.skip("the rendezvous needs concurrently resident workgroups: not on the CPU emulation")
+    shapes = [(1, 40, 56, C)] if not level else [(1, 64, 64, C), (1, 32, 32, 2 * C), (1, 16, 16, 4 * C)]
+
+    def run(fused_on):
+        prev = hb._BN_FUSED_BWD
+        hb._BN_FUSED_BWD = fused_on
+        try:
+            outs = []
+            xs, gs, bs, rs, zs = [], [], [], [], []
+            for k, (B, H, W, c) in enumerate(shapes):
+                x = _to_dev_nhwc(_rand(B, c, H, W, seed=10 + k) * 1.3 + 0.2).requires_grad_(True)
+                g = (torch.rand(c, generator=torch.Generator().manual_seed(20 + k)) + 0.5).to(DEV).requires_grad_(True)
+                b = (torch.randn(c, generator=torch.Generator().manual_seed(30 + k)) * 0.1).to(DEV).requires_grad_(True)
+                r = _to_dev_nhwc(_rand(B, c, H, W, seed=40 + k)).requires_grad_(True) if res else None
+                xs.append(x); gs.append(g); bs.append(b); rs.append(r)
+            for k, (B, H, W, c) in enumerate(shapes):
+                rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+                nbt = torch.zeros((), dtype=torch.long, device=DEV)
+                zs.append(hb.BatchNormActFn.apply(xs[k], gs[k], bs[k], rs[k], None, rm, rv, nbt, 0.1, 1e-5, True, True, False, None))
+            tot = sum((z.float() * nhwc(_rand(*[z.shape[0], z.shape[3], z.shape[1], z.shape[2]], seed=50 + k)).to(DEV)).sum()
+                      for k, z in enumerate(zs))
+            tot.backward()
+            torch.cuda.synchronize()
+            for k in range(len(shapes)):
+                outs.append((xs[k].grad.float().cpu(), gs[k].grad.cpu(), bs[k].grad.cpu(), rs[k].grad.float().cpu() if res else None))
+            return outs
+        finally:
+            hb._BN_FUSED_BWD = prev
+
+    L = hb.lib()
+    t0 = ctypes.c_uint(0)
+    assert L.ssa_bn_bwd_fused_timeouts(ctypes.byref(t0)) == 0
+    two = run(False)
+    one = run(True)
+    t1 = ctypes.c_uint(0)
+    assert L.ssa_bn_bwd_fused_timeouts(ctypes.byref(t1)) == 0
+    assert t1.value == t0.value, "workgroups timed out of the rendezvous: %d" % (t1.value - t0.value)
+    assert L.ssa_bn_bwd_fused_capacity() >= 256
+    for (dx2, dg2, db2, dr2), (dx1, dg1, db1, dr1) in zip(two, one):
+        check_close("fused dx", dx1, dx2, 1.6e-2, 1e-4)          # one 16-bit ulp
+        check_close("fused dgamma", dg1, dg2, 1e-5, 1e-5)
+        check_close("fused dbeta", db1, db2, 1e-5, 1e-5)
+        if res:
+            assert torch.equal(dr1, dr2)
+
+
 def test_bn_deferred_running_stats_two_passes():
     """Two training passes over one BatchNorm layer (the 0.5x and the 1.0x pass, problems of one
     grouped launch): the deferred batched update must equal the reference's sequential in-place

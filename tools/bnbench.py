@@ -67,7 +67,20 @@ class Prob:
                                     hb._s()), "bapply")
 
 
-def timeit(fn, reps):
+    def fused(self, from_x, dres, ticket):
+        """reduce + rendezvous + apply in one launch (csrc/bn.hip bn_bwd_fused_body); ticket: a zeroed 32-bit word"""
+        msc, msh = (self.coef[0], self.coef[1]) if from_x else (None, None)
+        hb.check(L.ssa_bn_bwd_fused(P(self.x), self.C, P(self.dz), self.C, None if from_x else P(self.z), self.C, P(self.dx), self.C,
+                                    P(self.dres) if dres else None, self.C, self.P, self.C, P(self.gamma), P(self.coef[2]),
+                                    P(self.coef[3]), P(self.bsums), self.nrep, float(self.P), 1, None, self.P, P(self.pg[0]),
+                                    P(self.pg[1]), 1.0, P(msc), P(msh), 1, P(self.mask) if (self.use_mask and not from_x) else None,
+                                    ctypes.c_void_p(ticket), hb._s()), "fused")
+
+
+TICKETS = None      # one zeroed word per fused call of a captured graph, cleared by a memset node at the graph's start
+
+
+def timeit(fn, reps, pre=None):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -76,6 +89,8 @@ def timeit(fn, reps):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         with torch.cuda.graph(g):
+            if pre is not None:
+                pre()
             for _ in range(reps):
                 fn()
     torch.cuda.synchronize()
@@ -110,6 +125,29 @@ def main():
                           ("bwd apply (bn1: x mask)", lambda p: p.bapply(True, False), 6)):
         t = timeit(lv(fn), reps)
         print("  %-32s %7.2f us   %5.2f TB/s algorithmic (%d B/element)" % (name, t, elems * bpe / t / 1e6, bpe))
+    # the one-launch backward: every call its own ticket word (8 problems x reps + warm-up calls), cleared per replay
+    tickets = torch.zeros(8 * (reps + 8) * 8, dtype=torch.int32, device=DEV)
+    state = {"i": 0}
+
+    def fused_level(from_x, dres):
+        def run():
+            with hb.group():
+                for p in probs:
+                    p.fused(from_x, dres, tickets.data_ptr() + 4 * state["i"])
+                    state["i"] += 1
+        return run
+
+    def pre():
+        state["i"] = 0
+        tickets.zero_()
+    for name, fn, bpe in (("bwd fused (bn2: z mask, dres)", fused_level(False, True), 10), ("bwd fused (bn1: x mask)", fused_level(True, False), 6)):
+        pre()
+        torch.cuda.synchronize()
+        t = timeit(fn, reps, pre)
+        print("  %-32s %7.2f us   %5.2f TB/s algorithmic (%d B/element; the two launches it replaces read 6 / 4 more)" % (name, t, elems * bpe / t / 1e6, bpe))
+    to = ctypes.c_uint(0)
+    L.ssa_bn_bwd_fused_timeouts(ctypes.byref(to))
+    print("  rendezvous timeouts: %d" % to.value)
     p0 = probs[0]
     for name, fn in (("apply 48@256^2 alone", lambda: p0.apply(True)), ("bwd apply 48@256^2 alone", lambda: p0.bapply(False, True))):
         print("  %-32s %7.2f us" % (name, timeit(fn, reps)))

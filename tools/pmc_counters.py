@@ -38,7 +38,7 @@ def family(i):
     if f in ("ConvTileAny", "ConvTilePAny", "ConvTilePK", "ConvTileP"):
         return "ConvTile"
     return {"ConvHaloGemm3": "ConvHaloGemm", "ConvHaloReg3": "ConvHaloGemm", "ConvHaloGemm1": "ConvHaloGemm", "ConvWgradHead3": "ConvWgradHead",
-            "ConvGemmWide1": "ConvGemmWide", "ConvWgradTileA": "ConvWgradTile", "BnBwdApplyXK": "BnBwdApplyK",
+            "ConvGemmWide1": "ConvGemmWide", "ConvWgradTileA": "ConvWgradTile", "BnBwdApplyXK": "BnBwdApplyK", "BnBwdFusedXK": "BnBwdFusedK", "BnBwdFusedZK": "BnBwdFusedK",
             "BnBwdApplyZK": "BnBwdApplyK", "BnBwdReduceXK": "BnBwdReduceK", "BnBwdReduceZK": "BnBwdReduceK"}.get(f, f)
 
 
