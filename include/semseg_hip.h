@@ -393,6 +393,22 @@ int ssa_bn_bwd_fused(const void* x, int ldx, const void* dz, int lddz, const voi
 int ssa_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta,
                        void* stream);
 
+/* ------------------------------------------------- SyncBN exchange, peer to peer ----
+ * One-shot all-reduce (SUM, fp64, in place) of the SyncBN partial sums over peer-mapped device memory -- what
+ * apex.parallel.SyncBatchNorm's all-reduce is in the reference (config.py:216-222, network/__init__.py:37-39) and
+ * ncclAllReduce is on this path by default.  Every rank writes its n values into its slot of every peer's exchange
+ * buffer, publishes a sequence number (system-scope release), waits for all peers' numbers in its own buffer and sums
+ * the slots in rank order: one single-workgroup kernel on `stream`, capturable (the sequence number lives in *seq_dev and
+ * is advanced by the kernel).  peers_dev: device array of `world` base addresses -- every rank's buffer as mapped into
+ * THIS process (hipIpcOpenMemHandle; the rank's own allocation at [rank]); each buffer *bytes of ssa_p2p_buffer_bytes(world,
+ * slot_doubles, &bytes) of zeroed fine-grained device memory.  n <= slot_doubles, else SSA_EUNSUPPORTED (the caller keeps
+ * the collective library for those).  ssa_p2p_timeouts: ranks that gave up waiting (~2 s) -- 0 unless a peer died.
+ * Host side: semseg_amd/p2p.py (opt-in, SSA_SYNCBN_P2P=1).                                                        */
+int ssa_p2p_buffer_bytes(int world, long slot_doubles, size_t* bytes);
+int ssa_p2p_allreduce_f64(double* data, long n, void* const* peers_dev, int rank, int world,
+                          unsigned long long* seq_dev, long slot_doubles, void* stream);
+int ssa_p2p_timeouts(unsigned* out);
+
 /* ----------------------------------------------------------- elementwise ---- */
 /* z = relu?(a + b + c + d); b,c,d optional.  HRNet fuse sum,
  * network/hrnetv2.py:236-252 (K12). All bf16, dense [n] with n % 8 == 0.      */

@@ -122,6 +122,9 @@ _SIGS = {
     "ssa_bn_bwd_apply": ([_P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_long, c_int,
                           _P, _P, _P, _P, c_int, c_double, c_int, _P, c_long, _P, _P, c_float, _P, _P, c_int, _P, _P], c_int),
     "ssa_bn_param_grads": ([_P, c_int, _P, _P, _P], c_int),
+    "ssa_p2p_buffer_bytes": ([c_int, c_long, POINTER(c_size_t)], c_int),
+    "ssa_p2p_allreduce_f64": ([_P, c_long, _P, c_int, c_int, _P, c_long, _P], c_int),
+    "ssa_p2p_timeouts": ([_P], c_int),
     "ssa_bn_bwd_fused_blocks": ([c_long, c_int], c_int),
     "ssa_bn_bwd_fused_capacity": ([], c_int),
     "ssa_bn_bwd_fused_timeouts": ([_P], c_int),

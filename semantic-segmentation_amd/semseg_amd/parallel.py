@@ -46,8 +46,10 @@ def sync_world(enabled=True, group=None):
 
 
 def _all_reduce_(t, average=False, group=None, comm_index=0):
-    from . import rccl
-    if rccl.usable(t, group):
+    from . import rccl, p2p
+    if not average and p2p.usable(t, group):
+        p2p.exchange(group).all_reduce_sum_(t)             # SSA_SYNCBN_P2P=1: one kernel over peer-mapped buffers
+    elif rccl.usable(t, group):
         rccl.comm(comm_index).all_reduce_(t, average)      # one RCCL call on the current stream
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
