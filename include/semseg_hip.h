@@ -408,6 +408,14 @@ int ssa_p2p_buffer_bytes(int world, long slot_doubles, size_t* bytes);
 int ssa_p2p_allreduce_f64(double* data, long n, void* const* peers_dev, int rank, int world,
                           unsigned long long* seq_dev, long slot_doubles, void* stream);
 int ssa_p2p_timeouts(unsigned* out);
+/* Exchange buffers without hipIpc: *ptr = `bytes` (rounded up to the allocation granularity -> *mapped_bytes) of zeroed
+ * uncached device memory on the current device, created through the virtual-memory API and exported as the POSIX file
+ * descriptor *fd (the caller hands it to the peers over a unix socket, SCM_RIGHTS, and closes it).  A peer maps the
+ * allocation with ssa_p2p_vmm_import(fd, mapped_bytes, &ptr) on ITS current device.  Needs no ptrace rights, which
+ * hipIpcOpenMemHandle in dmabuf mode (pidfd_getfd) does.  SSA_EUNSUPPORTED when the runtime refuses every variant.   */
+int ssa_p2p_vmm_alloc(size_t bytes, void** ptr, int* fd, size_t* mapped_bytes);
+int ssa_p2p_vmm_import(int fd, size_t mapped_bytes, void** ptr);
+int ssa_p2p_vmm_unmap(void* ptr, size_t mapped_bytes);
 
 /* ----------------------------------------------------------- elementwise ---- */
 /* z = relu?(a + b + c + d); b,c,d optional.  HRNet fuse sum,

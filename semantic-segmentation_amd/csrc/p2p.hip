@@ -8,7 +8,9 @@
 // behind it, waits until all peers' sequence numbers have arrived in its own buffer and sums the slots locally:
 //   * one kernel, ONE workgroup (no grid-wide dependency: it can always become resident), no communicator, no proxy
 //     thread -- a plain kernel node in the captured hipGraph of the step;
-//   * exchange buffer per rank (fine-grained device memory, opened by every peer through hipIpc):
+//   * exchange buffer per rank (uncached / fine-grained device memory; mapped by every peer from a POSIX file descriptor
+//     of the allocation -- ssa_p2p_vmm_* below, HIP's virtual-memory API, the route that needs no ptrace rights -- or
+//     opened through hipIpc where that is permitted):
 //       [2 parities][world slots][slot_doubles]  +  flags [2 parities][world] (one 64-byte line each);
 //   * the sequence number lives in device memory and is advanced by the kernel itself, so a replayed graph counts on;
 //     collective k uses parity k & 1: a rank can only start collective k + 2 after every peer has published k + 1, i.e.
@@ -20,6 +22,9 @@
 // tests detect, never a hung GPU.  The host side (semseg_amd/p2p.py) falls back to RCCL when the buffers cannot be
 // mapped or a message exceeds a slot.
 #include "common.h"
+#include <unistd.h>
+#include <cstring>
+#include <cstdint>
 #include "../../include/semseg_hip.h"
 
 namespace {
@@ -104,6 +109,113 @@ int ssa_p2p_allreduce_f64(double* data, long n, void* const* peers_dev, int rank
   hipLaunchKernelGGL(p2p_allreduce_f64_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
+#endif
+}
+
+// ---- exchange buffers through the virtual-memory API: hipMemCreate(uncached, exportable as a POSIX fd) on the owner,
+// hipMemImportFromShareableHandle + reserve + map + set-access on every peer.  The fd travels over a unix socket
+// (SCM_RIGHTS, semseg_amd/p2p.py): unlike hipIpcOpenMemHandle in dmabuf mode (pidfd_getfd) this needs neither
+// CAP_SYS_PTRACE nor a relaxed seccomp profile.
+#ifndef SSA_EMU
+namespace {
+int vmm_prop(hipMemAllocationProp* prop, int uncached) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  memset(prop, 0, sizeof(*prop));
+  prop->type = uncached ? hipMemAllocationTypeUncached : hipMemAllocationTypePinned;
+  prop->requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+  prop->location.type = hipMemLocationTypeDevice;
+  prop->location.id = dev;
+  return 0;
+}
+int vmm_map(hipMemGenericAllocationHandle_t h, size_t bytes, size_t gran, void** ptr) {
+  void* p = nullptr;
+  hipError_t e = hipMemAddressReserve(&p, bytes, gran, nullptr, 0);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemMap(p, bytes, 0, h, 0);
+  if (e != hipSuccess) { hipMemAddressFree(p, bytes); return (int)e; }
+  int dev = 0;
+  hipGetDevice(&dev);
+  hipMemAccessDesc acc;
+  memset(&acc, 0, sizeof(acc));
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(p, bytes, &acc, 1);
+  if (e != hipSuccess) { hipMemUnmap(p, bytes); hipMemAddressFree(p, bytes); return (int)e; }
+  *ptr = p;
+  return 0;
+}
+}  // namespace
+#endif
+
+int ssa_p2p_vmm_alloc(size_t bytes, void** ptr, int* fd, size_t* mapped_bytes) {
+  if (!bytes || !ptr || !fd || !mapped_bytes) return SSA_EINVAL;
+#ifdef SSA_EMU
+  return SSA_EUNSUPPORTED;
+#else
+  for (int uncached = 1; uncached >= 0; --uncached) {      // uncached = fine-grained; plain pinned if the type is refused
+    hipMemAllocationProp prop;
+    int rc = vmm_prop(&prop, uncached);
+    if (rc) return rc;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) continue;
+    const size_t nb = (bytes + gran - 1) / gran * gran;
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, nb, &prop, 0) != hipSuccess) continue;
+    int out_fd = -1;
+    if (hipMemExportToShareableHandle(&out_fd, h, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess || out_fd < 0) {
+      hipMemRelease(h);
+      continue;
+    }
+    void* p = nullptr;
+    rc = vmm_map(h, nb, gran, &p);
+    hipMemRelease(h);                    // the mapping (and the exported descriptor) keep the memory alive
+    if (rc) { close(out_fd); continue; }
+    if (hipMemset(p, 0, nb) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      hipMemUnmap(p, nb); hipMemAddressFree(p, nb); close(out_fd);
+      continue;
+    }
+    *ptr = p; *fd = out_fd; *mapped_bytes = nb;
+    return SSA_OK;
+  }
+  (void)hipGetLastError();
+  return SSA_EUNSUPPORTED;
+#endif
+}
+
+int ssa_p2p_vmm_import(int fd, size_t mapped_bytes, void** ptr) {
+  if (fd < 0 || !mapped_bytes || !ptr) return SSA_EINVAL;
+#ifdef SSA_EMU
+  return SSA_EUNSUPPORTED;
+#else
+  int version = 0;
+  hipRuntimeGetVersion(&version);
+  hipMemGenericAllocationHandle_t h;
+  // HIP < 7.1 reads the descriptor THROUGH the pointer, later runtimes take it by value (as the CUDA driver API does)
+  void* os_handle = version >= 70100000 ? reinterpret_cast<void*>(static_cast<uintptr_t>(fd)) : static_cast<void*>(&fd);
+  hipError_t e = hipMemImportFromShareableHandle(&h, os_handle, hipMemHandleTypePosixFileDescriptor);
+  if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+  hipMemAllocationProp prop;
+  vmm_prop(&prop, 1);
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) gran = 2u << 20;
+  int rc = vmm_map(h, mapped_bytes, gran, ptr);
+  hipMemRelease(h);
+  if (rc) (void)hipGetLastError();
+  return rc;
+#endif
+}
+
+int ssa_p2p_vmm_unmap(void* ptr, size_t mapped_bytes) {
+  if (!ptr || !mapped_bytes) return SSA_EINVAL;
+#ifdef SSA_EMU
+  return SSA_EUNSUPPORTED;
+#else
+  hipError_t e = hipMemUnmap(ptr, mapped_bytes);
+  hipError_t f = hipMemAddressFree(ptr, mapped_bytes);
+  return e != hipSuccess ? (int)e : (f != hipSuccess ? (int)f : SSA_OK);
 #endif
 }
 

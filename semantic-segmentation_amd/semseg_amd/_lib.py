@@ -125,6 +125,9 @@ _SIGS = {
     "ssa_p2p_buffer_bytes": ([c_int, c_long, POINTER(c_size_t)], c_int),
     "ssa_p2p_allreduce_f64": ([_P, c_long, _P, c_int, c_int, _P, c_long, _P], c_int),
     "ssa_p2p_timeouts": ([_P], c_int),
+    "ssa_p2p_vmm_alloc": ([c_size_t, POINTER(c_void_p), POINTER(c_int), POINTER(c_size_t)], c_int),
+    "ssa_p2p_vmm_import": ([c_int, c_size_t, POINTER(c_void_p)], c_int),
+    "ssa_p2p_vmm_unmap": ([_P, c_size_t], c_int),
     "ssa_bn_bwd_fused_blocks": ([c_long, c_int], c_int),
     "ssa_bn_bwd_fused_capacity": ([], c_int),
     "ssa_bn_bwd_fused_timeouts": ([_P], c_int),

@@ -7,11 +7,13 @@ its partial sums straight into every peer's exchange buffer over xGMI, publishes
 locally (csrc/p2p.hip: one single-workgroup kernel, a plain node of the captured step -- no communicator inside the
 graph for SyncBN at all).
 
-Set-up (once per process group): a fine-grained device buffer per rank, its hipIpc handle gathered over the existing
-torch.distributed group, every peer's buffer opened with hipIpcOpenMemHandle (works for two processes on ONE GPU as
-well -- which is how the GPU test exercises the kernel, the flags and the parity protocol; what one GPU cannot show is
-cross-GPU visibility over xGMI, which rests on the system-scope atomics of the kernel and the fine-grained allocation).
-Any failure on the way -- no fine-grained memory, a handle that does not open, a message larger than a slot -- leaves
+Set-up (once per process group): an uncached (fine-grained) device buffer per rank, mapped into every peer -- by a
+POSIX file descriptor of the allocation sent over a unix socket (HIP's virtual-memory API), or by a hipIpc handle
+gathered over the existing torch.distributed group where the container lets hipIpcOpenMemHandle work.  Both work for
+two processes on ONE GPU as well -- which is how the GPU test exercises the kernel, the flags and the parity protocol
+across address spaces; what one GPU cannot show is cross-GPU visibility over xGMI, which rests on the system-scope
+atomics of the kernel and the uncached allocation.
+Any failure on the way -- no exportable memory, a handle that does not open, a message larger than a slot -- leaves
 the exchange with RCCL / torch.distributed (`usable()` is False and parallel._all_reduce_ goes on as before)."""
 import ctypes
 import os
@@ -43,7 +45,16 @@ def _hip():
 
 
 class P2PExchange:
-    """Exchange buffers of one process group, mapped into this process."""
+    """Exchange buffers of one process group, mapped into this process.
+
+    Two ways to get a peer's buffer into this address space, tried in this order (every rank takes the same one: the
+    outcome of each attempt is all-gathered):
+      "fd"   the virtual-memory API: the owner creates the allocation exportable as a POSIX file descriptor
+             (ssa_p2p_vmm_alloc), the descriptor travels over an abstract unix socket (SCM_RIGHTS), the peer maps it
+             (ssa_p2p_vmm_import).  Needs no special rights;
+      "ipc"  hipIpcGetMemHandle / hipIpcOpenMemHandle on a fine-grained allocation.  In dmabuf mode the runtime fetches
+             the exporter's descriptor with pidfd_getfd, which an unprivileged container refuses (seccomp / no
+             CAP_SYS_PTRACE: `invalid device pointer`, measured on the round's GPU boxes, profiles/r06_notes.md)."""
 
     def __init__(self, group=None, slot_doubles=SLOT_DOUBLES):
         from ._lib import lib
@@ -56,24 +67,114 @@ class P2PExchange:
         self.device = torch.cuda.current_device()
         nb = ctypes.c_size_t(0)
         self.lib.ssa_p2p_buffer_bytes(self.world, self.slot, ctypes.byref(nb))
-        nbytes = nb.value
+        self.nbytes = nb.value
         self.mine = ctypes.c_void_p()
-        ok = self.hip.hipExtMallocWithFlags(ctypes.byref(self.mine), nbytes, _HIP_MALLOC_FINEGRAINED) == 0
+        self.mine_mapped = 0            # > 0: `mine` is a virtual-memory mapping of that many bytes
+        self.opened = []                # hipIpc mappings of peers
+        self.mapped = []                # (ptr, bytes) virtual-memory mappings of peers
+        self.route = None
+        errors = []
+        for route in os.environ.get("SSA_SYNCBN_P2P_ROUTE", "fd,ipc").split(","):
+            try:
+                ptrs = self._setup_fd() if route == "fd" else self._setup_ipc()
+                self.route = route
+                break
+            except RuntimeError as e:       # raised on EVERY rank together (see _agree)
+                errors.append("%s: %s" % (route, e))
+                self._free()
+        if self.route is None:
+            raise RuntimeError("; ".join(errors))
+        self.peers = torch.tensor(ptrs, dtype=torch.int64, device="cuda")
+        self.seq = torch.zeros(1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        dist.barrier(group=group)       # nobody writes a peer before every peer has cleared and mapped its buffer
+
+    def _agree(self, ok, what):
+        """All ranks learn whether all ranks succeeded; raises on every rank if one did not."""
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok), group=self.group)
+        if not all(flags):
+            raise RuntimeError("%s failed on rank(s) %s" % (what, [r for r, f in enumerate(flags) if not f]))
+
+    # ---- route "fd"
+    def _setup_fd(self):
+        import socket
+        import threading
+        fd, mapped = ctypes.c_int(-1), ctypes.c_size_t(0)
+        ok = self.lib.ssa_p2p_vmm_alloc(self.nbytes, ctypes.byref(self.mine), ctypes.byref(fd), ctypes.byref(mapped)) == 0
+        self.mine_mapped = mapped.value if ok else 0
+        token = [os.urandom(8).hex()]
+        dist.broadcast_object_list(token, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        name = lambda r: "\0ssa_p2p_%s_%d" % (token[0], r)           # abstract namespace: nothing to unlink
+        srv = None
+        if ok:
+            try:
+                srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                srv.bind(name(self.rank))
+                srv.listen(self.world)
+                srv.settimeout(60)
+            except OSError:
+                ok = False
+        try:
+            self._agree(ok, "exportable device allocation (hipMemCreate / hipMemExportToShareableHandle)")
+            sizes = [None] * self.world
+            dist.all_gather_object(sizes, self.mine_mapped, group=self.group)
+
+            def serve():
+                for _ in range(self.world - 1):
+                    try:
+                        c, _a = srv.accept()
+                    except OSError:
+                        return
+                    with c:
+                        socket.send_fds(c, [b"f"], [fd.value])
+
+            th = threading.Thread(target=serve, daemon=True)
+            th.start()
+            ptrs, failed = [], False
+            for r in range(self.world):
+                if r == self.rank:
+                    ptrs.append(self.mine.value)
+                    continue
+                p = ctypes.c_void_p()
+                try:
+                    with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as c:
+                        c.settimeout(60)
+                        c.connect(name(r))
+                        _m, fds, _f, _ad = socket.recv_fds(c, 1, 1)
+                    rc = self.lib.ssa_p2p_vmm_import(fds[0], sizes[r], ctypes.byref(p))
+                    os.close(fds[0])
+                    if rc != 0 or not p.value:
+                        raise OSError("ssa_p2p_vmm_import: %d" % rc)
+                    self.mapped.append((p, sizes[r]))
+                    ptrs.append(p.value)
+                except (OSError, IndexError):
+                    failed = True
+                    ptrs.append(0)
+            th.join(90)
+            self._agree(not failed, "mapping a peer's allocation (hipMemImportFromShareableHandle / hipMemMap)")
+            return ptrs
+        finally:
+            if srv is not None:
+                srv.close()
+            if fd.value >= 0:
+                os.close(fd.value)
+
+    # ---- route "ipc"
+    def _setup_ipc(self):
+        ok = self.hip.hipExtMallocWithFlags(ctypes.byref(self.mine), self.nbytes, _HIP_MALLOC_FINEGRAINED) == 0
         handle = _IpcHandle()
         if ok:
-            ok = self.hip.hipMemset(self.mine, 0, nbytes) == 0 and self.hip.hipDeviceSynchronize() == 0
+            ok = self.hip.hipMemset(self.mine, 0, self.nbytes) == 0 and self.hip.hipDeviceSynchronize() == 0
         if ok:
             ok = self.hip.hipIpcGetMemHandle(ctypes.byref(handle), self.mine) == 0
-        # every rank learns whether every rank got this far (a collective: all ranks take the same branch)
         infos = [None] * self.world
-        dist.all_gather_object(infos, (bool(ok), bytes(handle.reserved) if ok else b"", os.getpid()), group=group)
+        dist.all_gather_object(infos, (bool(ok), bytes(handle.reserved) if ok else b""), group=self.group)
         if not all(i[0] for i in infos):
-            self._free()
-            raise RuntimeError("peer-mapped exchange buffers unavailable on rank(s) %s" % [r for r, i in enumerate(infos) if not i[0]])
-        self.opened = []
-        ptrs = []
-        failed = False
-        for r, (_, raw, pid) in enumerate(infos):
+            raise RuntimeError("fine-grained allocation / hipIpcGetMemHandle failed on rank(s) %s"
+                               % [r for r, i in enumerate(infos) if not i[0]])
+        ptrs, failed = [], False
+        for r, (_, raw) in enumerate(infos):
             if r == self.rank:
                 ptrs.append(self.mine.value)
                 continue
@@ -86,23 +187,23 @@ class P2PExchange:
             else:
                 self.opened.append(p)
                 ptrs.append(p.value)
-        flags = [None] * self.world
-        dist.all_gather_object(flags, not failed, group=group)
-        if not all(flags):
-            self._free()
-            raise RuntimeError("hipIpcOpenMemHandle failed on rank(s) %s" % [r for r, f in enumerate(flags) if not f])
-        self.peers = torch.tensor(ptrs, dtype=torch.int64, device="cuda")
-        self.seq = torch.zeros(1, dtype=torch.int64, device="cuda")
-        torch.cuda.synchronize()
-        dist.barrier(group=group)       # nobody writes a peer before every peer has cleared and mapped its buffer
+        self._agree(not failed, "hipIpcOpenMemHandle")
+        return ptrs
 
     def _free(self):
-        for p in getattr(self, "opened", []):
+        for p in self.opened:
             self.hip.hipIpcCloseMemHandle(p)
         self.opened = []
+        for p, n in self.mapped:
+            self.lib.ssa_p2p_vmm_unmap(p, n)
+        self.mapped = []
         if self.mine:
-            self.hip.hipFree(self.mine)
+            if self.mine_mapped:
+                self.lib.ssa_p2p_vmm_unmap(self.mine, self.mine_mapped)
+            else:
+                self.hip.hipFree(self.mine)
             self.mine = ctypes.c_void_p()
+            self.mine_mapped = 0
 
     def fits(self, t):
         return t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and 0 < t.numel() <= self.slot
