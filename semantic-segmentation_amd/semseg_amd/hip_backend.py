@@ -742,6 +742,7 @@ _WGRAD_STRIP = int(os.environ.get("SSA_WGRAD_STRIP", "8"))       # 128-pixel sta
 # what gives the side stream something to run.  Measured (profiles/r03_notes.md, call S): stream off 23.30 ms; on with a
 # flush every 16 / 32 / 64 / 128 / 256 layers / at the end only = 23.93 / 23.39 / 23.11 / 22.94 / 22.75 / 23.32 ms.
 _WGRAD_SIDE = os.environ.get("SSA_WGRAD_STREAM", "1") != "0"
+_BIAS_SIDE = os.environ.get("SSA_BIAS_GRAD_STREAM", "1") != "0"      # conv bias gradients there too (_bias_grad)
 _WGRAD_FLUSH_AT = int(os.environ.get("SSA_WGRAD_FLUSH_AT", "256" if _WGRAD_SIDE else "100000"))
 # (Measured and removed, profiles/r03_notes.md calls Y, Z: a decaying flush interval and an early first flush.)
 # ... with a gradient sink installed (data parallel): flush every so many queued layers and exchange the completed arena
@@ -893,6 +894,47 @@ def _on_wgrad_stream():
         yield
 
 
+# A second forward stream for sub-graphs off the critical path (ops.fork): the upsampling half of an HRNet fuse level
+# (1x1 convs -> BatchNorm -> bilinear, ~35 us of 10-20 us launches) next to the chain of stride-2 convs (~110 us) it is
+# summed with.  autograd runs a node's backward on the stream of its forward, so the backward halves (bilinear backward
+# -> BatchNorm backward -> 1x1 data gradient, ~55 us per level) run in parallel too, with the engine's own cross-stream
+# waits.  Off when BatchNorm statistics are exchanged between ranks: the collectives of one communicator would then be
+# issued from two streams.
+_FORK = {"stream": None}
+_FORK_ON = os.environ.get("SSA_FUSE_STREAM", "1") != "0"
+
+
+def _tensors_of(out):
+    if torch.is_tensor(out):
+        yield out
+    elif isinstance(out, (list, tuple)):
+        for o in out:
+            yield from _tensors_of(o)
+
+
+def fork(thunk):
+    import torch.distributed as dist
+    if not _FORK_ON or not torch.cuda.is_available() or (dist.is_available() and dist.is_initialized()):
+        out = thunk()
+        return lambda: out
+    main = torch.cuda.current_stream()
+    if _FORK["stream"] is None:
+        _FORK["stream"] = torch.cuda.Stream()
+    side = _FORK["stream"]
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = thunk()
+
+    def join():
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(side)
+        for t in _tensors_of(out):
+            if t.is_cuda:
+                t.record_stream(cur)
+        return out
+    return join
+
+
 def join_wgrads():
     """The current stream waits for the weight gradients issued so far."""
     if _SIDE["pending"]:
@@ -961,12 +1003,27 @@ def _grad_as_bf16(dy, Cout):
     return out, cout_pad, cout_pad
 
 
-def _bias_grad(dyb, lddy, cout_pad, Cout):
+def _bias_grad(dyb, lddy, cout_pad, Cout, bias=None):
+    """db[Cout] = column sums of the incoming gradient.  bias = an nn.Parameter: like a weight gradient nothing in
+    backward waits for it -- computed on the weight-gradient stream, added into the parameter's gradient-arena slice,
+    returns None (three dependent launches of ~50 us per head conv and scale pass leave the critical path)."""
     B, Ho, Wo, _ = dyb.shape
-    out = torch.empty((cout_pad,), dtype=torch.float32, device=dyb.device)
-    scratch = torch.empty((2 * cout_pad,), dtype=torch.float64, device=dyb.device)
-    check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()), "ssa_colsum_bf16")
-    return out[:Cout]
+
+    def run():
+        out = torch.empty((cout_pad,), dtype=torch.float32, device=dyb.device)
+        scratch = torch.empty((2 * cout_pad,), dtype=torch.float64, device=dyb.device)
+        check(lib().ssa_colsum_bf16(_p(dyb), B * Ho * Wo, cout_pad, lddy, _p(out), _p(scratch), _s()), "ssa_colsum_bf16")
+        return out[:Cout]
+    if bias is None or not (_is_param(bias) and _WGRAD_SIDE and _BIAS_SIDE and dyb.is_cuda):
+        return run()
+    slot = _GRADS.slot(bias)
+    side = _side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        slot.add_(run())
+    dyb.record_stream(side)
+    _SIDE["pending"] = True
+    return None
 
 
 class ConvGroupFn(torch.autograd.Function):
@@ -995,7 +1052,7 @@ class ConvGroupFn(torch.autograd.Function):
                 stride, pad, dil, out_f32, want_stats = spec[i]
                 y, _ = _conv_fwd(xs[i], lds[i], ws[i], bs[i], stride, pad, dil, out_f32, want_stats)
                 ys.append(y)
-        ctx.save_for_backward(*(xs + ws))
+        ctx.save_for_backward(*(xs + ws + [tensors[3 * i + 2] for i in range(n) if bs[i] is not None]))
         ctx.meta = (spec, lds, [b is not None for b in bs], [tuple(y.shape[1:3]) for y in ys])
         return tuple(ys)
 
@@ -1003,7 +1060,8 @@ class ConvGroupFn(torch.autograd.Function):
     def backward(ctx, *dys):
         spec, lds, has_bias, out_hw = ctx.meta
         n = len(spec)
-        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:2 * n]
+        bias_of = dict(zip([i for i in range(n) if has_bias[i]], ctx.saved_tensors[2 * n:]))
         prep = [None] * n
         for i in range(n):
             if dys[i] is not None:
@@ -1030,7 +1088,7 @@ class ConvGroupFn(torch.autograd.Function):
                     if dw is not None and dw.dtype != w.dtype:
                         dw = dw.to(w.dtype)
                 if has_bias[i] and ctx.needs_input_grad[3 + 3 * i]:
-                    db = _bias_grad(dyb, lddy, cout_pad, Cout)
+                    db = _bias_grad(dyb, lddy, cout_pad, Cout, bias_of[i])
             grads += [dxs[i], dw, db]
         return tuple(grads)
 

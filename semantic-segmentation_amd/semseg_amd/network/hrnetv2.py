@@ -170,11 +170,14 @@ class HighResolutionModule(nn.Module):
         use = {(i, p): handles[k] for k, (i, p) in enumerate(jobs)}       # use[(j, p)][i]: row i's handle
         term = {}
         up = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j > i for p in range(P)]
+        join_up = None
         if up:
-            ts = conv_bn([rows[i][j][0] for i, j, p in up], [rows[i][j][1] for i, j, p in up],
-                         [use[(j, p)][i] for i, j, p in up])
-            ts = B.bilinear(ts, [tuple(ys[i][p].shape[1:3]) for i, j, p in up])
-            term.update(zip(up, ts))
+            # nothing below needs the upsampled terms before the final sum: a parallel branch (ops.fork)
+            def up_branch():
+                ts = conv_bn([rows[i][j][0] for i, j, p in up], [rows[i][j][1] for i, j, p in up],
+                             [use[(j, p)][i] for i, j, p in up])
+                return B.bilinear(ts, [tuple(ys[i][p].shape[1:3]) for i, j, p in up])
+            join_up = B.fork(up_branch)
         down = [(i, j, p) for i in range(len(rows)) for j in range(nb) if j < i for p in range(P)]
         state = {k: use[(k[1], k[2])][k[0]] for k in down}
         step = 0
@@ -188,6 +191,8 @@ class HighResolutionModule(nn.Module):
             state.update(zip(sel, outs))
             step += 1
         term.update(state)
+        if join_up is not None:
+            term.update(zip(up, join_up()))
         sums = []
         for i in range(len(rows)):
             for p in range(P):

@@ -95,6 +95,13 @@ class BackendBase:
         HIP backend sums their gradients with one grouped launch instead of autograd's adds)."""
         return [[t] * c for t, c in zip(tensors, counts)]
 
+    def fork(self, thunk):
+        """A sub-graph nothing on the caller's path needs until `join()`: returns join, a callable that hands back
+        thunk's result.  Here it simply ran; the HIP backend issues it on a second stream (a parallel branch of the
+        captured step) and `join()` makes the current stream wait for it."""
+        out = thunk()
+        return lambda: out
+
     @staticmethod
     def parallel(thunks, level=1):
         """Independent sub-graphs, issued one after the other (thunks[1:] first, thunks[0] last:
@@ -210,6 +217,9 @@ class HipBackend(BackendBase):
         for b, x in zip(blocks, xs):
             flat += [x, b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias]
         return list(self.hb.BasicBlockGroupFn.apply(metas, *flat))
+
+    def fork(self, thunk):
+        return self.hb.fork(thunk)
 
     def fan_out(self, tensors, counts):
         if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors) or max(counts) < 2 or \
