@@ -152,13 +152,13 @@ class _Packed:
 
 
 _PACKED = {}
-_JOB_TABLE = {"key": None, "dev": None, "n": 0, "tiles": None, "ntiles": 0, "max_ct_taps": 0}
 _PACK_TILED = os.environ.get("SSA_PACK_TILED", "1") != "0"
 
 
 def clear_pack_cache():
+    join_pack()
     _PACKED.clear()
-    _JOB_TABLE.update(key=None, dev=None, n=0, tiles=None, ntiles=0, max_ct_taps=0)
+    _JOB_TABLES.clear()
 
 
 def _pack_tiles(jobs, device):
@@ -188,9 +188,52 @@ def _make_job(w, out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, la
     return PackJob(w.data_ptr(), out.data_ptr(), 0, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout)
 
 
-def refresh_packed_filters():
+# The re-pack of a training step (288 MB of fp32 parameters -> their 16-bit operand forms, ~0.2 ms, HBM-bound) is the
+# first thing of the step and only the stem's filters are needed at once: begin_step packs the first SSA_PACK_EARLY
+# filters (registration order = order of first use) on the compute stream and the rest on a stream of its own, next to
+# the stem and layer1 (~0.7 ms of 10-30 us launches); the first conv that asks for one of the late filters makes the
+# compute stream wait (_packed_filter).  SSA_PACK_EARLY=0 (the default): one launch on the compute stream -- measured
+# with 20: 20.19 / 20.46 / 20.38 against 20.41 ms per step, nothing gained (profiles/r06_notes.md call S).
+_PACK_EARLY = int(os.environ.get("SSA_PACK_EARLY", "0"))
+_PACK_SIDE = {"stream": None, "pending": False, "late": frozenset()}
+_JOB_TABLES = {}
+
+
+def join_pack():
+    """The current stream waits for the filters being packed on the side stream."""
+    if _PACK_SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_PACK_SIDE["stream"])
+        _PACK_SIDE["pending"] = False
+        _PACK_SIDE["late"] = frozenset()
+
+
+def _pack_launch(stale):
+    # a table is valid for exactly these (source, destination) buffers: a model rebuilt at the
+    # same parameter addresses has new destination buffers and must not reuse the old table
+    tkey = tuple((k, e.out.data_ptr()) for k, e, _ in stale)
+    tab = _JOB_TABLES.get(tkey)
+    if tab is None:
+        if len(_JOB_TABLES) >= 8:
+            _JOB_TABLES.clear()
+        arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        dev = stale[0][2].device
+        tl = _pack_tiles([e.job for _, e, _ in stale], dev) if _PACK_TILED else None
+        tab = _JOB_TABLES[tkey] = dict(dev=host.to(dev), n=len(stale), tiles=tl[0] if tl else None,
+                                       ntiles=tl[1] if tl else 0, max_ct_taps=tl[2] if tl else 0)
+    if tab["tiles"] is not None:
+        check(lib().ssa_pack_filters_tiled(_p(tab["dev"]), _p(tab["tiles"]), tab["ntiles"],
+                                           tab["max_ct_taps"], _s()), "ssa_pack_filters_tiled")
+    else:
+        check(lib().ssa_pack_filters_batched(_p(tab["dev"]), tab["n"], 32, _s()),
+              "ssa_pack_filters_batched")
+
+
+def refresh_packed_filters(overlap=False):
     """Re-pack every registered filter whose parameter changed since it was
-    packed.  One launch for all of them."""
+    packed.  One launch for all of them; overlap=True (begin_step: host code asks for every filter before its conv is
+    launched): two launches, the second on a side stream (above)."""
+    join_pack()
     stale = []
     for key, e in list(_PACKED.items()):
         w = e.wref()
@@ -201,22 +244,19 @@ def refresh_packed_filters():
             stale.append((key, e, w))
     if not stale:
         return
-    # the table is valid for exactly these (source, destination) buffers: a model rebuilt at the
-    # same parameter addresses has new destination buffers and must not reuse the old table
-    tkey = tuple((k, e.out.data_ptr()) for k, e, _ in stale)
-    if _JOB_TABLE["key"] != tkey:
-        arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        dev = stale[0][2].device
-        tl = _pack_tiles([e.job for _, e, _ in stale], dev) if _PACK_TILED else None
-        _JOB_TABLE.update(key=tkey, dev=host.to(dev), n=len(stale), tiles=tl[0] if tl else None,
-                          ntiles=tl[1] if tl else 0, max_ct_taps=tl[2] if tl else 0)
-    if _JOB_TABLE["tiles"] is not None:
-        check(lib().ssa_pack_filters_tiled(_p(_JOB_TABLE["dev"]), _p(_JOB_TABLE["tiles"]), _JOB_TABLE["ntiles"],
-                                           _JOB_TABLE["max_ct_taps"], _s()), "ssa_pack_filters_tiled")
+    if overlap and 0 < _PACK_EARLY < len(stale) and stale[0][2].is_cuda:
+        early, late = stale[:_PACK_EARLY], stale[_PACK_EARLY:]
+        _pack_launch(early)
+        if _PACK_SIDE["stream"] is None:
+            _PACK_SIDE["stream"] = torch.cuda.Stream()
+        side = _PACK_SIDE["stream"]
+        side.wait_stream(torch.cuda.current_stream())         # the optimizer's update of the parameters
+        with torch.cuda.stream(side):
+            _pack_launch(late)
+        _PACK_SIDE["pending"] = True
+        _PACK_SIDE["late"] = frozenset(k for k, _, _ in late)
     else:
-        check(lib().ssa_pack_filters_batched(_p(_JOB_TABLE["dev"]), _JOB_TABLE["n"], 32, _s()),
-              "ssa_pack_filters_batched")
+        _pack_launch(stale)
     for _, e, w in stale:
         e.version = w._version
 
@@ -225,6 +265,8 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
     key = (weight.data_ptr(), mode, cin_pad, cout_pad)
     e = _PACKED.get(key)
     if e is not None and e.wref() is not None and e.version == weight._version and e.shape == tuple(weight.shape):
+        if _PACK_SIDE["pending"] and key in _PACK_SIDE["late"]:
+            join_pack()
         return e.out, e.Kpad
     Cout, Cin, KH, KW = weight.shape
     layout = 0                  # one fragment order (reserved field of ssa_pack_job)
@@ -252,7 +294,7 @@ def _packed_filter(weight, mode, cin_pad, cout_pad):
         e.job = _make_job(w, e.out, Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows, layout)
         if direct:              # only parameters packed straight from their own storage are batched
             _PACKED[key] = e
-            _JOB_TABLE.update(key=None)      # a new destination buffer: the device table is stale
+            _JOB_TABLES.clear()              # a new destination buffer: the device tables are stale
     check(lib().ssa_pack_filter(_p(w), _p(e.out), Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, api_mode, _s()),
           "ssa_pack_filter")
     e.version = weight._version
@@ -361,7 +403,7 @@ def begin_step(device=None):
         # stay "armed" (or keep stale slots) and no later backward pass would ever publish a gradient again
         del _WGRAD_Q[:]
         _GRADS.abandon()
-    refresh_packed_filters()
+    refresh_packed_filters(overlap=True)
     if device is not None:
         _ARENA.reset(device)
 
@@ -898,10 +940,13 @@ def _on_wgrad_stream():
 # (1x1 convs -> BatchNorm -> bilinear, ~35 us of 10-20 us launches) next to the chain of stride-2 convs (~110 us) it is
 # summed with.  autograd runs a node's backward on the stream of its forward, so the backward halves (bilinear backward
 # -> BatchNorm backward -> 1x1 data gradient, ~55 us per level) run in parallel too, with the engine's own cross-stream
-# waits.  Off when BatchNorm statistics are exchanged between ranks: the collectives of one communicator would then be
-# issued from two streams.
+# waits.  Branches with a BatchNorm in them stay on the main stream when BatchNorm statistics are exchanged between
+# ranks: the collectives of one communicator would otherwise be issued from two streams.  Users (SSA_FORK lists the
+# enabled ones): "fuse" above, "loss" = the RMI term next to the three BCE-only terms of the training loss.  Measured
+# (profiles/r06_notes.md, calls R, S): none 20.17, fuse 19.98, fuse + loss 19.72 ms per step; the OCR block's auxiliary
+# head next to conv3x3_ocr +0.5 ms (two MFMA-bound GEMMs sharing the chip) -- not kept.
 _FORK = {"stream": None}
-_FORK_ON = os.environ.get("SSA_FUSE_STREAM", "1") != "0"
+_FORK_TAGS = set(t for t in os.environ.get("SSA_FORK", "fuse,loss").split(",") if t)      # "" = none
 
 
 def _tensors_of(out):
@@ -912,9 +957,10 @@ def _tensors_of(out):
             yield from _tensors_of(o)
 
 
-def fork(thunk):
+def fork(thunk, tag="fuse", has_bn=True):
     import torch.distributed as dist
-    if not _FORK_ON or not torch.cuda.is_available() or (dist.is_available() and dist.is_initialized()):
+    if tag not in _FORK_TAGS or not torch.cuda.is_available() or \
+            (has_bn and dist.is_available() and dist.is_initialized()):
         out = thunk()
         return lambda: out
     main = torch.cuda.current_stream()

@@ -68,6 +68,8 @@ class OCR_block(nn.Module):
         if slots is not None:
             ctx_out = [s_[0] for s_ in slots] if multi else slots[0][0]
             feats_out = [s_[1] for s_ in slots] if multi else slots[0][1]
+        # (the auxiliary head as a parallel branch of the 3x3 conv -- ops.fork -- measured +0.5 ms per step: two
+        # MFMA-bound GEMMs sharing the chip, profiles/r06_notes.md call S)
         feats = conv_bn(self.conv3x3_ocr[0], self.conv3x3_ocr[1][0], pick(hh, 0), relu=True, out=feats_out)
         aux = conv_bn(self.aux_head[0], self.aux_head[1][0], pick(hh, 1), relu=True)
         aux_out = self.aux_head[2](aux, out_f32=True)              # [B,H,W,K] fp32
@@ -213,13 +215,16 @@ class MscaleOCR(_Base):
 
         if self.training:
             gts = inputs["gts"]
+            # the RMI term is a chain of small launches (pool -> Gram -> 9x9 solves): a parallel branch next to the
+            # three BCE-only terms (ops.fork)
+            join_main = B.fork(lambda: self.criterion(_nchw(joint_pred), gts, do_rmi=True), tag="loss", has_bn=False)
             aux_loss = self.criterion(_nchw(joint_aux), gts, do_rmi=cfg.LOSS.OCR_AUX_RMI)
-            main_loss = self.criterion(_nchw(joint_pred), gts, do_rmi=True)
-            loss = cfg.LOSS.OCR_ALPHA * aux_loss + main_loss
             wt = cfg.LOSS.SUPERVISED_MSCALE_WT
             if wt:
                 loss_lo = self.criterion(_nchw(B.bilinear(pred_05x, size)), gts, do_rmi=False)
                 loss_hi = self.criterion(_nchw(pred_10x), gts, do_rmi=False)
+            loss = cfg.LOSS.OCR_ALPHA * aux_loss + join_main()
+            if wt:
                 loss = loss + wt * loss_lo + wt * loss_hi
             return loss
         return {"pred": _nchw(joint_pred), "pred_05x": _nchw(pred_05x), "pred_10x": _nchw(pred_10x),

@@ -95,7 +95,7 @@ class BackendBase:
         HIP backend sums their gradients with one grouped launch instead of autograd's adds)."""
         return [[t] * c for t, c in zip(tensors, counts)]
 
-    def fork(self, thunk):
+    def fork(self, thunk, tag="fuse", has_bn=True):
         """A sub-graph nothing on the caller's path needs until `join()`: returns join, a callable that hands back
         thunk's result.  Here it simply ran; the HIP backend issues it on a second stream (a parallel branch of the
         captured step) and `join()` makes the current stream wait for it."""
@@ -218,8 +218,8 @@ class HipBackend(BackendBase):
             flat += [x, b.conv1.weight, b.bn1.weight, b.bn1.bias, b.conv2.weight, b.bn2.weight, b.bn2.bias]
         return list(self.hb.BasicBlockGroupFn.apply(metas, *flat))
 
-    def fork(self, thunk):
-        return self.hb.fork(thunk)
+    def fork(self, thunk, tag="fuse", has_bn=True):
+        return self.hb.fork(thunk, tag, has_bn)
 
     def fan_out(self, tensors, counts):
         if not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors) or max(counts) < 2 or \

@@ -93,7 +93,7 @@ def test_evaluation_proxy_routes_and_evicts_least_recently_used(monkeypatch):
         return gr, {k: v.clone() for k, v in inputs.items()}, {"pred": torch.zeros(1)}
     ev._capture = fake_capture
     from semseg_amd import hip_backend
-    monkeypatch.setattr(hip_backend, "refresh_packed_filters", lambda: None)
+    monkeypatch.setattr(hip_backend, "refresh_packed_filters", lambda overlap=False: None)
     a, b, c = ({"images": torch.zeros(1, 3, s, s)} for s in (8, 9, 10))
     for inp in (a, b, a, c, b):
         out = ev(inp)

@@ -494,8 +494,40 @@ def test_batched_filter_repack():
         w.mul_(-0.5).add_(0.25)                # in-place update, like an optimizer step
     hb.refresh_packed_filters()
     torch.cuda.synchronize()
-    assert hb._JOB_TABLE["tiles"] is not None and hb._JOB_TABLE["ntiles"] > 600     # the tile-balanced kernel ran
+    tab, = hb._JOB_TABLES.values()
+    assert tab["tiles"] is not None and tab["ntiles"] > 600     # the tile-balanced kernel ran
     batched = [t.clone() for t in first]       # same persistent buffers, refreshed in place
+    # ... and the step's form: the first filters on this stream, the rest on a side stream, joined by the first lookup
+    # of a late filter (begin_step -> refresh_packed_filters(overlap=True)); same bits as the one-launch form
+    saved = [w.clone() for w in ws]
+    for w in ws:
+        w.mul_(2.0).sub_(0.125)
+    early = hb._PACK_EARLY
+    hb._PACK_EARLY = 5
+    try:
+        hb.refresh_packed_filters(overlap=True)
+        assert hb._PACK_SIDE["pending"] and len(hb._PACK_SIDE["late"]) == len(specs) - 5
+        hb._packed_filter(ws[owners[2]], *specs[2])
+        assert hb._PACK_SIDE["pending"]                      # an early filter: nothing to wait for
+        hb._packed_filter(ws[owners[-1]], *specs[-1])
+        assert not hb._PACK_SIDE["pending"]                  # a late one: the compute stream waits
+    finally:
+        hb._PACK_EARLY = early
+    torch.cuda.synchronize()
+    split = [t.clone() for t in first]
+    for w in ws:
+        w.add_(0.0)                                          # version bump only
+    hb.refresh_packed_filters()
+    torch.cuda.synchronize()
+    for o, sp, got, one in zip(owners, specs, split, first):
+        assert torch.equal(got.view(torch.int16), one.view(torch.int16)), ("two launches vs one", o, sp)
+    assert any(not torch.equal(a.view(torch.int16), b.view(torch.int16)) for a, b in zip(split, batched))
+    for w, w1 in zip(ws, saved):
+        w.copy_(w1)
+    hb.refresh_packed_filters()
+    torch.cuda.synchronize()
+    for got, b0 in zip(first, batched):
+        assert torch.equal(got.view(torch.int16), b0.view(torch.int16))
     hb.clear_pack_cache()
     for o, sp, got in zip(owners, specs, batched):
         want = hb._packed_filter(ws[o], *sp)[0]
