@@ -440,6 +440,130 @@ __device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, 
   }
 }
 
+// ---- backward of an UPSAMPLING resize of a few-channel fp32 tensor (class logits [.., 19], attention maps [.., 1]):
+// the per-element gather above reads 8 x 8 (scale 4) scattered gradient values per input element, 76 bytes apart --
+// 0.84 TB/s on the 80 MB logit gradients of a 1024 x 1024 step, six launches of ~95 us.  Here a workgroup owns a tile
+// of kTileY x kTileX INPUT pixels: pass X reduces the gradient rows the tile can see along x into LDS
+// (tmp[row][tx][c], lanes = (tx, c): runs of C floats, every gradient line fetched once per workgroup and re-used from
+// L1 by the neighbouring taps), pass Y reduces the LDS rows along y -- window_x + window_y taps per element instead of
+// their product, no intermediate in HBM, one launch.  Weights and window origins per tile row / column are computed once
+// into LDS.  Summation order differs from the gather (x first): fp32 rounding only.
+constexpr int kTileX = 16;
+
+__device__ __forceinline__ void tight_range(int i, float scale, int out_size, int in_size, int* lo, int* hi) {
+  int a, b;
+  cand_range(i, scale, out_size, &a, &b);
+  while (a < b && weight_for(a, scale, in_size, i) == 0.f) ++a;
+  while (b > a && weight_for(b, scale, in_size, i) == 0.f) --b;
+  *lo = a; *hi = b;
+}
+
+template <typename OutT, int TY>
+__device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
+                                                       OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw,
+                                                       const int maxrows, const int bx, const int gx) {
+  SSA_DYN_LDS(float, lds);
+  // layout: wx[kTileX][kMaxCand] | wy[TY][kMaxCand] | xlo[kTileX] nx[kTileX] ylo[TY] ny[TY] (ints) | tmp[rows][kTileX][C]
+  float* wxs = lds;
+  float* wys = wxs + kTileX * kMaxCand;
+  int* xlo = reinterpret_cast<int*>(wys + TY * kMaxCand);
+  int* nxs = xlo + kTileX;
+  int* ylo = nxs + kTileX;
+  int* nys = ylo + TY;
+  float* tmp = reinterpret_cast<float*>(nys + TY);
+  const int tid = threadIdx.x;
+  const int tiles_x = (Wi + kTileX - 1) / kTileX, tiles_y = (Hi + TY - 1) / TY;
+  const int ntiles = B * tiles_y * tiles_x;
+  const int rowlen = kTileX * C;
+  for (int tile = bx; tile < ntiles; tile += gx) {
+    const int tx0 = (tile % tiles_x) * kTileX;
+    const int t1 = tile / tiles_x;
+    const int ty0 = (t1 % tiles_y) * TY, b = t1 / tiles_y;
+    __syncthreads();                       // the previous tile's readers are done with the tables and tmp
+    if (tid < kTileX) {
+      const int ix = tx0 + tid;
+      int lo = 0, hi = -1;
+      if (ix < Wi) tight_range(ix, sw, Wo, Wi, &lo, &hi);
+      int n = hi - lo + 1;
+      if (n > kMaxCand) n = kMaxCand;      // (host guarantees windows <= kMaxCand for the scales routed here)
+      xlo[tid] = lo; nxs[tid] = n < 0 ? 0 : n;
+      for (int k = 0; k < kMaxCand; ++k) wxs[tid * kMaxCand + k] = k < n ? weight_for(lo + k, sw, Wi, ix) : 0.f;
+    } else if (tid >= 64 && tid < 64 + TY) {
+      const int j = tid - 64, iy = ty0 + j;
+      int lo = 0, hi = -1;
+      if (iy < Hi) tight_range(iy, sh, Ho, Hi, &lo, &hi);
+      int n = hi - lo + 1;
+      if (n > kMaxCand) n = kMaxCand;
+      ylo[j] = lo; nys[j] = n < 0 ? 0 : n;
+      for (int k = 0; k < kMaxCand; ++k) wys[j * kMaxCand + k] = k < n ? weight_for(lo + k, sh, Hi, iy) : 0.f;
+    }
+    __syncthreads();
+    const int r0 = ylo[0];
+    int r1 = r0 - 1;
+#pragma unroll
+    for (int j = 0; j < TY; ++j) { const int e = ylo[j] + nys[j] - 1; if (nys[j] > 0 && e > r1) r1 = e; }
+    int nrows = r1 - r0 + 1;
+    if (nrows > maxrows) nrows = maxrows;          // (never: the host sized tmp for the tile's span)
+    // ---- pass X: tmp[r][tx][c] = sum_k wx[tx][k] * dy[b, r0 + r, xlo[tx] + k, c]
+    const float* img = dy + (long)b * Ho * Wo * lddy;
+    for (int item = tid; item < nrows * rowlen; item += 256) {
+      const int r = item / rowlen, q = item - r * rowlen;
+      const int tx = q / C, c = q - tx * C;
+      const float* src = img + ((long)(r0 + r) * Wo + xlo[tx]) * lddy + c;
+      const float* w = wxs + tx * kMaxCand;
+      const int n = nxs[tx];
+      float acc = 0.f;
+      for (int k = 0; k < n; ++k) acc += w[k] * src[(long)k * lddy];
+      tmp[item] = acc;
+    }
+    __syncthreads();
+    // ---- pass Y: dx[b, ty0 + j, tx0 + tx, c] = sum_k wy[j][k] * tmp[ylo[j] - r0 + k][tx][c]
+    for (int item = tid; item < TY * rowlen; item += 256) {
+      const int j = item / rowlen, q = item - j * rowlen;
+      const int tx = q / C, c = q - tx * C;
+      const int iy = ty0 + j, ix = tx0 + tx;
+      if (iy >= Hi || ix >= Wi) continue;
+      const float* w = wys + j * kMaxCand;
+      const int n = nys[j];
+      const float* src = tmp + (ylo[j] - r0) * rowlen + q;
+      float acc = 0.f;
+      for (int k = 0; k < n; ++k)
+        if (ylo[j] - r0 + k < nrows) acc += w[k] * src[k * rowlen];
+      st_from_f32(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + c, acc);
+    }
+  }
+}
+
+template <typename OutT, int TY>
+struct BilinearBwdTileK {
+  struct Args { const float* dy; OutT* dx; int B, Ho, Wo, C, lddy, Hi, Wi, lddx; float sh, sw; int maxrows; };
+  static constexpr int NT = 256;
+  static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
+    bilinear_bwd_tile_body<OutT, TY>(a.dy, a.B, a.Ho, a.Wo, a.C, a.lddy, a.dx, a.Hi, a.Wi, a.lddx, a.sh, a.sw, a.maxrows, bx, gx);
+  }
+};
+// gradient rows / columns an input pixel can receive from: ceil(2 / scale) + 1 covers the two-tap footprint's inverse
+static int bwd_window(float scale) { return (int)ceilf(2.f / scale) + 1; }
+static int bwd_tile_rows(float sh, int TY) { return (int)ceilf((float)(TY + 1) / sh) + 2; }
+static size_t bwd_tile_lds(float sh, int TY, int C) {
+  return sizeof(float) * ((kTileX + TY) * kMaxCand + 2 * (kTileX + TY) + (size_t)bwd_tile_rows(sh, TY) * kTileX * C);
+}
+template <typename OutT, int TY>
+int launch_bilinear_bwd_tile(const void* dy, int B, int Ho, int Wo, int C, int lddy, void* dx, int Hi, int Wi, int lddx,
+                             float sh, float sw, hipStream_t s) {
+  typedef BilinearBwdTileK<OutT, TY> K;
+  typename K::Args a{(const float*)dy, (OutT*)dx, B, Ho, Wo, C, lddy, Hi, Wi, lddx, sh, sw, bwd_tile_rows(sh, TY)};
+  const long ntiles = (long)B * ((Hi + TY - 1) / TY) * ((Wi + kTileX - 1) / kTileX);
+  return ssa::submit<K>(a, (int)(ntiles > 16384 ? 16384 : ntiles), 1, bwd_tile_lds(sh, TY, C), s);
+}
+// routed here: fp32 gradient of an upsampling resize, few channels, windows that fit the weight tables and the LDS rows
+static bool bwd_tile_ok(int B, int Ho, int Wo, int Hi, int Wi, int C, float sh, float sw, int TY) {
+  if (C > kPxMaxC || sh > 1.f || sw > 1.f) return false;
+  if (bwd_window(sw) > kMaxCand || bwd_window(sh) > kMaxCand) return false;
+  if (bwd_tile_lds(sh, TY, C) > 60 * 1024) return false;
+  return (long)B * Ho * Wo < (1L << 30);
+}
+
 template <typename InT, typename OutT>
 struct BilinearPxK {
   struct Args { const InT* src; OutT* dst; int B, Hs, Ws, C, lds, Hd, Wd, ldd; float sh, sw; };
@@ -498,6 +622,12 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
     return launch_bilinear<bf16_t, bf16_t, true, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n / 8, s);
   // (a per-pixel gather for the few-channel fp32 tensors was measured 4x SLOWER than the per-element
   // kernel -- lanes = pixels read with a 76-byte stride -- and is not used; profiles/r02_notes.md)
+  // few-channel fp32 gradient of an upsampling resize: the LDS-tiled separable kernel (one launch)
+  static const bool tiled = [] { const char* e = getenv("SSA_BILINEAR_BWD_TILE"); return !(e && e[0] == '0'); }();
+  if (tiled && dy_dtype == 1 && bwd_tile_ok(B, Ho, Wo, Hi, Wi, C, sh, sw, 4)) {
+    if (dx_dtype == 1) return launch_bilinear_bwd_tile<float, 4>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
+    return launch_bilinear_bwd_tile<bf16_t, 4>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
+  }
   if (dy_dtype == 1 && dx_dtype == 1)
     return launch_bilinear<float, float, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);
   if (dy_dtype == 1 && dx_dtype == 0)

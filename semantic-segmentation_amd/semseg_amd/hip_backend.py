@@ -946,7 +946,7 @@ def _on_wgrad_stream():
 # (profiles/r06_notes.md, calls R, S): none 20.17, fuse 19.98, fuse + loss 19.72 ms per step; the OCR block's auxiliary
 # head next to conv3x3_ocr +0.5 ms (two MFMA-bound GEMMs sharing the chip) -- not kept.
 _FORK = {"stream": None}
-_FORK_TAGS = set(t for t in os.environ.get("SSA_FORK", "fuse,loss").split(",") if t)      # "" = none
+_FORK_TAGS = set(t for t in os.environ.get("SSA_FORK", "fuse,loss,ocr").split(",") if t)      # "" = none
 
 
 def _tensors_of(out):

@@ -22,7 +22,12 @@ class SpatialGather_Module(nn.Module):
         """feats / probs: tensors, or lists of tensors (the scale passes)."""
         B = ops.backend()
         if isinstance(feats, (list, tuple)):
-            return [self.forward(f, p) for f, p in zip(feats, probs)]
+            # a pass is a chain of eight launches of a few workgroups: all but the last pass on the forked stream
+            n = len(feats)
+            joins = [B.fork(lambda f=f, p=p: self.forward(f, p), tag="ocr", has_bn=False)
+                     for f, p in zip(feats[:n - 1], probs[:n - 1])]
+            last = self.forward(feats[n - 1], probs[n - 1])
+            return [j() for j in joins] + [last]
         ctx = B.ocr_gather(feats, probs)            # [B,K,C] fp32
         return B.to_act(ctx).unsqueeze(2)           # [B,K,1,C]
 
@@ -61,9 +66,11 @@ class ObjectAttentionBlock(nn.Module):
         """x / proxy: tensors, or lists of tensors (the scale passes; the 1x1 conv stacks then run
         as grouped launches).  out: placement of the result (ops.cat_slots)."""
         B = ops.backend()
+        # key and value come from the K object regions (launches of 2-8 workgroups): a parallel branch of the query stack
+        join_kv = B.fork(lambda: (_run_stack(self.f_object, proxy),     # [B,K,1,D]
+                                  _run_stack(self.f_down, proxy)), tag="ocr")
         q = _run_stack(self.f_pixel, x)                     # [B,H,W,D]
-        k = _run_stack(self.f_object, proxy)                # [B,K,1,D]
-        v = _run_stack(self.f_down, proxy)                  # [B,K,1,D]
+        k, v = join_kv()
         scale = self.key_channels ** -0.5
         if isinstance(x, (list, tuple)):
             ctx = [B.ocr_attention(qi, ki.squeeze(2), vi.squeeze(2), scale) for qi, ki, vi in zip(q, k, v)]
