@@ -458,7 +458,7 @@ __device__ __forceinline__ void tight_range(int i, float scale, int out_size, in
   *lo = a; *hi = b;
 }
 
-template <typename OutT, int TY>
+template <typename OutT, int TY, int TAPS>
 __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
                                                        OutT* __restrict__ dx, int Hi, int Wi, int lddx, float sh, float sw,
                                                        const int maxrows, const int bx, const int gx) {
@@ -485,7 +485,7 @@ __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__
       int lo = 0, hi = -1;
       if (ix < Wi) tight_range(ix, sw, Wo, Wi, &lo, &hi);
       int n = hi - lo + 1;
-      if (n > kMaxCand) n = kMaxCand;      // (host guarantees windows <= kMaxCand for the scales routed here)
+      if (n > TAPS) n = TAPS;              // (never: the host picks TAPS >= the widest window of the scale)
       xlo[tid] = lo; nxs[tid] = n < 0 ? 0 : n;
       for (int k = 0; k < kMaxCand; ++k) wxs[tid * kMaxCand + k] = k < n ? weight_for(lo + k, sw, Wi, ix) : 0.f;
     } else if (tid >= 64 && tid < 64 + TY) {
@@ -493,7 +493,7 @@ __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__
       int lo = 0, hi = -1;
       if (iy < Hi) tight_range(iy, sh, Ho, Hi, &lo, &hi);
       int n = hi - lo + 1;
-      if (n > kMaxCand) n = kMaxCand;
+      if (n > TAPS) n = TAPS;
       ylo[j] = lo; nys[j] = n < 0 ? 0 : n;
       for (int k = 0; k < kMaxCand; ++k) wys[j * kMaxCand + k] = k < n ? weight_for(lo + k, sh, Hi, iy) : 0.f;
     }
@@ -505,16 +505,36 @@ __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__
     int nrows = r1 - r0 + 1;
     if (nrows > maxrows) nrows = maxrows;          // (never: the host sized tmp for the tile's span)
     // ---- pass X: tmp[r][tx][c] = sum_k wx[tx][k] * dy[b, r0 + r, xlo[tx] + k, c]
+    // An item = four gradient rows of one (tx, c): 4 x kMaxCand loads with no branch between them (taps beyond the
+    // window re-read its last column with weight 0), so that they are all in flight before the first multiply --
+    // with a data-dependent trip count the loop ran one load at a time (69 us per 80 MB launch, call U).
     const float* img = dy + (long)b * Ho * Wo * lddy;
-    for (int item = tid; item < nrows * rowlen; item += 256) {
-      const int r = item / rowlen, q = item - r * rowlen;
+    const int rgroups = (nrows + 3) >> 2;
+    for (int item = tid; item < rgroups * rowlen; item += 256) {
+      const int rg = item / rowlen, q = item - rg * rowlen;
       const int tx = q / C, c = q - tx * C;
-      const float* src = img + ((long)(r0 + r) * Wo + xlo[tx]) * lddy + c;
-      const float* w = wxs + tx * kMaxCand;
       const int n = nxs[tx];
-      float acc = 0.f;
-      for (int k = 0; k < n; ++k) acc += w[k] * src[(long)k * lddy];
-      tmp[item] = acc;
+      float w[TAPS];
+      int off[TAPS];
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) {
+        w[k] = wxs[tx * kMaxCand + k];
+        off[k] = (k < n ? k : (n > 0 ? n - 1 : 0)) * lddy;
+      }
+      const float* src = img + ((long)(r0 + rg * 4) * Wo + xlo[tx]) * lddy + c;
+      float acc[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = rg * 4 + rr;
+        const float* sr = src + (long)(r < nrows ? rr : 0) * Wo * lddy;      // rows past the tile: re-read, not stored
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) a += w[k] * sr[off[k]];
+        acc[rr] = a;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (rg * 4 + rr < nrows) tmp[(rg * 4 + rr) * rowlen + q] = n > 0 ? acc[rr] : 0.f;
     }
     __syncthreads();
     // ---- pass Y: dx[b, ty0 + j, tx0 + tx, c] = sum_k wy[j][k] * tmp[ylo[j] - r0 + k][tx][c]
@@ -523,23 +543,26 @@ __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__
       const int tx = q / C, c = q - tx * C;
       const int iy = ty0 + j, ix = tx0 + tx;
       if (iy >= Hi || ix >= Wi) continue;
-      const float* w = wys + j * kMaxCand;
       const int n = nys[j];
-      const float* src = tmp + (ylo[j] - r0) * rowlen + q;
+      const int base = ylo[j] - r0;
       float acc = 0.f;
-      for (int k = 0; k < n; ++k)
-        if (ylo[j] - r0 + k < nrows) acc += w[k] * src[k * rowlen];
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) {
+        int r = base + (k < n ? k : n - 1);
+        r = r < nrows ? r : nrows - 1;
+        acc += wys[j * kMaxCand + k] * tmp[r * rowlen + q];
+      }
       st_from_f32(dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + c, acc);
     }
   }
 }
 
-template <typename OutT, int TY>
+template <typename OutT, int TY, int TAPS>
 struct BilinearBwdTileK {
   struct Args { const float* dy; OutT* dx; int B, Ho, Wo, C, lddy, Hi, Wi, lddx; float sh, sw; int maxrows; };
   static constexpr int NT = 256;
   static __device__ __forceinline__ void run(const Args& a, int bx, int, int gx) {
-    bilinear_bwd_tile_body<OutT, TY>(a.dy, a.B, a.Ho, a.Wo, a.C, a.lddy, a.dx, a.Hi, a.Wi, a.lddx, a.sh, a.sw, a.maxrows, bx, gx);
+    bilinear_bwd_tile_body<OutT, TY, TAPS>(a.dy, a.B, a.Ho, a.Wo, a.C, a.lddy, a.dx, a.Hi, a.Wi, a.lddx, a.sh, a.sw, a.maxrows, bx, gx);
   }
 };
 // gradient rows / columns an input pixel can receive from: ceil(2 / scale) + 1 covers the two-tap footprint's inverse
@@ -548,18 +571,24 @@ static int bwd_tile_rows(float sh, int TY) { return (int)ceilf((float)(TY + 1) /
 static size_t bwd_tile_lds(float sh, int TY, int C) {
   return sizeof(float) * ((kTileX + TY) * kMaxCand + 2 * (kTileX + TY) + (size_t)bwd_tile_rows(sh, TY) * kTileX * C);
 }
-template <typename OutT, int TY>
+// taps the widest window of a scale has: 2 f for an integer upsampling factor f (what the tight ranges come to), else
+// the inverse footprint's bound
+static int bwd_taps(float scale) {
+  const float f = 1.f / scale;
+  return f == floorf(f) ? 2 * (int)f : bwd_window(scale);
+}
+template <typename OutT, int TY, int TAPS>
 int launch_bilinear_bwd_tile(const void* dy, int B, int Ho, int Wo, int C, int lddy, void* dx, int Hi, int Wi, int lddx,
                              float sh, float sw, hipStream_t s) {
-  typedef BilinearBwdTileK<OutT, TY> K;
+  typedef BilinearBwdTileK<OutT, TY, TAPS> K;
   typename K::Args a{(const float*)dy, (OutT*)dx, B, Ho, Wo, C, lddy, Hi, Wi, lddx, sh, sw, bwd_tile_rows(sh, TY)};
   const long ntiles = (long)B * ((Hi + TY - 1) / TY) * ((Wi + kTileX - 1) / kTileX);
   return ssa::submit<K>(a, (int)(ntiles > 16384 ? 16384 : ntiles), 1, bwd_tile_lds(sh, TY, C), s);
 }
 // routed here: fp32 gradient of an upsampling resize, few channels, windows that fit the weight tables and the LDS rows
 static bool bwd_tile_ok(int B, int Ho, int Wo, int Hi, int Wi, int C, float sh, float sw, int TY) {
-  if (C > kPxMaxC || sh > 1.f || sw > 1.f) return false;
-  if (bwd_window(sw) > kMaxCand || bwd_window(sh) > kMaxCand) return false;
+  if (C < 8 || C > kPxMaxC || sh > 1.f || sw > 1.f) return false;       // (one channel: 16 of 256 lanes busy -- the gather)
+  if (bwd_taps(sw) > kMaxCand || bwd_taps(sh) > kMaxCand) return false;
   if (bwd_tile_lds(sh, TY, C) > 60 * 1024) return false;
   return (long)B * Ho * Wo < (1L << 30);
 }
@@ -625,8 +654,11 @@ int ssa_bilinear_bwd(const void* dy, int dy_dtype, int B, int Ho, int Wo, int C,
   // few-channel fp32 gradient of an upsampling resize: the LDS-tiled separable kernel (one launch)
   static const bool tiled = [] { const char* e = getenv("SSA_BILINEAR_BWD_TILE"); return !(e && e[0] == '0'); }();
   if (tiled && dy_dtype == 1 && bwd_tile_ok(B, Ho, Wo, Hi, Wi, C, sh, sw, 4)) {
-    if (dx_dtype == 1) return launch_bilinear_bwd_tile<float, 4>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
-    return launch_bilinear_bwd_tile<bf16_t, 4>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s);
+    const int taps = bwd_taps(sw) > bwd_taps(sh) ? bwd_taps(sw) : bwd_taps(sh);
+#define SSA_BWD_TILE(T, N) launch_bilinear_bwd_tile<T, 4, N>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, s)
+    if (dx_dtype == 1) return taps <= 4 ? SSA_BWD_TILE(float, 4) : taps <= 8 ? SSA_BWD_TILE(float, 8) : SSA_BWD_TILE(float, 12);
+    return taps <= 4 ? SSA_BWD_TILE(bf16_t, 4) : taps <= 8 ? SSA_BWD_TILE(bf16_t, 8) : SSA_BWD_TILE(bf16_t, 12);
+#undef SSA_BWD_TILE
   }
   if (dy_dtype == 1 && dx_dtype == 1)
     return launch_bilinear<float, float, false, true>(dy, B, Ho, Wo, C, lddy, dx, Hi, Wi, lddx, sh, sw, n, s);

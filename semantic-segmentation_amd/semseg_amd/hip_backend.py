@@ -1785,7 +1785,11 @@ def _bilinear_bwd_group(jobs):
     logits the separable form measured SLOWER twice -- with per-element passes (scalar loads: 542 against 470 us per
     step, profiles/r04_notes.md) and with a row pass that stages gradient rows in LDS plus a flat float4 column pass
     (0.80 against 0.28 ms per step, profiles/r05_notes.md call G: 60 KB of LDS per workgroup and twelve candidate
-    weights per element cost more than the gather's re-reads, which hit L2)."""
+    weights per element cost more than the gather's re-reads, which hit L2).  Round 6: ssa_bilinear_bwd itself routes
+    those (fp32, 8..32 channels, upsampling) to ONE LDS-tiled launch -- both separable passes inside a 4 x 16-pixel input
+    tile, the row pass with all of a thread's loads in flight (4 rows x 4 / 8 / 12 taps, no branch between them): 73 -> 32
+    us at 256^2 <- 1024^2, 87 -> 45 us at 512^2 <- 1024^2 (profiles/r06_bilinbench.txt), -0.27 ms per step; the earlier
+    forms lost because their loops ran one load at a time."""
     L = lib()
 
     def separable(j):
