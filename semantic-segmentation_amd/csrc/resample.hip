@@ -5,6 +5,7 @@
 // network/hrnetv2.py:246-249,440-445.
 // The backward is a gather over the output pixels that reference an input
 // pixel -- deterministic, no atomics.
+#include <type_traits>
 #include "common.h"
 #include "group.h"
 #include "../../include/semseg_hip.h"
@@ -88,6 +89,15 @@ __device__ __forceinline__ float weight_for(int o, float scale, int in_size, int
   if (s.i0 == i) w += s.l0;
   if (s.i1 == i) w += s.l1;
   return w;
+}
+
+// the candidates of an input index that really carry weight
+__device__ __forceinline__ void tight_range(int i, float scale, int out_size, int in_size, int* lo, int* hi) {
+  int a, b;
+  cand_range(i, scale, out_size, &a, &b);
+  while (a < b && weight_for(a, scale, in_size, i) == 0.f) ++a;
+  while (b > a && weight_for(b, scale, in_size, i) == 0.f) --b;
+  *lo = a; *hi = b;
 }
 
 // ---- backward gather, 8 bf16 channels per thread
@@ -209,14 +219,13 @@ __device__ __forceinline__ void bilinear_bwd_x_body(const InT* __restrict__ dy, 
     long t = i / VC;
     const int ix = (int)(t % Wi);
     const long r0 = (t / Wi) * kXRows;
+    // the columns with a non-zero weight: 2 f for an integer factor f.  Up to 8 of them go as ONE batch of loads with
+    // no branch in between (taps past the window re-read its last column with weight 0) -- with a zero-weight test
+    // between the candidates' loads they were issued one at a time (profiles/r06_notes.md, call U: the same change made
+    // the few-channel fp32 form 2.3x faster)
     int xlo, xhi;
-    cand_range(ix, sw, Wo, &xlo, &xhi);
-    // the candidates' weights once per thread (up to kMaxCand stay in registers; wider windows recompute per row)
-    float wxs[kMaxCand];
+    tight_range(ix, sw, Wo, Wi, &xlo, &xhi);
     const int nx = xhi - xlo + 1;
-    const bool hoisted = nx <= kMaxCand;
-#pragma unroll
-    for (int k = 0; k < kMaxCand; ++k) wxs[k] = (hoisted && k < nx) ? weight_for(xlo + k, sw, Wi, ix) : 0.f;
     for (int rr = 0; rr < kXRows; ++rr) {
       const long r = r0 + rr;
       if (r >= rows) break;
@@ -224,19 +233,38 @@ __device__ __forceinline__ void bilinear_bwd_x_body(const InT* __restrict__ dy, 
 #pragma unroll
       for (int j = 0; j < V; ++j) acc[j] = 0.f;
       const InT* row = dy + r * (long)Wo * lddy + cg * V;
-      if (hoisted) {
+      auto batch = [&](auto taps) {
+        constexpr int T = decltype(taps)::value;
+        float w[T];
+        long off[T];
 #pragma unroll
-        for (int k = 0; k < kMaxCand; ++k) {
-          if (wxs[k] == 0.f) continue;
-          if constexpr (V == 8) {
-            float g[8];
-            unpack8(*reinterpret_cast<const uint4*>(row + (long)(xlo + k) * lddy), g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += wxs[k] * g[j];
-          } else {
-            acc[0] += wxs[k] * ld_as_f32(row + (long)(xlo + k) * lddy);
-          }
+        for (int k = 0; k < T; ++k) {
+          w[k] = k < nx ? weight_for(xlo + k, sw, Wi, ix) : 0.f;
+          off[k] = (long)(xlo + (k < nx ? k : nx - 1)) * lddy;
         }
+        if constexpr (V == 8) {
+          uint4 raw[T];
+#pragma unroll
+          for (int k = 0; k < T; ++k) raw[k] = *reinterpret_cast<const uint4*>(row + off[k]);
+#pragma unroll
+          for (int k = 0; k < T; ++k) {
+            float g[8];
+            unpack8(raw[k], g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w[k] * g[j];
+          }
+        } else {
+          float g[T];
+#pragma unroll
+          for (int k = 0; k < T; ++k) g[k] = ld_as_f32(row + off[k]);
+#pragma unroll
+          for (int k = 0; k < T; ++k) acc[0] += w[k] * g[k];
+        }
+      };
+      if (nx <= 4) {
+        batch(std::integral_constant<int, 4>());
+      } else if (nx <= 8) {
+        batch(std::integral_constant<int, 8>());
       } else {
         for (int ox = xlo; ox <= xhi; ++ox) {
           const float wx = weight_for(ox, sw, Wi, ix);
@@ -275,21 +303,54 @@ __device__ __forceinline__ void bilinear_bwd_y_body(const float* __restrict__ tm
     const int iy = (int)(t % Hi);
     const int b = (int)(t / Hi);
     int ylo, yhi;
-    cand_range(iy, sh, Ho, &ylo, &yhi);
+    tight_range(iy, sh, Ho, Hi, &ylo, &yhi);
+    const int ny = yhi - ylo + 1;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
     const float* col = tmp + ((long)b * Ho * Wi + ix) * C + cg * V;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      const float wy = weight_for(oy, sh, Hi, iy);
-      if (wy == 0.f) continue;
-      const float* src = col + (long)oy * Wi * C;
+    auto batch = [&](auto taps) {          // as in pass X: the window's rows as one batch of loads
+      constexpr int T = decltype(taps)::value;
+      float w[T];
+      const float* src[T];
+#pragma unroll
+      for (int k = 0; k < T; ++k) {
+        w[k] = k < ny ? weight_for(ylo + k, sh, Hi, iy) : 0.f;
+        src[k] = col + (long)(ylo + (k < ny ? k : ny - 1)) * Wi * C;
+      }
       if constexpr (V == 8) {
-        const float4 a = *reinterpret_cast<const float4*>(src), c4 = *reinterpret_cast<const float4*>(src + 4);
-        acc[0] += wy * a.x; acc[1] += wy * a.y; acc[2] += wy * a.z; acc[3] += wy * a.w;
-        acc[4] += wy * c4.x; acc[5] += wy * c4.y; acc[6] += wy * c4.z; acc[7] += wy * c4.w;
+        float4 a[T], c4[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) { a[k] = *reinterpret_cast<const float4*>(src[k]); c4[k] = *reinterpret_cast<const float4*>(src[k] + 4); }
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+          acc[0] += w[k] * a[k].x; acc[1] += w[k] * a[k].y; acc[2] += w[k] * a[k].z; acc[3] += w[k] * a[k].w;
+          acc[4] += w[k] * c4[k].x; acc[5] += w[k] * c4[k].y; acc[6] += w[k] * c4[k].z; acc[7] += w[k] * c4[k].w;
+        }
       } else {
-        acc[0] += wy * src[0];
+        float g[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) g[k] = src[k][0];
+#pragma unroll
+        for (int k = 0; k < T; ++k) acc[0] += w[k] * g[k];
+      }
+    };
+    if (ny <= 4) {
+      batch(std::integral_constant<int, 4>());
+    } else if (ny <= 8) {
+      batch(std::integral_constant<int, 8>());
+    } else {
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = weight_for(oy, sh, Hi, iy);
+        if (wy == 0.f) continue;
+        const float* src = col + (long)oy * Wi * C;
+        if constexpr (V == 8) {
+          const float4 a = *reinterpret_cast<const float4*>(src), c4 = *reinterpret_cast<const float4*>(src + 4);
+          acc[0] += wy * a.x; acc[1] += wy * a.y; acc[2] += wy * a.z; acc[3] += wy * a.w;
+          acc[4] += wy * c4.x; acc[5] += wy * c4.y; acc[6] += wy * c4.z; acc[7] += wy * c4.w;
+        } else {
+          acc[0] += wy * src[0];
+        }
       }
     }
     OutT* o = dx + ((long)(b * Hi + iy) * Wi + ix) * lddx + cg * V;
@@ -449,14 +510,6 @@ __device__ __forceinline__ void bilinear_fwd_px_body(const InT* __restrict__ x, 
 // their product, no intermediate in HBM, one launch.  Weights and window origins per tile row / column are computed once
 // into LDS.  Summation order differs from the gather (x first): fp32 rounding only.
 constexpr int kTileX = 16;
-
-__device__ __forceinline__ void tight_range(int i, float scale, int out_size, int in_size, int* lo, int* hi) {
-  int a, b;
-  cand_range(i, scale, out_size, &a, &b);
-  while (a < b && weight_for(a, scale, in_size, i) == 0.f) ++a;
-  while (b > a && weight_for(b, scale, in_size, i) == 0.f) --b;
-  *lo = a; *hi = b;
-}
 
 template <typename OutT, int TY, int TAPS>
 __device__ __forceinline__ void bilinear_bwd_tile_body(const float* __restrict__ dy, int B, int Ho, int Wo, int C, int lddy,
