@@ -42,3 +42,18 @@ def test_forced_dist_step_is_the_single_gpu_program():
     assert ld == ld and abs(ld - lp) <= 0.1 * abs(lp)
     assert abs(le - lp) <= 0.1 * abs(lp)
     assert dist1["config"]["collectives_per_step"] < 700
+
+
+def test_overlapped_gradient_exchange_is_the_same_step():
+    """SSA_DDP_OVERLAP=1 (the arena ranges all-reduced on a communication stream with a second communicator, concurrent
+    with backward) against 0 (the same ranges on the compute stream), both inside the captured graph over a one-rank
+    communicator: the same number of exchanges, the same training trajectory up to the order of the fp64 atomics.
+    (Two RANKS cannot share this box's one GPU under RCCL -- it refuses duplicate devices --, so the two-rank form of
+    this comparison runs on the emulated kernels over gloo: tests/test_ddp_overlap_emu_cpu.py.)"""
+    on = _bench({"SSA_FORCE_DIST": "1", "SSA_DDP_OVERLAP": "1"})
+    off = _bench({"SSA_FORCE_DIST": "1", "SSA_DDP_OVERLAP": "0"})
+    assert on["config"]["hipgraph"] is True and off["config"]["hipgraph"] is True
+    assert on["config"]["grad_exchanges_per_step"] == off["config"]["grad_exchanges_per_step"] >= 1
+    lo, lf = on["config"]["loss"], off["config"]["loss"]
+    print("overlap on %.2f ms/step loss %.4f | off %.2f ms/step loss %.4f" % (on["ms_per_step"], lo, off["ms_per_step"], lf))
+    assert lo == lo and abs(lo - lf) <= 0.1 * abs(lf)
