@@ -168,13 +168,18 @@ class GraphedEval:
     into the signature's static inputs, re-packs the filters of parameters that changed since the last call (training
     between two validations; one batched launch, outside the graph), replays, and returns CLONES of the static outputs
     (`clone_outputs=False` hands out the static buffers themselves: valid until the next call with that signature).
-    At most `max_graphs` signatures stay captured, least recently used evicted first."""
+    At most `max_graphs` signatures stay captured, least recently used evicted first.  A signature is captured when it
+    comes the `capture_after`-th time (default: the second) and runs with eager launches before that: a capture costs
+    two more host-side passes than an eager call, which a validation set whose images all differ in size (Mapillary)
+    would pay on every image and never get back; a fixed-size set (Cityscapes) replays from its third image on."""
 
-    def __init__(self, net, warmup=1, max_graphs=4, clone_outputs=True):
+    def __init__(self, net, warmup=1, max_graphs=4, clone_outputs=True, capture_after=2):
         self.net, self.warmup, self.max_graphs, self.clone_outputs = net, warmup, max(1, int(max_graphs)), clone_outputs
+        self.capture_after = max(1, int(capture_after))
         self._graphs = collections.OrderedDict()       # signature -> (graph, static inputs, static outputs)
+        self._seen = collections.Counter()             # signature -> calls so far (signatures not captured yet)
         self.eager_only = False
-        self.replays = self.captures = self.evictions = 0
+        self.replays = self.captures = self.evictions = self.eager_calls = 0
 
     def invalidate(self):
         self._graphs.clear()
@@ -208,6 +213,13 @@ class GraphedEval:
         if ent is None:
             if self.eager_only:
                 return self._forward(inputs)
+            self._seen[sig] += 1
+            if self._seen[sig] < self.capture_after:
+                if len(self._seen) > 4096:          # a long run over ever-new sizes: forget the counts, not the graphs
+                    self._seen.clear()
+                self.eager_calls += 1
+                return self._forward(inputs)
+            del self._seen[sig]
             while len(self._graphs) >= self.max_graphs:      # free the evicted forward's pool BEFORE capturing the next
                 self._graphs.popitem(last=False)
                 self.evictions += 1
@@ -321,10 +333,10 @@ class _GraphedOptim:
         setattr(self.__dict__["_optim"], name, value)
 
 
-def _eval_stepper(net, max_eval_graphs, clone_outputs=True):
+def _eval_stepper(net, max_eval_graphs, clone_outputs=True, capture_after=2):
     if os.environ.get("SSA_GRAPHED_EVAL", "1") == "0" or max_eval_graphs <= 0:
         return None
-    return GraphedEval(net, max_graphs=max_eval_graphs, clone_outputs=clone_outputs)
+    return GraphedEval(net, max_graphs=max_eval_graphs, clone_outputs=clone_outputs, capture_after=capture_after)
 
 
 def graph_training(net, optim, warmup=2, max_graphs=4, max_eval_graphs=4):
@@ -334,8 +346,8 @@ def graph_training(net, optim, warmup=2, max_graphs=4, max_eval_graphs=4):
     return _GraphedNet(net, stepper, _eval_stepper(net, max_eval_graphs)), _GraphedOptim(optim, stepper)
 
 
-def graph_eval(net, max_graphs=4, clone_outputs=True):
+def graph_eval(net, max_graphs=4, clone_outputs=True, capture_after=2):
     """net -> proxy whose evaluation-mode calls under torch.no_grad() replay a captured forward per input signature
     (GraphedEval); training-mode calls go to the module unchanged.  For evaluation-only runs (train.py --eval val/folder,
     utils/trnval_utils.py:134-141): `net = semseg_amd.graph_eval(net)`."""
-    return _GraphedNet(net, None, _eval_stepper(net, max_graphs, clone_outputs))
+    return _GraphedNet(net, None, _eval_stepper(net, max_graphs, clone_outputs, capture_after))

@@ -71,7 +71,7 @@ def test_evaluation_proxy_routes_and_evicts_least_recently_used(monkeypatch):
     the module; the signature cache is LRU (capture stubbed: the bookkeeping around it is what runs here); a capture
     that raises switches evaluation to eager launches for good; SSA_GRAPHED_EVAL=0 installs no evaluation stepper."""
     net = _net().eval()
-    g = graphed.graph_eval(net, max_graphs=2)
+    g = graphed.graph_eval(net, max_graphs=2, capture_after=1)
     ev = g._eval_stepper
     assert isinstance(ev, graphed.GraphedEval) and g._stepper is None
     x = torch.randn(1, 3, 8, 8)
@@ -101,8 +101,16 @@ def test_evaluation_proxy_routes_and_evicts_least_recently_used(monkeypatch):
     # a, b captured; a replayed (now most recent); c evicts b; b comes back and evicts a
     assert (ev.captures, ev.evictions, ev.replays) == (4, 2, 5)
     assert [k[0][1] for k in ev._graphs] == [(1, 3, 10, 10), (1, 3, 9, 9)]
+    # the default policy: a signature is captured when it comes the second time -- sizes that never repeat stay eager
+    ev3 = graphed.GraphedEval(net, max_graphs=2)
+    ev3._capture = fake_capture
+    calls = []
+    ev3._forward = lambda inputs: calls.append(tuple(inputs["images"].shape)) or {"pred": torch.ones(1)}
+    for s_ in (8, 9, 10, 11, 9, 9):
+        ev3({"images": torch.zeros(1, 3, s_, s_)})
+    assert (ev3.captures, ev3.eager_calls, ev3.replays) == (1, 4, 2) and len(calls) == 4
     # a capture that raises: eager from then on
-    ev2 = graphed.GraphedEval(net, max_graphs=1)
+    ev2 = graphed.GraphedEval(net, max_graphs=1, capture_after=1)
     ev2._capture = lambda inputs: (_ for _ in ()).throw(RuntimeError("no device"))
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     net_calls = []

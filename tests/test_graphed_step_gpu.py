@@ -110,7 +110,7 @@ def test_validation_loop_through_graph_eval_matches_eager():
         imgs = [_image(h, w, 7 + i).cuda() for i, (h, w) in enumerate(sizes)]
         gts = torch.zeros(1, 256, 256, dtype=torch.long, device="cuda")
         want = _eval_loop(net, imgs, gts)
-        g = graph_eval(net, max_graphs=2)
+        g = graph_eval(net, max_graphs=2, capture_after=1)
         assert not g.training and g.wrapped is net
         got = _eval_loop(g, imgs, gts)
         ev = g._eval_stepper

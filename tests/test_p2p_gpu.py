@@ -128,9 +128,36 @@ def test_ranks_as_streams_of_one_process(world=2):
     try:
         peers = torch.tensor([p.value for p, _ in bufs], dtype=torch.int64, device="cuda")
         seqs = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        streams = [torch.cuda.Stream() for _ in range(world)]
         t0 = ctypes.c_uint(0)
-        L.ssa_p2p_timeouts(ctypes.byref(t0))
+
+        def timeouts():
+            L.ssa_p2p_timeouts(ctypes.byref(t0))
+            return t0.value
+
+        # The two "ranks" must really run side by side: streams that the runtime put on ONE hardware queue serialise,
+        # the first kernel then waits (bounded: ~2 s) for a peer queued behind it.  Probe with one collective and take
+        # other streams of torch's pool if that happened; a box that never runs two of them concurrently cannot run
+        # this form of the test (the two-process test above does not depend on it).
+        streams, probes = None, 0
+        for _attempt in range(4):
+            cand = [torch.cuda.Stream() for _ in range(world)]
+            before = timeouts()
+            probe = [torch.full((8,), float(r + 1), dtype=torch.float64, device="cuda") for r in range(world)]
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(cand[r]):
+                    check(L.ssa_p2p_allreduce_f64(ctypes.c_void_p(probe[r].data_ptr()), 8, ctypes.c_void_p(peers.data_ptr()),
+                                                  r, world, ctypes.c_void_p(seqs[r].data_ptr()), slot,
+                                                  ctypes.c_void_p(cand[r].cuda_stream)), "ssa_p2p_allreduce_f64")
+            torch.cuda.synchronize()
+            probes += 1
+            if timeouts() == before:
+                assert all(torch.equal(t.cpu(), torch.full((8,), float(sum(range(1, world + 1))), dtype=torch.float64)) for t in probe)
+                streams = cand
+                break
+        if streams is None:
+            pytest.skip("no two streams of this process ran concurrently in %d attempts" % probes)
+        timeouts()
         torch.cuda.synchronize()
         sizes = [1, 7, 1000, slot, 333] * 5                     # 25 collectives: both parities a dozen times
         data = [[(torch.arange(n, dtype=torch.float64) * (r + 1) + k).cuda() for k, n in enumerate(sizes)] for r in range(world)]
@@ -142,14 +169,13 @@ def test_ranks_as_streams_of_one_process(world=2):
                                                   r, world, ctypes.c_void_p(seqs[r].data_ptr()), slot,
                                                   ctypes.c_void_p(streams[r].cuda_stream)), "ssa_p2p_allreduce_f64")
         torch.cuda.synchronize()
-        t1 = ctypes.c_uint(0)
-        L.ssa_p2p_timeouts(ctypes.byref(t1))
-        assert t1.value == t0.value, "a rank gave up waiting for a peer's sequence number"
+        before = t0.value
+        assert timeouts() == before, "a rank gave up waiting for a peer's sequence number"
         for k, n in enumerate(sizes):
             want = sum(torch.arange(n, dtype=torch.float64) * (r + 1) + k for r in range(world))
             for r in range(world):
                 assert torch.equal(data[r][k].cpu(), want), (r, k, n)
-        assert all(int(s.item()) == len(sizes) for s in seqs)
+        assert all(int(s.item()) == len(sizes) + probes for s in seqs)
         # a message larger than a slot is refused, not truncated
         big = torch.zeros(slot + 1, dtype=torch.float64, device="cuda")
         assert L.ssa_p2p_allreduce_f64(ctypes.c_void_p(big.data_ptr()), slot + 1, ctypes.c_void_p(peers.data_ptr()), 0, world,
