@@ -241,7 +241,9 @@ int ssa_conv2d_wgrad_reduce(const float* partial, int nsplit, int cout_pad,
 typedef struct ssa_pack_job {
   const float* w_oihw;
   void* w_packed;
-  long elem_begin;   /* unused by the kernel (reserved)                        */
+  long elem_begin;   /* ssa_pack_filters_tiled: 1 + index of the next job packed from the same OIHW tensor (its tiles
+                      * are then NOT listed: the owner's workgroups write every chained form from one read); 0: none.
+                      * ssa_pack_filters_batched ignores it                                                   */
   int Cout, Cin, KH, KW, cin_pad, cout_pad, Kpad, mode, rows;
   int layout;        /* reserved, 0: mode 2 / 3 write the one fragment order of conv_tile(_p).hip / conv_halo_gemm.hip */
 } ssa_pack_job;
@@ -591,6 +593,13 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
                        int H, int W, int C, const float* dpooled, int Hp, int Wp,
                        const float* upstream, double coef, float* dlogits,
                        int accumulate, void* stream);
+/* The same with the BCE half of RMILoss.forward_sigmoid's gradient (loss/rmi.py:103-134: 0.5 * bce + 0.5 * rmi) folded in:
+ * dlogits = bce_grad * upstream * bce_coef / (bce_acc[1] + bce_denom_add) + the RMI term -- what ssa_scale_grad_to
+ * followed by the accumulating form computes, in one pass over the logits' gradient.                              */
+int ssa_rmi_bwd_logits_bce(const float* logits, int ld, const int64_t* labels, int B, int H, int W, int C,
+                           const float* dpooled, int Hp, int Wp, const float* upstream, double coef,
+                           const float* bce_grad, double bce_coef, const double* bce_acc, double bce_denom_add,
+                           float* dlogits, void* stream);
 
 /* Tail of the input pipeline on the device: joint crop window + optional
  * horizontal flip of the cropped pair (transforms/joint_transforms.py:276-281

@@ -510,9 +510,14 @@ __global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
                                       const int64_t* __restrict__ labels, int B, int H, int W, int C,
                                       const float* __restrict__ dpooled, int Hp, int Wp,
                                       const float* __restrict__ upstream, double coef,
-                                      float* __restrict__ dlogits, int accumulate) {
+                                      float* __restrict__ dlogits, int accumulate,
+                                      const float* __restrict__ bce_src, double bce_coef,
+                                      const double* __restrict__ bce_acc, double bce_denom_add) {
   const long n = (long)B * H * W * C;
   const float k = (float)((double)upstream[0] * coef / 16.0);
+  // bce_src: the un-normalised BCE gradient of the same logits (ssa_bce_fwd) -- scaled here as ssa_scale_grad_to would,
+  // instead of a pass of its own over the 80 MB that this kernel then reads back
+  const float kb = bce_src ? (float)((double)upstream[0] * bce_coef / (bce_acc[1] + bce_denom_add)) : 0.f;
   // every load of an element is issued whatever its label says (none of the addresses depends on it) and four
   // elements go per trip: with the label -> branch -> logit -> pooled-gradient chain of dependent loads, one element
   // at a time, the 160 MB of a 1024 x 1024 x 19 call took 103 us
@@ -532,7 +537,7 @@ __global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
       lab[u] = labels[p];
       lg[u] = logits[p * ld + c];
       dp[u] = dpooled[(((long)b * C + c) * Hp + py) * Wp + px];
-      old[u] = accumulate ? dlogits[i] : 0.f;
+      old[u] = bce_src ? bce_src[i] * kb : (accumulate ? dlogits[i] : 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -683,7 +688,19 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
   if (!logits || !labels || !dpooled || !upstream || !dlogits) return SSA_EINVAL;
   hipLaunchKernelGGL(rmi_bwd_logits_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0,
                      (hipStream_t)stream, logits, ld, labels, B, H, W, C, dpooled, Hp, Wp, upstream,
-                     coef, dlogits, accumulate);
+                     coef, dlogits, accumulate, (const float*)nullptr, 0.0, (const double*)nullptr, 0.0);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_rmi_bwd_logits_bce(const float* logits, int ld, const int64_t* labels, int B, int H, int W,
+                           int C, const float* dpooled, int Hp, int Wp, const float* upstream,
+                           double coef, const float* bce_grad, double bce_coef, const double* bce_acc,
+                           double bce_denom_add, float* dlogits, void* stream) {
+  if (!logits || !labels || !dpooled || !upstream || !dlogits || !bce_grad || !bce_acc) return SSA_EINVAL;
+  hipLaunchKernelGGL(rmi_bwd_logits_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0,
+                     (hipStream_t)stream, logits, ld, labels, B, H, W, C, dpooled, Hp, Wp, upstream,
+                     coef, dlogits, 0, bce_grad, bce_coef, bce_acc, bce_denom_add);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }

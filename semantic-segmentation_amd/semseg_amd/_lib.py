@@ -176,6 +176,8 @@ _SIGS = {
     "ssa_rmi_bwd_pooled": ([_P, _P, _P, c_int, c_int, c_int, _P, _P], c_int),
     "ssa_rmi_bwd_logits": ([_P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P,
                             c_double, _P, c_int, _P], c_int),
+    "ssa_rmi_bwd_logits_bce": ([_P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_double, _P, c_double, _P,
+                                c_double, _P, _P], c_int),
     "ssa_image_u8_crop_flip_normalize": ([_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P],
                                          c_int),
     "ssa_resample_u8": ([_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P], c_int),

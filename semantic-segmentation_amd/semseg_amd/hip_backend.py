@@ -162,14 +162,23 @@ def clear_pack_cache():
 
 
 def _pack_tiles(jobs, device):
-    """Work list of ssa_pack_filters_tiled: every job's [Cout] x [Cin] plane in 32 x ct tiles.
+    """Work list of ssa_pack_filters_tiled: every SOURCE tensor's [Cout] x [Cin] plane in 32 x ct tiles; the jobs that
+    pack the same tensor (its operand forms) are chained through `elem_begin`, the tiles name the first of them.
     -> (device int32 [ntiles, 4], ntiles, max ct*taps), or None when a filter is too large for that path."""
     L = lib()
     tiles, worst = [], 0
+    last = {}                  # (source, shape) -> index of the latest job of that source
     for i, j in enumerate(jobs):
         ct = L.ssa_pack_tile_channels(j.KH, j.KW)
         if ct <= 0:
             return None
+        j.elem_begin = 0
+        key = (j.w, j.Cout, j.Cin, j.KH, j.KW)
+        prev = last.get(key)
+        last[key] = i
+        if prev is not None:
+            jobs[prev].elem_begin = i + 1          # the owner's workgroups go on with this form
+            continue
         worst = max(worst, ct * j.KH * j.KW)
         for co0 in range(0, j.Cout, 32):
             for ci0 in range(0, j.Cin, ct):
@@ -215,10 +224,13 @@ def _pack_launch(stale):
     if tab is None:
         if len(_JOB_TABLES) >= 8:
             _JOB_TABLES.clear()
-        arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        arr = (PackJob * len(stale))(*[e.job for _, e, _ in stale])      # copies: the chain links are this table's
         dev = stale[0][2].device
-        tl = _pack_tiles([e.job for _, e, _ in stale], dev) if _PACK_TILED else None
+        tl = _pack_tiles(arr, dev) if _PACK_TILED else None
+        if tl is None:
+            for j in arr:
+                j.elem_begin = 0
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         tab = _JOB_TABLES[tkey] = dict(dev=host.to(dev), n=len(stale), tiles=tl[0] if tl else None,
                                        ntiles=tl[1] if tl else 0, max_ct_taps=tl[2] if tl else 0)
     if tab["tiles"] is not None:
@@ -2308,10 +2320,11 @@ class BceRmiFn(torch.autograd.Function):
         B, H, W, C = logits.shape
         Hp, Wp = ppr.shape[1], ppr.shape[2]
         g = torch.empty_like(dl)
-        check(L.ssa_scale_grad_to(_p(dl), _p(g), g.numel(), _p(up), ctx.lam, _p(acc), 1.0, _s()), "ssa_scale_grad_to")
         dpool = torch.empty_like(ppr)
         check(L.ssa_rmi_bwd_pooled(_p(ppr), _p(pla), _p(gmat), B * C, Hp, Wp, _p(dpool), _s()), "ssa_rmi_bwd_pooled")
         coef = (1.0 - ctx.lam) / (9.0 * B)
-        check(L.ssa_rmi_bwd_logits(_p(logits), ctx.ld, _p(labels), B, H, W, C, _p(dpool), Hp, Wp, _p(up), coef,
-                                   _p(g), 1, _s()), "ssa_rmi_bwd_logits")
+        # lam * d(bce) + (1 - lam) * d(rmi) in ONE pass over the gradient (the scaling of the saved BCE gradient used to
+        # be a pass of its own: ssa_scale_grad_to, then the accumulating form of this kernel)
+        check(L.ssa_rmi_bwd_logits_bce(_p(logits), ctx.ld, _p(labels), B, H, W, C, _p(dpool), Hp, Wp, _p(up), coef,
+                                       _p(dl), ctx.lam, _p(acc), 1.0, _p(g), _s()), "ssa_rmi_bwd_logits_bce")
         return g, None, None, None

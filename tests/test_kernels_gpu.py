@@ -495,7 +495,8 @@ def test_batched_filter_repack():
     hb.refresh_packed_filters()
     torch.cuda.synchronize()
     tab, = hb._JOB_TABLES.values()
-    assert tab["tiles"] is not None and tab["ntiles"] > 600     # the tile-balanced kernel ran
+    assert tab["tiles"] is not None and 300 < tab["ntiles"] < 600   # the tile-balanced kernel ran, ONE tile list per
+    # source tensor: the 25 operand forms of the 8 tensors are chained (600+ tiles if every form fetched its own)
     batched = [t.clone() for t in first]       # same persistent buffers, refreshed in place
     # ... and the step's form: the first filters on this stream, the rest on a side stream, joined by the first lookup
     # of a late filter (begin_step -> refresh_packed_filters(overlap=True)); same bits as the one-launch form
@@ -506,11 +507,12 @@ def test_batched_filter_repack():
     hb._PACK_EARLY = 5
     try:
         hb.refresh_packed_filters(overlap=True)
-        assert hb._PACK_SIDE["pending"] and len(hb._PACK_SIDE["late"]) == len(specs) - 5
-        hb._packed_filter(ws[owners[2]], *specs[2])
-        assert hb._PACK_SIDE["pending"]                      # an early filter: nothing to wait for
-        hb._packed_filter(ws[owners[-1]], *specs[-1])
-        assert not hb._PACK_SIDE["pending"]                  # a late one: the compute stream waits
+        if ws[0].is_cuda:                                        # (the CPU emulation has no second stream: one launch)
+            assert hb._PACK_SIDE["pending"] and len(hb._PACK_SIDE["late"]) == len(specs) - 5
+            hb._packed_filter(ws[owners[2]], *specs[2])
+            assert hb._PACK_SIDE["pending"]                      # an early filter: nothing to wait for
+            hb._packed_filter(ws[owners[-1]], *specs[-1])
+            assert not hb._PACK_SIDE["pending"]                  # a late one: the compute stream waits
     finally:
         hb._PACK_EARLY = early
     torch.cuda.synchronize()
