@@ -563,6 +563,11 @@ int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int 
 /* loss = acc[0] / (acc[1] + denom_add) ; writes fp32 scalar                    */
 int ssa_loss_finalize(const double* acc, double denom_add, float* loss, void* stream);
 /* g[i] *= upstream[0] * coef / (acc[1] + denom_add)                            */
+/* Backward of ssa_bce_fwd WITHOUT its saved gradient: dlogits = (sigmoid - onehot) * mask * upstream * coef /
+ * (acc[1] + denom_add), recomputed from the logits (dense [P, C], ld == C, P * C % 4 == 0, 16-byte aligned; otherwise
+ * SSA_EUNSUPPORTED and the caller scales the gradient ssa_bce_fwd saved).  loss/rmi.py:103-112's autograd backward. */
+int ssa_bce_bwd(const float* logits, int ld, const int64_t* labels, long P, int C, const float* upstream,
+                double coef, const double* acc, double denom_add, float* dlogits, void* stream);
 int ssa_scale_grad(float* g, long n, const float* upstream, double coef,
                    const double* acc, double denom_add, void* stream);
 /* dst[i] = src[i] * upstream[0] * coef / (acc[1] + denom_add): the same without touching src (the un-normalised
@@ -595,7 +600,8 @@ int ssa_rmi_bwd_logits(const float* logits, int ld, const int64_t* labels, int B
                        int accumulate, void* stream);
 /* The same with the BCE half of RMILoss.forward_sigmoid's gradient (loss/rmi.py:103-134: 0.5 * bce + 0.5 * rmi) folded in:
  * dlogits = bce_grad * upstream * bce_coef / (bce_acc[1] + bce_denom_add) + the RMI term -- what ssa_scale_grad_to
- * followed by the accumulating form computes, in one pass over the logits' gradient.                              */
+ * followed by the accumulating form computes, in one pass over the logits' gradient.  bce_grad NULL: the BCE half is
+ * recomputed from the logits (the forward then saves no gradient).                                                */
 int ssa_rmi_bwd_logits_bce(const float* logits, int ld, const int64_t* labels, int B, int H, int W, int C,
                            const float* dpooled, int Hp, int Wp, const float* upstream, double coef,
                            const float* bce_grad, double bce_coef, const double* bce_acc, double bce_denom_add,

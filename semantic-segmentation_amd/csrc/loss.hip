@@ -143,6 +143,47 @@ __global__ __launch_bounds__(NT) void bce_stream_kernel(const float* __restrict_
   block_acc2(lsum, lcnt, acc);
 }
 
+// Backward of the dense masked BCE without a saved gradient: d = (sigmoid(v) - onehot) * upstream * coef / count for
+// the valid pixels, recomputed from the logits with the forward's arithmetic (one exponential, hardware rcp) -- the
+// forward then writes no gradient at all (80 MB per loss term at 1024 x 1024 x 19) and the scaling pass that read it
+// back (ssa_scale_grad_to) is this kernel.
+__global__ __launch_bounds__(NT) void bce_bwd_stream_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                            unsigned n4, int C, const float* __restrict__ upstream, double coef,
+                                                            const double* __restrict__ acc, double denom_add,
+                                                            float* __restrict__ dlogits) {
+  const float s = (float)((double)upstream[0] * coef / (acc[1] + denom_add));
+  const unsigned last_pix = (n4 * 4u) / (unsigned)C - 1u;
+  auto element = [&](unsigned g, const float4 v4, unsigned pix, long lab, const long lab_next) {
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float d[4];
+    const unsigned pix0 = pix;
+    int c = (int)(g * 4u - pix * (unsigned)C);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c == C) { c = 0; ++pix; lab = (pix == pix0 + 1u) ? lab_next : labels[pix]; }
+      const bool valid = lab >= 0 && lab < C;
+      const float t = (c == lab) ? 1.f : 0.f;
+      const float e = __expf(-fabsf(v[k]));
+      const float r = __frcp_rn(1.f + e);
+      d[k] = valid ? ((v[k] >= 0.f ? r : e * r) - t) * s : 0.f;
+      ++c;
+    }
+    reinterpret_cast<float4*>(dlogits)[g] = make_float4(d[0], d[1], d[2], d[3]);
+  };
+  const unsigned stride = gridDim.x * NT;
+  for (unsigned g = blockIdx.x * NT + threadIdx.x; g < n4; g += 2u * stride) {
+    const bool two = g + stride < n4;
+    const unsigned g2 = two ? g + stride : g;
+    const float4 va = reinterpret_cast<const float4*>(logits)[g];
+    const float4 vb = reinterpret_cast<const float4*>(logits)[g2];
+    const unsigned pa = (g * 4u) / (unsigned)C, pb = (g2 * 4u) / (unsigned)C;
+    const long la = labels[pa], la1 = labels[pa < last_pix ? pa + 1u : last_pix];
+    const long lb = labels[pb], lb1 = labels[pb < last_pix ? pb + 1u : last_pix];
+    element(g, va, pa, la, la1);
+    if (two) element(g2, vb, pb, lb, lb1);
+  }
+}
+
 __global__ void loss_finalize_kernel(const double* __restrict__ acc, double denom_add,
                                      float* __restrict__ loss) {
   loss[0] = (float)(acc[0] / (acc[1] + denom_add));
@@ -517,7 +558,8 @@ __global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
   const float k = (float)((double)upstream[0] * coef / 16.0);
   // bce_src: the un-normalised BCE gradient of the same logits (ssa_bce_fwd) -- scaled here as ssa_scale_grad_to would,
   // instead of a pass of its own over the 80 MB that this kernel then reads back
-  const float kb = bce_src ? (float)((double)upstream[0] * bce_coef / (bce_acc[1] + bce_denom_add)) : 0.f;
+  // bce_acc without bce_src: the BCE half is recomputed here from the logit this thread holds anyway
+  const float kb = bce_acc ? (float)((double)upstream[0] * bce_coef / (bce_acc[1] + bce_denom_add)) : 0.f;
   // every load of an element is issued whatever its label says (none of the addresses depends on it) and four
   // elements go per trip: with the label -> branch -> logit -> pooled-gradient chain of dependent loads, one element
   // at a time, the 160 MB of a 1024 x 1024 x 19 call took 103 us
@@ -525,10 +567,12 @@ __global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
   for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
     float lg[4], dp[4], old[4];
     long lab[4];
+    int cc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long i = i0 + u * stride < n ? i0 + u * stride : i0;
       const int c = (int)(i % C);
+      cc[u] = c;
       const long p = i / C;
       const int x = (int)(p % W);
       const long t = p / W;
@@ -547,6 +591,11 @@ __global__ void rmi_bwd_logits_kernel(const float* __restrict__ logits, int ld,
       if (lab[u] >= 0 && lab[u] < C) {
         const float s = 1.f / (1.f + expf(-lg[u]));
         g = k * dp[u] * s * (1.f - s);
+        if (bce_acc && !bce_src) {          // (sigmoid - onehot) * kb, with the BCE forward's arithmetic
+          const float e = __expf(-fabsf(lg[u]));
+          const float r = __frcp_rn(1.f + e);
+          g += ((lg[u] >= 0.f ? r : e * r) - (cc[u] == (int)lab[u] ? 1.f : 0.f)) * kb;
+        }
       }
       dlogits[i] = old[u] + g;
     }
@@ -618,6 +667,19 @@ int ssa_scale_grad_to(const float* src, float* dst, long n, const float* upstrea
   if (!src || !dst || !upstream || !acc || n <= 0) return SSA_EINVAL;
   hipLaunchKernelGGL(scale_grad_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, n,
                      upstream, coef, acc, denom_add);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
+}
+
+int ssa_bce_bwd(const float* logits, int ld, const int64_t* labels, long P, int C, const float* upstream, double coef,
+                const double* acc, double denom_add, float* dlogits, void* stream) {
+  if (!logits || !labels || !upstream || !acc || !dlogits || P <= 0 || C < 4 || C > 128) return SSA_EINVAL;
+  const long n = P * C;
+  if (ld != C || n % 4 || n >= (1L << 31) ||
+      ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15u) != 0)
+    return SSA_EUNSUPPORTED;                     // (the caller keeps the saved gradient of ssa_bce_fwd for those)
+  hipLaunchKernelGGL(bce_bwd_stream_kernel, dim3(grid_for(n / 4, 2048)), dim3(NT), 0, (hipStream_t)stream, logits, labels,
+                     (unsigned)(n / 4), C, upstream, coef, acc, denom_add, dlogits);
   SSA_LAUNCH_CHECK();
   return SSA_OK;
 }
@@ -697,7 +759,7 @@ int ssa_rmi_bwd_logits_bce(const float* logits, int ld, const int64_t* labels, i
                            int C, const float* dpooled, int Hp, int Wp, const float* upstream,
                            double coef, const float* bce_grad, double bce_coef, const double* bce_acc,
                            double bce_denom_add, float* dlogits, void* stream) {
-  if (!logits || !labels || !dpooled || !upstream || !dlogits || !bce_grad || !bce_acc) return SSA_EINVAL;
+  if (!logits || !labels || !dpooled || !upstream || !dlogits || !bce_acc) return SSA_EINVAL;   // bce_grad NULL: recomputed
   hipLaunchKernelGGL(rmi_bwd_logits_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0,
                      (hipStream_t)stream, logits, ld, labels, B, H, W, C, dpooled, Hp, Wp, upstream,
                      coef, dlogits, 0, bce_grad, bce_coef, bce_acc, bce_denom_add);

@@ -167,6 +167,7 @@ _SIGS = {
     "ssa_ce_fwd": ([_P, c_int, _P, c_long, c_int, c_int, _P, _P, _P], c_int),
     "ssa_bce_fwd": ([_P, c_int, _P, c_long, c_int, _P, _P, _P], c_int),
     "ssa_loss_finalize": ([_P, c_double, _P, _P], c_int),
+    "ssa_bce_bwd": ([_P, c_int, _P, c_long, c_int, _P, c_double, _P, c_double, _P, _P], c_int),
     "ssa_scale_grad": ([_P, c_long, _P, c_double, _P, c_double, _P], c_int),
     "ssa_scale_grad_to": ([_P, _P, c_long, _P, c_double, _P, c_double, _P], c_int),
     "ssa_rmi_pool": ([_P, c_int, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P], c_int),

@@ -2270,7 +2270,9 @@ class CrossEntropyFn(torch.autograd.Function):
 
 
 class BceRmiFn(torch.autograd.Function):
-    """RMILoss.forward_sigmoid: masked BCE, optionally 0.5*bce + 0.5*rmi."""
+    """RMILoss.forward_sigmoid: masked BCE, optionally 0.5*bce + 0.5*rmi.  On dense logits the forward saves NO
+    gradient: the backward recomputes (sigmoid - onehot) from the logits, already scaled (ssa_bce_bwd, or inside the RMI
+    term's kernel) -- an 80 MB write per loss term at 1024 x 1024 x 19 and the pass that read it back are gone."""
 
     @staticmethod
     def forward(ctx, logits, labels, do_rmi, weight_lambda):
@@ -2283,14 +2285,18 @@ class BceRmiFn(torch.autograd.Function):
         dev = logits.device
         acc = torch.empty((2,), dtype=torch.float64, device=dev)
         need = ctx.needs_input_grad[0]
-        dl = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if need else None
+        n = B * H * W * C
+        recompute = bool(need and ld == C and C >= 4 and n % 4 == 0 and n < (1 << 31) and logits.data_ptr() % 16 == 0)
+        dl = torch.empty((B, H, W, C), dtype=torch.float32, device=dev) if (need and not recompute) else None
         check(L.ssa_bce_fwd(_p(logits), ld, _p(labels), B * H * W, C, _p(acc), _p(dl), _s()), "ssa_bce_fwd")
         bce = torch.empty((), dtype=torch.float32, device=dev)
         check(L.ssa_loss_finalize(_p(acc), 1.0, _p(bce), _s()), "ssa_loss_finalize")
         ctx.do_rmi = bool(do_rmi)
         ctx.lam = float(weight_lambda)
+        ctx.recompute = recompute
+        ctx.ld = ld
         if not do_rmi:
-            ctx.save_for_backward(dl, acc)
+            ctx.save_for_backward(*((logits, labels, acc) if recompute else (dl, acc)))
             return bce
         Hp, Wp = H // 4 + 1, W // 4 + 1
         ppr = torch.empty((B * C, Hp, Wp), dtype=torch.float32, device=dev)
@@ -2304,7 +2310,6 @@ class BceRmiFn(torch.autograd.Function):
         rmi = torch.empty((), dtype=torch.float32, device=dev)
         check(L.ssa_rmi_finalize(_p(loss_bc), B, C, _p(rmi), _s()), "ssa_rmi_finalize")
         ctx.save_for_backward(dl, acc, logits, labels, ppr, pla, gmat)
-        ctx.ld = ld
         return ctx.lam * bce + (1.0 - ctx.lam) * rmi
 
     @staticmethod
@@ -2312,6 +2317,13 @@ class BceRmiFn(torch.autograd.Function):
         L = lib()
         up = up.float().contiguous()
         if not ctx.do_rmi:
+            if ctx.recompute:
+                logits, labels, acc = ctx.saved_tensors
+                B, H, W, C = logits.shape
+                g = torch.empty_like(logits)
+                check(L.ssa_bce_bwd(_p(logits), ctx.ld, _p(labels), B * H * W, C, _p(up), 1.0, _p(acc), 1.0, _p(g), _s()),
+                      "ssa_bce_bwd")
+                return g, None, None, None
             dl, acc = ctx.saved_tensors
             g = torch.empty_like(dl)
             check(L.ssa_scale_grad_to(_p(dl), _p(g), g.numel(), _p(up), 1.0, _p(acc), 1.0, _s()), "ssa_scale_grad_to")
@@ -2319,12 +2331,12 @@ class BceRmiFn(torch.autograd.Function):
         dl, acc, logits, labels, ppr, pla, gmat = ctx.saved_tensors
         B, H, W, C = logits.shape
         Hp, Wp = ppr.shape[1], ppr.shape[2]
-        g = torch.empty_like(dl)
+        g = torch.empty_like(logits)
         dpool = torch.empty_like(ppr)
         check(L.ssa_rmi_bwd_pooled(_p(ppr), _p(pla), _p(gmat), B * C, Hp, Wp, _p(dpool), _s()), "ssa_rmi_bwd_pooled")
         coef = (1.0 - ctx.lam) / (9.0 * B)
-        # lam * d(bce) + (1 - lam) * d(rmi) in ONE pass over the gradient (the scaling of the saved BCE gradient used to
-        # be a pass of its own: ssa_scale_grad_to, then the accumulating form of this kernel)
+        # lam * d(bce) + (1 - lam) * d(rmi) in ONE pass over the gradient: the BCE half from the saved un-normalised
+        # gradient, or (dense logits: none was saved) recomputed from the logit the kernel holds anyway
         check(L.ssa_rmi_bwd_logits_bce(_p(logits), ctx.ld, _p(labels), B, H, W, C, _p(dpool), Hp, Wp, _p(up), coef,
                                        _p(dl), ctx.lam, _p(acc), 1.0, _p(g), _s()), "ssa_rmi_bwd_logits_bce")
         return g, None, None, None

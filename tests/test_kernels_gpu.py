@@ -906,11 +906,15 @@ def test_cross_entropy():
     check_close("ce_grad", nchw(ld.grad), lr.grad, 1e-4, 1e-4)
 
 
+# (2, 64, 96): dense, element count a multiple of four -- the forward saves no gradient, the backward recomputes it
+# (ssa_bce_bwd / inside ssa_rmi_bwd_logits_bce); (1, 65, 97): an odd pixel count -- the saved-gradient path
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 65, 97)])
 @pytest.mark.parametrize("do_rmi", [False, True])
-def test_bce_rmi(do_rmi):
+def test_bce_rmi(do_rmi, shape):
     from oracle import ops as O
     hb = _hb()
-    B, C, H, W = 2, 19, 64, 96
+    C = 19
+    B, H, W = shape
     logits = torch.randn(B, C, H, W) * 2
     lab = _labels(B, H, W, C, seed=3)
     lr = logits.clone().requires_grad_(True)
