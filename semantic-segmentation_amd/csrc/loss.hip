@@ -126,19 +126,25 @@ __global__ __launch_bounds__(NT) void bce_stream_kernel(const float* __restrict_
     lsum += (double)part;
     if (dlogits) reinterpret_cast<float4*>(dlogits)[g] = make_float4(d[0], d[1], d[2], d[3]);
   };
-  // two elements per trip, their four loads issued before the arithmetic of either: with one float4 per thread in
-  // flight (262 K threads x 16 B = 4 MB) the 160 MB of a 1024 x 1024 x 19 call took 70 us (2.3 TB/s)
+  // four elements per trip, their loads issued before the arithmetic of any: with one float4 per thread in flight
+  // (262 K threads x 16 B = 4 MB) the 160 MB of a 1024 x 1024 x 19 call took 70 us (2.3 TB/s).  512 workgroups: every
+  // one ends in two same-address fp64 atomics, which queue at ~25 ns each (ColsumK, profiles/r06_notes.md call V).
   const unsigned stride = gridDim.x * NT;
-  for (unsigned g = blockIdx.x * NT + threadIdx.x; g < n4; g += 2u * stride) {
-    const bool two = g + stride < n4;
-    const unsigned g2 = two ? g + stride : g;
-    const float4 va = reinterpret_cast<const float4*>(logits)[g];
-    const float4 vb = reinterpret_cast<const float4*>(logits)[g2];
-    const unsigned pa = (g * 4u) / (unsigned)C, pb = (g2 * 4u) / (unsigned)C;
-    const long la = labels[pa], la1 = labels[pa < last_pix ? pa + 1u : last_pix];
-    const long lb = labels[pb], lb1 = labels[pb < last_pix ? pb + 1u : last_pix];
-    element(g, va, pa, la, la1);
-    if (two) element(g2, vb, pb, lb, lb1);
+  for (unsigned g0 = blockIdx.x * NT + threadIdx.x; g0 < n4; g0 += 4u * stride) {
+    float4 v[4];
+    unsigned gi[4], pi[4];
+    long l0[4], l1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      gi[u] = g0 + u * stride < n4 ? g0 + u * stride : g0;
+      v[u] = reinterpret_cast<const float4*>(logits)[gi[u]];
+      pi[u] = (gi[u] * 4u) / (unsigned)C;
+      l0[u] = labels[pi[u]];
+      l1[u] = labels[pi[u] < last_pix ? pi[u] + 1u : last_pix];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u == 0 || g0 + u * stride < n4) element(gi[u], v[u], pi[u], l0[u], l1[u]);
   }
   block_acc2(lsum, lcnt, acc);
 }
@@ -638,8 +644,8 @@ int ssa_bce_fwd(const float* logits, int ld, const int64_t* labels, long P, int 
   if (e != hipSuccess) return (int)e;
   const long n = P * C;
   if (ld == C && n % 4 == 0 && n < (1L << 31) && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15u) == 0) {
-    // 1024 blocks = 4 per CU: every block ends in two fp64 atomics on the same two addresses, which serialise
-    hipLaunchKernelGGL(bce_stream_kernel, dim3(grid_for(n / 4, 1024)), dim3(NT), 0, s, logits, labels, (unsigned)(n / 4), C,
+    // 512 blocks = 2 per CU: every block ends in two fp64 atomics on the same two addresses, which serialise
+    hipLaunchKernelGGL(bce_stream_kernel, dim3(grid_for(n / 4, 512)), dim3(NT), 0, s, logits, labels, (unsigned)(n / 4), C,
                        acc, dlogits);
     SSA_LAUNCH_CHECK();
     return SSA_OK;
