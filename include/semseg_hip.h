@@ -336,6 +336,19 @@ typedef struct ssa_bn_update_job {
 /* jobs_dev: device array of ssa_bn_update_job; one launch for all layers.     */
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels,
                                   void* stream);
+/* Evaluation-mode coefficients of many layers in one launch (use_running = 1 of ssa_bn_finalize, the same arithmetic):
+ * coef = [4][C] scale, shift, mean, invstd.  nn.BatchNorm2d.eval() of the reference (network/mynn.py:18-24) computes them
+ * inside every cuDNN call; here they were one launch per layer and scale pass.  jobs_dev: device array.            */
+typedef struct ssa_bn_eval_job {
+  const float* gamma;          /* NULL: 1 */
+  const float* beta;           /* NULL: 0 */
+  const float* running_mean;
+  const float* running_var;
+  float* coef;
+  int C;
+  float eps;
+} ssa_bn_eval_job;
+int ssa_bn_finalize_eval_batched(const void* jobs_dev, int njobs, int max_channels, void* stream);
 /* From (possibly all-reduced) sums and total count: scale/shift for the apply
  * pass, mean/invstd for backward, running-stat update (momentum, unbiased var).
  * use_running=1 (eval): scale/shift from running stats, sums ignored.          */

@@ -830,6 +830,27 @@ struct BnUpdateJob {      // mirror of ssa_bn_update_job (include/semseg_hip.h),
   int pad_;
 };
 
+struct BnEvalJob {          // mirror of ssa_bn_eval_job (include/semseg_hip.h)
+  const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+  float* coef;              // [4][C]: scale, shift, mean, invstd
+  int C; float eps;
+};
+
+__global__ __launch_bounds__(128) void bn_finalize_eval_batched_kernel(const BnEvalJob* __restrict__ jobs) {
+  const BnEvalJob j = jobs[blockIdx.y];
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  if (c >= j.C) return;
+  // the arithmetic of bn_finalize_kernel(use_running = 1)
+  const double mean = j.running_mean[c], var = j.running_var[c];
+  const double invstd = 1.0 / sqrt(var + (double)j.eps);
+  const double g = j.gamma ? (double)j.gamma[c] : 1.0;
+  const double b = j.beta ? (double)j.beta[c] : 0.0;
+  j.coef[c] = (float)(g * invstd);
+  j.coef[j.C + c] = (float)(b - mean * g * invstd);
+  j.coef[2 * j.C + c] = (float)mean;
+  j.coef[3 * j.C + c] = (float)invstd;
+}
+
 __global__ __launch_bounds__(128) void bn_update_running_kernel(const BnUpdateJob* __restrict__ jobs) {
   const BnUpdateJob j = jobs[blockIdx.y];
   const int c = blockIdx.x * 128 + threadIdx.x;
@@ -956,6 +977,18 @@ int ssa_bn_apply_train(const void* x, int ldx, const void* residual, int ldr, vo
                                            count > 1.0 ? count / (count - 1.0) : 1.0,
                                            P, pix_per_img, g.ppb, ldx, ldr, ldz, C, nrep, relu, momentum, eps}),
                        2 * C * sizeof(float), (hipStream_t)stream);
+}
+
+// Evaluation-mode coefficients of MANY BatchNorm layers in one launch: scale / shift (and mean / invstd) from the running
+// statistics -- constants of an evaluation forward that were one single-workgroup launch per layer and scale pass
+// (314 per single-scale forward of HRNet-OCR: 17 % of its time, profiles/r06_notes.md call EV).
+int ssa_bn_finalize_eval_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {
+  if (!jobs_dev || njobs < 1 || max_channels < 1) return SSA_EINVAL;
+  static_assert(sizeof(BnEvalJob) == 48, "ssa_bn_eval_job layout");
+  hipLaunchKernelGGL(bn_finalize_eval_batched_kernel, dim3((max_channels + 127) / 128, njobs), dim3(128), 0,
+                     (hipStream_t)stream, (const BnEvalJob*)jobs_dev);
+  SSA_LAUNCH_CHECK();
+  return SSA_OK;
 }
 
 int ssa_bn_update_running_batched(const void* jobs_dev, int njobs, int max_channels, void* stream) {

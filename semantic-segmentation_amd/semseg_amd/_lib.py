@@ -46,6 +46,12 @@ class PackJob(ctypes.Structure):
         "Cout", "Cin", "KH", "KW", "cin_pad", "cout_pad", "Kpad", "mode", "rows", "layout")]
 
 
+class BnEvalJob(ctypes.Structure):
+    """Mirror of ssa_bn_eval_job (48 bytes)."""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("coef", c_void_p), ("C", c_int), ("eps", c_float)]
+
+
 class BnUpdateJob(ctypes.Structure):
     """Mirror of ssa_bn_update_job (104 bytes)."""
     _fields_ = [("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
@@ -113,6 +119,7 @@ _SIGS = {
     "ssa_pack_tile_channels": ([c_int, c_int], c_int),
     "ssa_conv2d_dgrad_s2": ([c_int] * 9 + [_P, _P, _P, _P, _P], c_int),
     "ssa_pack_filters_tiled": ([_P, _P, c_int, c_int, _P], c_int),
+    "ssa_bn_finalize_eval_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,
                          _P, _P, _P, _P, _P], c_int),
     "ssa_bn_apply": ([_P, c_int, _P, c_int, _P, c_int, c_long, c_int, _P, _P, c_int, _P,

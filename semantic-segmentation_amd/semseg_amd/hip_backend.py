@@ -29,7 +29,7 @@ import weakref
 
 import torch
 
-from ._lib import lib, check, ConvDesc, PackJob, BnUpdateJob, ProfileRec
+from ._lib import lib, check, ConvDesc, PackJob, BnUpdateJob, BnEvalJob, ProfileRec
 
 from ._lib import ACT as _ACT_NAME     # storage format of the activations = the library build (SSA_ACT_DTYPE)
 ACT_DTYPE = torch.float16 if _ACT_NAME == "fp16" else torch.bfloat16
@@ -400,6 +400,79 @@ class _BnUpdates:
 _BN_UPDATES = _BnUpdates()
 
 
+# --------------------------------------------------------------------------
+# evaluation-mode BatchNorm coefficients: constants of a forward, one launch for all layers
+# --------------------------------------------------------------------------
+class _BnEvalCoefs:
+    """scale / shift / mean / invstd of every BatchNorm an inference forward (no autograd) uses, in persistent [4, C]
+    buffers.  They used to be one single-workgroup launch per layer AND scale pass (314 per single-scale forward of
+    HRNet-OCR, 17 % of its time).  Now: begin_step refreshes every registered layer's buffer with ONE batched launch
+    (ssa_bn_finalize_eval_batched: part of a captured forward, so a replay after training reads the current running
+    statistics) when the previous forward used the registry; a layer seen for the first time, or a forward that
+    follows a training forward, computes its coefficients singly as before and registers.  Validity is a generation
+    number bumped by every begin_step -- the running statistics are written by kernels through raw pointers, version
+    counters would not notice."""
+
+    def __init__(self):
+        self.entries = {}        # key -> [weakref(running_mean), running_var, gamma, beta, coef, generation, C, eps]
+        self.gen = 0
+        self.uses = 0
+        self.table_key = None
+        self.table = None
+        self.max_c = 1
+
+    def begin(self):
+        self.gen += 1
+        used, self.uses = self.uses, 0
+        if not used or not self.entries:
+            return
+        dead = [k for k, e in self.entries.items() if e[0]() is None]
+        for k in dead:
+            del self.entries[k]
+        if not self.entries:
+            return
+        key = tuple(self.entries)
+        if key != self.table_key:
+            jobs = [BnEvalJob(None if e[2] is None else e[2].data_ptr(), None if e[3] is None else e[3].data_ptr(),
+                              e[0]().data_ptr(), e[1].data_ptr(), e[4].data_ptr(), e[6], e[7]) for e in self.entries.values()]
+            arr = (BnEvalJob * len(jobs))(*jobs)
+            dev = next(iter(self.entries.values()))[4].device
+            if any(e[4].device != dev for e in self.entries.values()):
+                return                       # layers on several devices: the single launches stay
+            self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            self.table_key = key
+            self.max_c = max(e[6] for e in self.entries.values())
+        check(lib().ssa_bn_finalize_eval_batched(_p(self.table), len(self.entries), self.max_c, _s()),
+              "ssa_bn_finalize_eval_batched")
+        for e in self.entries.values():
+            e[5] = self.gen
+
+    def get(self, meta, gamma, beta, C, device):
+        """The layer's [4, C] coefficient buffer, current for this forward; None: not cacheable (the caller computes)."""
+        rm, rv = meta.running_mean, meta.running_var
+        ok = lambda t: t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.device == device)  # noqa: E731
+        if rm is None or rv is None or not (ok(rm) and ok(rv) and ok(gamma) and ok(beta)):
+            return None
+        key = (rm.data_ptr(), rv.data_ptr(), 0 if gamma is None else gamma.data_ptr(), 0 if beta is None else beta.data_ptr(),
+               float(meta.eps))
+        e = self.entries.get(key)
+        if e is None or e[0]() is not rm or e[6] != C:
+            e = self.entries[key] = [weakref.ref(rm), rv, gamma, beta,
+                                     torch.empty((4, C), dtype=torch.float32, device=device), -1, C, float(meta.eps)]
+            self.table_key = None
+        self.uses += 1
+        if e[5] != self.gen:
+            coef = e[4]
+            check(lib().ssa_bn_finalize(None, 1.0, C, _p(gamma), _p(beta), _p(rm), _p(rv), float(meta.momentum),
+                                        float(meta.eps), 1, _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _s()),
+                  "ssa_bn_finalize")
+            e[5] = self.gen
+        return e[4]
+
+
+_BN_EVAL = _BnEvalCoefs()
+
+
 def end_forward():
     """Apply the running-statistics updates of every BatchNorm that ran in training
     mode since begin_step (one launch, passes in issue order)."""
@@ -409,6 +482,7 @@ def end_forward():
 def begin_step(device=None):
     _BN_UPDATES.step = {}
     _PENDING_STATS.clear()
+    _BN_EVAL.begin()
     if _GRADS.armed or _WGRAD_Q or _GRADS.slots or _GRADS.chunks:
         # a backward pass that raised never ran its end-of-backward callback (or raised inside it): its queued
         # weight-gradient jobs and its half-filled gradient slices are abandoned here -- otherwise the arena would
@@ -1185,7 +1259,8 @@ def _allreduce_sums(sums_list):
 
 class BnMeta:
     """Non-tensor description of one BatchNorm call (built by the operator surface)."""
-    __slots__ = ("momentum", "eps", "training", "relu", "sync", "pass_stats", "running_mean", "running_var", "nbt", "out")
+    __slots__ = ("momentum", "eps", "training", "relu", "sync", "pass_stats", "running_mean", "running_var", "nbt", "out",
+                 "infer")
 
     def __init__(self, momentum, eps, training, relu, sync, pass_stats, running_mean, running_var, nbt=None):
         # training: running_mean/var/nbt given = updated by the normalisation kernel itself (one pass
@@ -1193,6 +1268,9 @@ class BnMeta:
         self.momentum, self.eps, self.training, self.relu, self.sync = momentum, eps, training, relu, sync
         self.pass_stats, self.running_mean, self.running_var, self.nbt = pass_stats, running_mean, running_var, nbt
         self.out = None       # where z goes: a [B,H,W,C] channel slice of a wider buffer (ops.cat_slots), else a new tensor
+        # built with autograd off (inside Function.forward grad mode is ALWAYS off, and needs_input_grad only says that
+        # the parameters could take a gradient): nothing will ask this call for a backward pass
+        self.infer = not torch.is_grad_enabled()
 
 
 def _bn_out(m, shape, device):
@@ -1469,12 +1547,15 @@ class BnActGroupFn(torch.autograd.Function):
         else:
             masks = [None] * n
             zs, coefs, counts, worlds = [], [], [], [0] * n
-            for i in range(n):
+            cached = all(m.infer for m in metas)     # (under autograd the coefficients are saved for a backward pass:
+            for i in range(n):                       # a later refresh in place must not reach them)
                 C = xs[i].shape[3]
-                coef = torch.empty((4, C), dtype=torch.float32, device=xs[i].device)
-                check(L.ssa_bn_finalize(None, 1.0, C, _p(gs[i]), _p(bs[i]), _p(metas[i].running_mean),
-                                        _p(metas[i].running_var), float(metas[i].momentum), float(metas[i].eps), 1,
-                                        _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _s()), "ssa_bn_finalize")
+                coef = _BN_EVAL.get(metas[i], gs[i], bs[i], C, xs[i].device) if cached else None
+                if coef is None:
+                    coef = torch.empty((4, C), dtype=torch.float32, device=xs[i].device)
+                    check(L.ssa_bn_finalize(None, 1.0, C, _p(gs[i]), _p(bs[i]), _p(metas[i].running_mean),
+                                            _p(metas[i].running_var), float(metas[i].momentum), float(metas[i].eps), 1,
+                                            _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _s()), "ssa_bn_finalize")
                 coefs.append(coef)
                 counts.append(float(xs[i].shape[0] * xs[i].shape[1] * xs[i].shape[2]))
             with group():

@@ -704,6 +704,68 @@ def test_bn_eval():
     check_close("bn_eval", nchw(z.float()), y)
 
 
+def test_bn_eval_coefficient_registry():
+    """Inference forwards take their BatchNorm coefficients from persistent buffers: computed singly the first time a
+    layer is seen, refreshed by ONE batched launch at the next begin_step -- and never stale: running statistics and
+    affine parameters changed between two forwards (as a training step does, through raw pointers: no version counter
+    moves) reach the next forward; under autograd the registry is not used."""
+    from oracle import ops as O
+    hb = _hb()
+    B, H, W = 1, 7, 9
+    layers = []
+    for k, C in enumerate((48, 64, 720)):
+        g = torch.Generator().manual_seed(40 + k)
+        layers.append(dict(C=C, x=_rand(B, C, H, W, seed=50 + k), gamma=torch.rand(C, generator=g) + 0.5,
+                           beta=torch.randn(C, generator=g) * 0.1, rm=torch.randn(C, generator=g) * 0.2,
+                           rv=torch.rand(C, generator=g) + 0.5))
+    for l in layers:
+        l["dev"] = {k: l[k].to(DEV) for k in ("gamma", "beta", "rm", "rv")}
+        l["xd"] = _to_dev_nhwc(l["x"])
+
+    def forward():
+        hb.begin_step()
+        with torch.no_grad():
+            return [hb.BatchNormActFn.apply(l["xd"], l["dev"]["gamma"], l["dev"]["beta"], None, None, l["dev"]["rm"],
+                                            l["dev"]["rv"], None, 0.1, 1e-5, False, True, False) for l in layers]
+
+    def check(zs, tag):
+        torch.cuda.synchronize()
+        for l, z in zip(layers, zs):
+            d = l["dev"]
+            want = torch.relu(O.batch_norm(l["x"], d["gamma"].cpu(), d["beta"].cpu(), d["rm"].cpu().clone(), d["rv"].cpu().clone(), False))
+            check_close("bn_eval registry %s C=%d" % (tag, l["C"]), nchw(z.float()), want)
+
+    reg = hb._BN_EVAL
+    z1 = forward()                                   # first sight: single launches, registered
+    check(z1, "first")
+    mine = [l["dev"]["rm"] for l in layers]
+    assert sum(any(e[0]() is t for t in mine) for e in reg.entries.values()) == 3
+    z2 = forward()                                   # the batched refresh
+    check(z2, "batched")
+    assert reg.table is not None and all(e[5] == reg.gen for e in reg.entries.values())
+    for a, b in zip(z1, z2):
+        assert torch.equal(a, b)
+    for l in layers:                                 # what a training step does to a layer, behind autograd's back
+        d = l["dev"]
+        d["rm"].data.mul_(1.5).add_(0.1)
+        d["rv"].data.mul_(0.5).add_(0.2)
+        d["gamma"].data.mul_(-0.75)
+    z3 = forward()
+    check(z3, "after an update")
+    assert not torch.equal(z3[0], z2[0])
+    hb.begin_step()                                  # a forward that used no inference BatchNorm (a training forward) ...
+    hb.begin_step()
+    for l in layers:
+        l["dev"]["beta"].data.add_(0.25)
+    check(forward(), "after a training forward")    # ... then the single launches again, still current
+    # under autograd: fresh coefficients per call, the registry untouched
+    uses = reg.uses
+    xg = layers[0]["xd"].clone().requires_grad_(True)
+    d = layers[0]["dev"]
+    z = hb.BatchNormActFn.apply(xg, d["gamma"], d["beta"], None, None, d["rm"], d["rv"], None, 0.1, 1e-5, False, True, False)
+    assert z.requires_grad and reg.uses == uses
+
+
 # ---------------------------------------------------------------- pooling
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 48, 64), (1, 64, 33, 47), (1, 8, 5, 7)])
 def test_maxpool3x3s2(B, C, H, W):

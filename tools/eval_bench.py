@@ -76,6 +76,8 @@ if __name__ == "__main__":
             [0.25, 0.5, 1.0, 2.0], 1632, 2177, iters, classes=65)
         sys.exit(0)
     run("configs[1] HRNet-OCR single-scale eval", "ocrnet.HRNet", None, 1024, 2048, iters)
+    if len(sys.argv) > 2 and sys.argv[2] == "c1":          # (profiling runs: the single-scale row only)
+        sys.exit(0)
     run("configs[2] HRNet-OCR-MScale {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1024, 2048, iters)
     run("configs[4] Mapillary 65 classes {0.5,1.0,2.0} eval", "ocrnet.HRNet_Mscale", [0.5, 1.0, 2.0], 1536, 2048, iters,
         classes=65)
