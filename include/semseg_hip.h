@@ -140,6 +140,10 @@ int ssa_conv2d_tile_aux(const ssa_conv_desc* d, const void* x, const void* w_fra
  * the next halo in flight during the MFMAs, a register-only epilogue (swapped MFMA operands + v_permlane32_swap) and
  * the BatchNorm statistics in registers over the strip; three workgroups per CU.  No bias (SSA_EUNSUPPORTED).
  * stats / aux / aux_mode / coef as ssa_conv2d_tile_aux (aux_mode 0: none).
+ * aux_mode 3 / 4 (inference; stats NULL): the conv's BatchNorm in evaluation mode as the epilogue -- z = scale * y + shift
+ * (+ aux, the residual tile, when given), 4: followed by the ReLU; coef = the layer's [4][Cout] table (rows 0, 1 = scale,
+ * shift: ssa_bn_finalize / ssa_bn_finalize_eval_batched); y is rounded to 16 bits first, so z equals ssa_bn_apply on the
+ * stored conv output bit for bit.  conv -> bn -> relu of network/hrnetv2.py:37-66 in eval() as one launch.
  * ssa_conv_tile_strip(units): work (in units of one 128-pixel tile x one 48-channel chunk x one n-block = 27 MFMAs
  * per wave) a workgroup of the calling thread's NEXT launches should carry -- the caller of a grouped level knows the
  * level's total; 0 = derive from each problem alone.                                                              */

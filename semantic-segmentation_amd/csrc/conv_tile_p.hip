@@ -51,6 +51,7 @@ struct TilePArgs {
   const bf16_t* aux; const float* coef;                    // epilogue tile; [4][Cout] table of aux_mode 2
   int ldx, Cin, ldy, H, W, Cout, nb_total, tiles_x, tiles_y, ldaux;
   int total_tiles, tiles_per_wg, ngroups, nwg;
+  int relu;                                                 // aux_mode 3 / 4
 };
 
 // Bijective XCD-aware order (block b runs on XCD b % 8): XCD x gets one contiguous range of work items.
@@ -103,7 +104,11 @@ __device__ __forceinline__ float half_sum32(float v) {
 
 template <int NB, int TPC, int AUXM>
 struct ConvTileP {
-  static constexpr bool AUX = AUXM != 0;
+  // aux_mode 3 / 4 (inference): the conv's BatchNorm as the epilogue -- z = act(scale * y + shift [+ residual]) with
+  // y the 16-bit-rounded conv output, i.e. bit for bit what the separate apply pass computes from the stored y;
+  // 3: no residual, 4: residual tile in `aux`.  The ReLU is a run-time flag.
+  static constexpr bool AUX = AUXM == 1 || AUXM == 2 || AUXM == 4;
+  static constexpr bool AFFINE = AUXM >= 3;
   typedef TilePArgs Args;
   static constexpr int NT = 256;
   static constexpr int CK = 48;                      // input channels per unit
@@ -245,10 +250,11 @@ struct ConvTileP {
     // n-block nb and m = 0, 1, the 16-byte piece of channels  nb0*32 + nb*32 + 16*m + 8*(lane >> 5) .. + 7
     const int eh = lane >> 5, epx = lane & 31;
     const int ech = nb0 * 32 + 8 * eh;                            // first channel of piece (nb 0, m 0)
-    float S[AUXM == 1 ? 1 : NAUX * 8], Q[AUXM == 1 ? 1 : NAUX * 8];  // statistics of this lane's channels over the strip
+    constexpr int NSTAT = (AUXM == 1 || AFFINE) ? 1 : NAUX * 8;
+    float S[NSTAT], Q[NSTAT];  // statistics of this lane's channels over the strip
 #pragma unroll
-    for (int j = 0; j < (AUXM == 1 ? 1 : NAUX * 8); ++j) { S[j] = 0.f; Q[j] = 0.f; }
-    if constexpr (AUXM == 2) {
+    for (int j = 0; j < NSTAT; ++j) { S[j] = 0.f; Q[j] = 0.f; }
+    if constexpr (AUXM == 2 || AFFINE) {
       for (int i = tid; i < 2 * NB * 32; i += NT) {
         const int k = i / (NB * 32), c = nb0 * 32 + i - k * (NB * 32);
         ctab[i] = c < Cout ? coef[k * Cout + c] : 0.f;
@@ -398,6 +404,28 @@ struct ConvTileP {
 #pragma unroll
               for (int j = 0; j < 8; ++j) f[j] += xv[j];
               o = pack8(f);
+            } else if constexpr (AFFINE) {
+              float f[8];
+              unpack8(o, f);
+              const float4 ma0 = *reinterpret_cast<const float4*>(ctab + coff + 8 * eh);
+              const float4 ma1 = *reinterpret_cast<const float4*>(ctab + coff + 8 * eh + 4);
+              const float4 mb0 = *reinterpret_cast<const float4*>(ctab + NB * 32 + coff + 8 * eh);
+              const float4 mb1 = *reinterpret_cast<const float4*>(ctab + NB * 32 + coff + 8 * eh + 4);
+              const float ma[8] = {ma0.x, ma0.y, ma0.z, ma0.w, ma1.x, ma1.y, ma1.z, ma1.w};
+              const float mb[8] = {mb0.x, mb0.y, mb0.z, mb0.w, mb1.x, mb1.y, mb1.z, mb1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] = f[j] * ma[j] + mb[j];          // (the arithmetic of bn_apply_rows)
+              if constexpr (AUXM == 4) {
+                float xv[8];
+                unpack8(auxv[p], xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] += xv[j];
+              }
+              if (a.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+              }
+              o = pack8(f);
             } else if constexpr (AUXM == 2) {
               float f[8], xv[8];
               unpack8(o, f);
@@ -438,8 +466,8 @@ struct ConvTileP {
       for (int i = 0; i < 24 * 8; ++i) tdbg[i] = i < n_iter * 8 ? tlds[i] : 0;
 #endif
     // ---- statistics of the strip: 32 pixel lanes -> wave -> workgroup -> one fp64 atomic per channel
-    if constexpr (AUXM == 1) {
-      return;          // residual add: no statistics (stats is NULL by contract)
+    if constexpr (AUXM == 1 || AFFINE) {
+      return;          // residual add / inference epilogue: no statistics (stats is NULL by contract)
     } else {
       if (stats == nullptr) return;
 #pragma unroll
@@ -539,8 +567,12 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* w_frag
   if (!ssa_conv2d_tile_p_supported(dp) || bias) return SSA_EUNSUPPORTED;   // the trunk convs have no bias (hrnetv2.py:31-34)
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w_frag)) & 15u)
     return SSA_EINVAL;
-  if (aux_mode < 0 || aux_mode > 2) return SSA_EINVAL;
-  if (aux_mode && (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u))) return SSA_EINVAL;
+  if (aux_mode < 0 || aux_mode > 4) return SSA_EINVAL;
+  // 3 / 4: the conv's inference BatchNorm as the epilogue (coef = its [4][Cout] table), 4 with the ReLU; aux = the
+  // residual tile or NULL
+  const bool affine = aux_mode >= 3;
+  if (affine && (!coef || stats)) return SSA_EINVAL;
+  if ((aux_mode == 1 || aux_mode == 2 || (affine && aux)) && (!aux || ldaux % 8 || (reinterpret_cast<uintptr_t>(aux) & 15u))) return SSA_EINVAL;
   if (aux_mode == 2 && (!coef || !stats)) return SSA_EINVAL;
   if (aux_mode == 1 && stats) return SSA_EINVAL;
   if (dp->ldy % 8) return SSA_EINVAL;
@@ -550,12 +582,14 @@ int ssa_conv2d_tile_p(const ssa_conv_desc* dp, const void* x, const void* w_frag
   a.y = (bf16_t*)y; a.stats = stats; a.aux = (const bf16_t*)aux; a.coef = coef;
   a.ldx = d.ldx; a.Cin = d.Cin; a.ldy = d.ldy; a.H = d.H; a.W = d.W; a.Cout = d.Cout;
   a.ldaux = ldaux;
+  a.relu = aux_mode == 4;
   a.nb_total = a.tiles_x = a.tiles_y = a.total_tiles = a.tiles_per_wg = a.ngroups = a.nwg = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (aux_mode) {
     case 0: return launch_p<0>(d, a, s);
     case 1: return launch_p<1>(d, a, s);
-    default: return launch_p<2>(d, a, s);
+    case 2: return launch_p<2>(d, a, s);
+    default: return aux ? launch_p<4>(d, a, s) : launch_p<3>(d, a, s);
   }
 }
 

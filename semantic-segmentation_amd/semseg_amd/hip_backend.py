@@ -1521,6 +1521,62 @@ def _dz_bf16(dz, C):
     return dz, lddz
 
 
+# --------------------------------------------------------------------------
+# inference: conv -> BatchNorm(eval) [+ residual] [-> ReLU] as ONE launch (the trunk's 3x3 convs)
+# --------------------------------------------------------------------------
+_FUSE_EVAL_BN = os.environ.get("SSA_FUSE_EVAL_BN", "1") != "0"
+
+
+def conv_bn_infer_group(convs, metas, gammas, betas, xs, ress, relus):
+    """For every problem ssa_conv2d_tile_p takes (3x3, stride 1, pad 1, no bias, 48 / 96 / 192 / 384 input channels --
+    the HRNet trunk), with autograd off and the BatchNorm in evaluation mode: the normalisation, the residual add and
+    the ReLU are the conv kernel's epilogue (aux_mode 3 / 4: bit for bit what ssa_bn_apply computes from the stored
+    conv output, which is then neither written nor read back).  Returns a list with the result per problem, None
+    where the problem is not eligible (the caller runs conv and BatchNorm separately for those)."""
+    n = len(xs)
+    outs = [None] * n
+    if not _FUSE_EVAL_BN:
+        return outs
+    jobs = []
+    for i in range(n):
+        conv, m = convs[i], metas[i]
+        if m.training or not m.infer or conv.bias is not None or tuple(conv.kernel_size) != (3, 3) or \
+                conv.stride[0] != 1 or conv.padding[0] != 1 or conv.dilation[0] != 1 or getattr(conv, "groups", 1) != 1:
+            continue
+        x = xs[i]
+        if x.dtype != ACT_DTYPE:
+            continue
+        x, ldx = _pixels(x)
+        B, H, W, Cin = x.shape
+        w = conv.weight
+        Cout = w.shape[0]
+        if w.shape[1] != Cin or Cout % 8 or x.data_ptr() % 16:
+            continue
+        td = _tile_desc(B, H, W, Cin, ldx, Cout, (3, 3), 1, 1, 1, H, W, False)
+        if not tile_p_supported(td):
+            continue
+        res, ldr = (None, 0)
+        if ress[i] is not None:
+            if ress[i].dtype != ACT_DTYPE or tuple(ress[i].shape) != (B, H, W, Cout):
+                continue
+            res, ldr = _pixels(ress[i])
+            if ldr % 8 or res.data_ptr() % 16:
+                continue
+        g = gammas[i].detach() if gammas[i] is not None else None
+        b = betas[i].detach() if betas[i] is not None else None
+        coef = _BN_EVAL.get(m, g, b, Cout, x.device)
+        if coef is None:
+            continue
+        jobs.append((i, td, x, w, res, ldr, coef, 4 if relus[i] else 3))
+    if not jobs:
+        return outs
+    with group(), tile_strip([j[1] for j in jobs]):
+        for i, td, x, w, res, ldr, coef, mode in jobs:
+            wp, _ = _packed_filter(w, 2, td.Cin, 0)
+            outs[i] = _tile_conv(td, x, wp, None, None, aux=res, ldaux=ldr, coef=coef, mode=mode)
+    return outs
+
+
 class BnActGroupFn(torch.autograd.Function):
     """z = post * act(bn(x) + residual) for N independent problems.
     metas[i]: BnMeta; tensors = (x_0, gamma_0, beta_0, residual_0, post_0, x_1, ...)."""

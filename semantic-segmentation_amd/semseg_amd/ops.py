@@ -196,12 +196,30 @@ class HipBackend(BackendBase):
 
     def _conv_bn_group(self, convs, bns, xs, residual=None, relu=False, post=None, outs=None):
         n = len(xs)
+        ress, relus, posts = _lst(residual, n), _lst(relu, n), _lst(post, n)
+        if not torch.is_grad_enabled() and outs is None and not any(b.training for b in bns) and \
+                all(po is None for po in posts):
+            # inference: the trunk's 3x3 convs carry their BatchNorm (+ residual, ReLU) as the epilogue -- one launch
+            # instead of two and no round trip of the conv output through HBM (hip_backend.conv_bn_infer_group)
+            metas = [self._bn_meta(b, r) for b, r in zip(bns, relus)]
+            zs = self.hb.conv_bn_infer_group(convs, metas, [b.weight for b in bns], [b.bias for b in bns], xs, ress, relus)
+            rest = [i for i in range(n) if zs[i] is None]
+            if rest and len(rest) < n:
+                sub = self._conv_bn_unfused([convs[i] for i in rest], [bns[i] for i in rest], [xs[i] for i in rest],
+                                            [ress[i] for i in rest], [relus[i] for i in rest], [None] * len(rest), None)
+                for i, z in zip(rest, sub):
+                    zs[i] = z
+            if not rest or len(rest) < n:
+                return zs
+        return self._conv_bn_unfused(convs, bns, xs, ress, relus, posts, outs)
+
+    def _conv_bn_unfused(self, convs, bns, xs, ress, relus, posts, outs):
         spec = tuple((c.stride[0], c.padding[0], c.dilation[0], False, bool(b.training)) for c, b in zip(convs, bns))
         flat = []
         for xi, c in zip(xs, convs):
             flat += [xi, c.weight, c.bias]
         ys = self.hb.ConvGroupFn.apply(spec, *flat)
-        return self._bn_group(list(ys), bns, _lst(residual, n), _lst(relu, n), _lst(post, n), outs)
+        return self._bn_group(list(ys), bns, ress, relus, posts, outs)
 
     def basic_block(self, blocks, xs):
         ok = torch.is_grad_enabled() and all(

@@ -413,3 +413,81 @@ def test_conv_bn_into_cat_slots_equals_torch_cat(training):
         assert torch.equal(p, q), ("forward tensor %d differs" % i, float((p - q).abs().max()))
     for i, (p, q) in enumerate(zip(g1, g0)):
         check_close("cat-slot gradient %d" % i, p, q, 1e-6, 1e-6)
+
+
+def test_inference_conv_bn_as_one_launch_equals_the_two_launches():
+    """Inference (autograd off, BatchNorm in evaluation mode): the trunk's 3x3 convs carry normalisation, residual add
+    and ReLU as their epilogue (ssa_conv2d_tile_p aux_mode 3 / 4, hip_backend.conv_bn_infer_group).  The epilogue works on
+    the 16-bit-rounded conv output with the apply pass's own arithmetic, so the result must equal conv -> ssa_bn_apply
+    BIT FOR BIT -- for a BasicBlock level as the evaluation forward issues it (conv1: ReLU, conv2: residual + ReLU),
+    without ReLU, with ragged tiles, and next to problems the fused kernel does not take (64 channels, a 1x1 conv, a
+    biased conv), which must come out of the same call through the separate launches."""
+    from semseg_amd import ops, nn as snn
+    hb = _hb()
+    be = ops.HipBackend()
+    level = [(48, 40, 36), (96, 20, 18), (192, 17, 33), (384, 16, 16), (64, 24, 24)]
+
+    def build():
+        torch.manual_seed(11)
+        convs = [snn.Conv2d(C, C, 3, padding=1, bias=False) for C, _, _ in level]
+        convs += [snn.Conv2d(48, 96, 1, bias=False), snn.Conv2d(96, 96, 3, padding=1, bias=True)]
+        bns = [snn.BatchNorm2d(c.out_channels) for c in convs]
+        for i, b in enumerate(bns):
+            g = torch.Generator().manual_seed(200 + i)
+            b.running_mean.copy_(torch.randn(b.num_features, generator=g) * 0.2)
+            b.running_var.copy_(torch.rand(b.num_features, generator=g) + 0.5)
+            b.weight.data.copy_(torch.rand(b.num_features, generator=g) + 0.5)
+            b.bias.data.copy_(torch.randn(b.num_features, generator=g) * 0.1)
+        mods = torch.nn.ModuleList(convs + bns).to(DEV).eval()
+        return list(mods[:len(convs)]), list(mods[len(convs):])
+
+    xs = [_dev(_rand(1, C, H, W, seed=300 + i)) for i, (C, H, W) in enumerate(level)]
+    xs += [_dev(_rand(1, 48, 12, 20, seed=310)), _dev(_rand(1, 96, 20, 18, seed=311))]
+    ress = [_dev(_rand(1, C, H, W, seed=320 + i)) for i, (C, H, W) in enumerate(level)] + [None, None]
+
+    def run(fused):
+        convs, bns = build()
+        hb.clear_pack_cache()
+        old = hb._FUSE_EVAL_BN
+        hb._FUSE_EVAL_BN = fused
+        try:
+            outs = []
+            with torch.no_grad():
+                for _ in range(2):                  # second forward: coefficients from the batched refresh
+                    hb.begin_step(torch.device(DEV))
+                    a = be.conv_bn_act(convs, bns, xs, relu=True)
+                    b = be.conv_bn_act(convs, bns, xs, residual=ress, relu=True)
+                    c = be.conv_bn_act(convs, bns, xs, residual=ress, relu=False)
+                    be.end_forward()
+                    outs = list(a) + list(b) + list(c)
+            if DEV == "cuda":
+                torch.cuda.synchronize()
+            return [t.float().cpu() for t in outs]
+        finally:
+            hb._FUSE_EVAL_BN = old
+
+    modes = []
+    tile_conv = hb._tile_conv
+
+    def spy(*a, **k):
+        modes.append(k.get("mode", 0))
+        return tile_conv(*a, **k)
+    hb._tile_conv = spy
+    try:
+        two = run(False)
+        assert not any(m >= 3 for m in modes)
+        del modes[:]
+        one = run(True)
+    finally:
+        hb._tile_conv = tile_conv
+    # two forwards x (ReLU, residual + ReLU, residual) x the four trunk problems went through the epilogue
+    assert sum(m == 4 for m in modes) == 2 * 2 * 4 and sum(m == 3 for m in modes) == 2 * 4, modes
+    for i, (a, b) in enumerate(zip(one, two)):
+        assert torch.equal(a, b), "output %d: max |diff| %g" % (i, float((a - b).abs().max()))
+    assert all(float(t.abs().max()) > 0.1 for t in one)
+    # under autograd the separate launches stay (the backward wants the conv output)
+    convs, bns = build()
+    hb.begin_step(torch.device(DEV))
+    x = xs[0].clone().requires_grad_(True)
+    z = be.conv_bn_act(convs[0], bns[0], x, relu=True)
+    assert z.requires_grad

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}" || exit 1
 export TMPDIR=/tmp
 T=${1:-r6ev}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py tests/test_graphed_step_gpu.py tests/test_siblings_gpu.py tests/test_attnscale_gpu.py tests/test_deepv3_gpu.py -q -x -m gpu > gpurun_out/${T}_tests.log 2>&1
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_group_gpu.py tests/test_e2e_gpu.py tests/test_graphed_step_gpu.py tests/test_siblings_gpu.py tests/test_attnscale_gpu.py tests/test_deepv3_gpu.py -q -x -m gpu > gpurun_out/${T}_tests.log 2>&1
 echo "tests rc=$?"; tail -3 gpurun_out/${T}_tests.log
 timeout 600 python -m pytest tests/test_parity_eval_gpu.py tests/test_fp16_storage_gpu.py -q -x -m gpu > gpurun_out/${T}_parity_eval.log 2>&1
 echo "eval parity rc=$?"; tail -3 gpurun_out/${T}_parity_eval.log
