@@ -189,6 +189,14 @@ int ssa_conv2d_halo_reg(const ssa_conv_desc* d, const void* x, const void* w_fra
 /* Tile configuration ssa_conv2d_igemm would use for this problem
  * (0: 128x128, 1: 256x64, 2: 128x96, 3: 256x32, 4: 64x64, 5: 128x64 tiles). */
 int ssa_conv2d_igemm_tile(const ssa_conv_desc* d);
+/* ssa_conv2d_igemm with the conv's BatchNorm in evaluation mode as the epilogue (inference): z = scale * y + shift
+ * (+ residual [B,Ho,Wo,Cout], pixel stride ldres) and, relu != 0, the ReLU; coef = the layer's [4][Cout] table (rows 0, 1);
+ * y = the conv output (+ bias) rounded to 16 bits first, so z equals ssa_bn_apply on the stored output bit for bit.
+ * 16-bit output, not transposed.  conv -> bn (-> relu) of the stem, layer1 and the fuse layers
+ * (network/hrnetv2.py:278-300, 192-222) in eval() as one launch.                                                  */
+int ssa_conv2d_igemm_affine(const ssa_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                            const float* coef, const void* residual, int ldres, int relu, void* stream);
+
 
 /* Data gradient of a 3x3, stride-2, pad-1 convolution (the fuse / transition / stem
  * down-convs of network/hrnetv2.py:218-250, 357-371; cuDNN's backward-data behind

@@ -65,6 +65,8 @@ struct IgemmArgs {
   // strided output (parity classes of a stride-2 data gradient, ssa_conv2d_dgrad_s2): GEMM row
   // m = (b, oy, ox) is stored at pixel b*o_HW + (oy*o_mul + o_py)*o_W + ox*o_mul + o_px; o_mul = 0: pixel m
   int o_mul, o_py, o_px, o_W, o_HW;
+  // inference epilogue (ssa_conv2d_igemm_affine): z = act(scale * y + shift [+ residual]) on the 16-bit-rounded y
+  const float* aff; const bf16_t* res; int ldres, relu;
 };
 
 // K-stage depth of the forward / data-gradient kernel: 64 for the small tiles.  Their launches are chains of
@@ -297,6 +299,37 @@ struct ConvIgemm {
     if (m >= M || n >= d.Cout) continue;
     bf16_t* dst = y + opix(m) * d.ldy + n;
     const bf16_t* src = Cs + row * LDC + cp * 8;
+    if (a.aff != nullptr) {
+      // the conv's inference BatchNorm (+ residual, ReLU) with the arithmetic of bn_apply_rows on the rounded output
+      const float* sc = a.aff + n;
+      const float* sh = a.aff + d.Cout + n;
+      const bf16_t* rp = a.res ? a.res + opix(m) * a.ldres + n : nullptr;
+      if (n + 8 <= d.Cout) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(src), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] * sc[j] + sh[j];
+        if (rp) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(rp), r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += r[j];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+        }
+        *reinterpret_cast<uint4*>(dst) = pack8(f);
+      } else {
+        for (int j = 0; n + j < d.Cout; ++j) {
+          float f = bf2f(src[j]) * sc[j] + sh[j];
+          if (rp) f += bf2f(rp[j]);
+          if (a.relu) f = fmaxf(f, 0.f);
+          dst[j] = f2bf(f);
+        }
+      }
+      continue;
+    }
     if (n + 8 <= d.Cout) {
       *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
     } else {
@@ -803,6 +836,8 @@ int choose_fwd_tile(long M, int N) {
 }
 
 struct OutMap { int mul, py, px, W, HW; };
+struct IgemmAffine { const float* aff; const bf16_t* res; int ldres, relu; };
+static thread_local IgemmAffine g_affine = {nullptr, nullptr, 0, 0};      // set around one launch by ssa_conv2d_igemm_affine
 
 template <int WGM, int WGN, int MI, int NI>
 int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float* bias, void* y,
@@ -818,6 +853,7 @@ int launch_fwd(const ssa_conv_desc& d, const void* x, const void* w, const float
   a.tiles_n = tiles_n; a.tr_shift = tr_shift;
   a.o_mul = om ? om->mul : 0; a.o_py = om ? om->py : 0; a.o_px = om ? om->px : 0;
   a.o_W = om ? om->W : 0; a.o_HW = om ? om->HW : 0;
+  a.aff = g_affine.aff; a.res = g_affine.res; a.ldres = g_affine.ldres; a.relu = g_affine.relu;
   return ssa::submit<ConvIgemm<WGM, WGN, MI, NI>>(a, tiles_m * tiles_n, 1, lds, s);
 }
 
@@ -891,6 +927,16 @@ int ssa_conv2d_igemm_stats(const ssa_conv_desc* dp, const void* x, const void* w
     case 5: return launch_fwd<2, 2, 2, 1>(d, x, w_packed, bias, y, s, tr_shift, stats);
     default: return SSA_EINVAL;
   }
+}
+
+int ssa_conv2d_igemm_affine(const ssa_conv_desc* dp, const void* x, const void* w_packed, const float* bias, void* y,
+                            const float* coef, const void* residual, int ldres, int relu, void* stream) {
+  if (!dp || !coef || dp->out_f32 || dp->transposed) return SSA_EINVAL;
+  if (residual && (ldres % 8 || !aligned16(residual))) return SSA_EINVAL;
+  g_affine = IgemmAffine{coef, (const bf16_t*)residual, ldres, relu ? 1 : 0};
+  const int rc = ssa_conv2d_igemm_stats(dp, x, w_packed, bias, y, nullptr, stream);
+  g_affine = IgemmAffine{nullptr, nullptr, 0, 0};
+  return rc;
 }
 
 int ssa_conv2d_dgrad_s2(int B, int H, int W, int Cin, int lddx, int Ho, int Wo, int cout_pad, int lddy,

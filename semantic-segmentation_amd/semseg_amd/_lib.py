@@ -119,6 +119,7 @@ _SIGS = {
     "ssa_pack_tile_channels": ([c_int, c_int], c_int),
     "ssa_conv2d_dgrad_s2": ([c_int] * 9 + [_P, _P, _P, _P, _P], c_int),
     "ssa_pack_filters_tiled": ([_P, _P, c_int, c_int, _P], c_int),
+    "ssa_conv2d_igemm_affine": ([POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize_eval_batched": ([_P, c_int, c_int, _P], c_int),
     "ssa_bn_finalize": ([_P, c_double, c_int, _P, _P, _P, _P, c_float, c_float, c_int,
                          _P, _P, _P, _P, _P], c_int),

@@ -657,7 +657,7 @@ def _conv_bytes(P_in, Cin, P_out, Cout, k, out_bytes=2):
 
 
 def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil, transposed, out_f32,
-           cfg=-1, stats=None, out=None):
+           cfg=-1, stats=None, out=None, affine=None):
     """Raw launch: x viewed as [B,H,W,Cin] (ldx) -> y [B,Ho,Wo,Cout] (`out`: a dense tensor of that size to write)."""
     B, H, W, Cin = geom_in
     Ho, Wo = geom_out
@@ -669,6 +669,11 @@ def _igemm(x, ldx, geom_in, wp, Kpad, bias, geom_out, Cout, k, stride, pad, dil,
     # algorithmic flops: taps that fall on the stride grid only (transposed) = forward flops
     taps = k[0] * k[1] / (stride * stride if transposed else 1)
     _note(2.0 * B * Ho * Wo * Cout * Cin * taps, _conv_bytes(B * H * W, Cin, B * Ho * Wo, Cout, k, 4 if out_f32 else 2))
+    if affine is not None:          # (coef, residual, ldres, relu): the inference BatchNorm as the epilogue
+        coef, res, ldres, relu = affine
+        check(lib().ssa_conv2d_igemm_affine(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _p(coef), _p(res), ldres,
+                                            int(relu), _s()), "ssa_conv2d_igemm_affine")
+        return y
     check(lib().ssa_conv2d_igemm_stats(ctypes.byref(d), _p(x), _p(wp), _p(bias), _p(y), _p(stats), _s()),
           "ssa_conv2d_igemm")
     return y
@@ -1528,11 +1533,15 @@ _FUSE_EVAL_BN = os.environ.get("SSA_FUSE_EVAL_BN", "1") != "0"
 
 
 def conv_bn_infer_group(convs, metas, gammas, betas, xs, ress, relus):
-    """For every problem ssa_conv2d_tile_p takes (3x3, stride 1, pad 1, no bias, 48 / 96 / 192 / 384 input channels --
-    the HRNet trunk), with autograd off and the BatchNorm in evaluation mode: the normalisation, the residual add and
-    the ReLU are the conv kernel's epilogue (aux_mode 3 / 4: bit for bit what ssa_bn_apply computes from the stored
-    conv output, which is then neither written nor read back).  Returns a list with the result per problem, None
-    where the problem is not eligible (the caller runs conv and BatchNorm separately for those)."""
+    """Inference (autograd off, BatchNorm in evaluation mode): normalisation, residual add and ReLU as the EPILOGUE of
+    the conv kernel, for the problems of a grouped call that run on
+      * ssa_conv2d_tile_p (3x3, stride 1, pad 1, no bias, 48 / 96 / 192 / 384 input channels: the HRNet trunk;
+        aux_mode 3 / 4), or
+      * the implicit-GEMM kernel (whatever the halo / wide kernels do not take: stem, layer1's 1x1 convs, the fuse
+        layers' 1x1 and stride-2 convs; ssa_conv2d_igemm_affine).
+    Both work on the 16-bit-rounded conv output with ssa_bn_apply's arithmetic: bit for bit the result of the two
+    launches, whose conv output is then neither written nor read back.  Returns a list with the result per problem,
+    None where the problem is not eligible (the caller runs conv and BatchNorm separately for those)."""
     n = len(xs)
     outs = [None] * n
     if not _FUSE_EVAL_BN:
@@ -1540,24 +1549,24 @@ def conv_bn_infer_group(convs, metas, gammas, betas, xs, ress, relus):
     jobs = []
     for i in range(n):
         conv, m = convs[i], metas[i]
-        if m.training or not m.infer or conv.bias is not None or tuple(conv.kernel_size) != (3, 3) or \
-                conv.stride[0] != 1 or conv.padding[0] != 1 or conv.dilation[0] != 1 or getattr(conv, "groups", 1) != 1:
+        if m.training or not m.infer or getattr(conv, "groups", 1) != 1 or xs[i].dtype != ACT_DTYPE:
             continue
-        x = xs[i]
-        if x.dtype != ACT_DTYPE:
-            continue
-        x, ldx = _pixels(x)
+        x, ldx = _pixels(xs[i])
         B, H, W, Cin = x.shape
         w = conv.weight
-        Cout = w.shape[0]
-        if w.shape[1] != Cin or Cout % 8 or x.data_ptr() % 16:
+        Cout, Cin_real, KH, KW = w.shape
+        stride, pad, dil = conv.stride[0], conv.padding[0], conv.dilation[0]
+        if Cin < Cin_real or Cin % 8 or Cout % 8 or x.data_ptr() % 16 or w.dtype != torch.float32:
             continue
-        td = _tile_desc(B, H, W, Cin, ldx, Cout, (3, 3), 1, 1, 1, H, W, False)
-        if not tile_p_supported(td):
-            continue
+        Ho = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        td = _tile_desc(B, H, W, Cin, ldx, Cout, (KH, KW), stride, pad, dil, Ho, Wo, False)
+        on_tile_p = conv.bias is None and tile_p_supported(td)
+        if not on_tile_p and (tile_supported(td) or wide_supported(td) or halo_supported(td)):
+            continue                                    # conv_tile.hip / the head kernels: no such epilogue (yet)
         res, ldr = (None, 0)
         if ress[i] is not None:
-            if ress[i].dtype != ACT_DTYPE or tuple(ress[i].shape) != (B, H, W, Cout):
+            if ress[i].dtype != ACT_DTYPE or tuple(ress[i].shape) != (B, Ho, Wo, Cout):
                 continue
             res, ldr = _pixels(ress[i])
             if ldr % 8 or res.data_ptr() % 16:
@@ -1567,13 +1576,23 @@ def conv_bn_infer_group(convs, metas, gammas, betas, xs, ress, relus):
         coef = _BN_EVAL.get(m, g, b, Cout, x.device)
         if coef is None:
             continue
-        jobs.append((i, td, x, w, res, ldr, coef, 4 if relus[i] else 3))
+        bias = None
+        if conv.bias is not None:
+            bias = conv.bias.detach()
+            if bias.dtype != torch.float32:
+                continue
+        jobs.append((i, on_tile_p, td, x, ldx, w, bias, res, ldr, coef, bool(relus[i]), (Ho, Wo), (KH, KW), stride, pad, dil))
     if not jobs:
         return outs
-    with group(), tile_strip([j[1] for j in jobs]):
-        for i, td, x, w, res, ldr, coef, mode in jobs:
-            wp, _ = _packed_filter(w, 2, td.Cin, 0)
-            outs[i] = _tile_conv(td, x, wp, None, None, aux=res, ldaux=ldr, coef=coef, mode=mode)
+    with group(), tile_strip([j[2] for j in jobs if j[1]]):
+        for i, on_tile_p, td, x, ldx, w, bias, res, ldr, coef, relu, ohw, k, stride, pad, dil in jobs:
+            if on_tile_p:
+                wp, _ = _packed_filter(w, 2, td.Cin, 0)
+                outs[i] = _tile_conv(td, x, wp, None, None, aux=res, ldaux=ldr, coef=coef, mode=4 if relu else 3)
+            else:
+                wp, Kpad = _packed_filter(w, 0, td.Cin, 0)
+                outs[i] = _igemm(x, ldx, (td.B, td.H, td.W, td.Cin), wp, Kpad, bias, ohw, td.Cout, k, stride, pad, dil,
+                                 False, False, affine=(coef, res, ldr, relu))
     return outs
 
 

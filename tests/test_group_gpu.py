@@ -430,7 +430,8 @@ def test_inference_conv_bn_as_one_launch_equals_the_two_launches():
     def build():
         torch.manual_seed(11)
         convs = [snn.Conv2d(C, C, 3, padding=1, bias=False) for C, _, _ in level]
-        convs += [snn.Conv2d(48, 96, 1, bias=False), snn.Conv2d(96, 96, 3, padding=1, bias=True)]
+        convs += [snn.Conv2d(48, 96, 1, bias=False), snn.Conv2d(96, 96, 3, padding=1, bias=True),
+                  snn.Conv2d(48, 96, 3, stride=2, padding=1, bias=False), snn.Conv2d(40, 72, 1, bias=True)]
         bns = [snn.BatchNorm2d(c.out_channels) for c in convs]
         for i, b in enumerate(bns):
             g = torch.Generator().manual_seed(200 + i)
@@ -442,8 +443,12 @@ def test_inference_conv_bn_as_one_launch_equals_the_two_launches():
         return list(mods[:len(convs)]), list(mods[len(convs):])
 
     xs = [_dev(_rand(1, C, H, W, seed=300 + i)) for i, (C, H, W) in enumerate(level)]
-    xs += [_dev(_rand(1, 48, 12, 20, seed=310)), _dev(_rand(1, 96, 20, 18, seed=311))]
-    ress = [_dev(_rand(1, C, H, W, seed=320 + i)) for i, (C, H, W) in enumerate(level)] + [None, None]
+    xs += [_dev(_rand(1, 48, 12, 20, seed=310)), _dev(_rand(1, 96, 20, 18, seed=311)), _dev(_rand(1, 48, 21, 19, seed=312)),
+           _dev(_rand(2, 40, 7, 9, seed=313))]
+    # (the 1x1, the stride-2 and the biased 40 -> 72 conv run on the implicit-GEMM kernel: epilogue there too, the last
+    # two with a residual of the OUTPUT's shape; 64 channels and the biased 3x3 run on conv_tile.hip: two launches)
+    ress = [_dev(_rand(1, C, H, W, seed=320 + i)) for i, (C, H, W) in enumerate(level)] + \
+        [None, None, _dev(_rand(1, 96, 11, 10, seed=330)), _dev(_rand(2, 72, 7, 9, seed=331))]
 
     def run(fused):
         convs, bns = build()
@@ -466,20 +471,25 @@ def test_inference_conv_bn_as_one_launch_equals_the_two_launches():
         finally:
             hb._FUSE_EVAL_BN = old
 
-    modes = []
-    tile_conv = hb._tile_conv
+    modes, affine = [], []
+    tile_conv, igemm = hb._tile_conv, hb._igemm
+
+    def spy_igemm(*a, **k):
+        affine.append(k.get("affine") is not None)
+        return igemm(*a, **k)
 
     def spy(*a, **k):
         modes.append(k.get("mode", 0))
         return tile_conv(*a, **k)
-    hb._tile_conv = spy
+    hb._tile_conv, hb._igemm = spy, spy_igemm
     try:
         two = run(False)
-        assert not any(m >= 3 for m in modes)
-        del modes[:]
+        assert not any(m >= 3 for m in modes) and not any(affine)
+        del modes[:], affine[:]
         one = run(True)
     finally:
-        hb._tile_conv = tile_conv
+        hb._tile_conv, hb._igemm = tile_conv, igemm
+    assert sum(affine) == 2 * 3 * 3 and all(affine), affine       # the three implicit-GEMM problems, every call
     # two forwards x (ReLU, residual + ReLU, residual) x the four trunk problems went through the epilogue
     assert sum(m == 4 for m in modes) == 2 * 2 * 4 and sum(m == 3 for m in modes) == 2 * 4, modes
     for i, (a, b) in enumerate(zip(one, two)):
